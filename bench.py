@@ -1,0 +1,220 @@
+#!/usr/bin/env python3
+"""Benchmark of the candidate-bucket filter on MI355X: mapped reads/sec + % of the HBM roofline.
+
+    python bench.py --gpus 1 --steps 5 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path (sample kernel + vote kernel) over one batch of synthetic reads
+already resident in HBM.  Workload at N=1 = BASELINE.json configs[1]: Egu-like 1.70 Gbp synthetic
+genome cut into 65 536-bp buckets, `-f 1` index, 1 M x 300 bp simulated reads (sub 0.002,
+ins = del 0.00025), CLI-default parameters (k=12 q=9 S=15 e=0.4 -> F=6).  With N GPUs the index is
+replicated, every rank maps its own 1 M-read shard, and there is no collective on the data path
+(weak scaling); torch.distributed only provides the barrier and the max-over-ranks of the time.
+
+Rank 0 prints ONE JSON line.  `roofline` prices the vote kernel: algorithmic bytes = (index rows the
+reference ANDs, both orientations) x ceil(NB/8)   / mean kernel time from HIP events on
+the kernel's own stream.  `cpu_baseline` = the CPU oracle (a port: the reference cannot be built
+here) timed on one host core over a bounded sample of the same reads.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "bucket-map_amd", "python"))
+
+HBM_PEAK_GBPS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+WORKLOADS = {
+    # name: (total genome bp, bucket_len, read_len, reads per GPU)
+    "egu": (1_701_312_507, 65536, 300, 1_000_000),        # BASELINE.json configs[1] (headline)
+    "ecoli": (4_641_652, 65536, 150, 10_000),             # configs[0] geometry (plumbing)
+    "mini": (40_000_000, 65536, 300, 100_000),            # quick rehearsal
+}
+
+
+def egu_like_record_lengths(total):
+    """16 records of 100 Mbp + 916 records with lengths uniform in [10 kbp, 210 kbp]
+    (seed 20240002) rescaled so that the total is `total`."""
+    import numpy as np
+    big = [100_000_000] * 16
+    if total <= sum(big):
+        return [total]
+    rng = np.random.default_rng(20240002)
+    small = rng.integers(10_000, 210_001, 916).astype(np.float64)
+    rest = total - sum(big)
+    small = np.floor(small * (rest / small.sum())).astype(np.int64)
+    small[-1] += rest - small.sum()
+    return big + [int(x) for x in small]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="egu", choices=sorted(WORKLOADS))
+    ap.add_argument("--reads", type=int, default=0, help="reads per GPU (default: the workload's)")
+    ap.add_argument("--params", default="default", choices=["default", "bench"],
+                    help="default = CLI defaults (k12 q9 S15 F6); bench = benchmark_map.sh (-s 20 -e 0.6 -l 14 -b 10)")
+    ap.add_argument("--cpu-sample", type=int, default=20000, help="reads timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--host-threads", type=int, default=0)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+
+    # torch first: its bundled HIP runtime (soname libamdhip64.so.7) must be the one libbmf.so binds to,
+    # otherwise the process would hold two HIP runtimes.
+    import torch
+    import torch.distributed as dist
+    import numpy as np
+
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    import bucket_map_amd as bma
+    from bucket_map_amd import host
+
+    total_bp, bucket_len, read_len, n_reads = WORKLOADS[args.workload]
+    if args.reads:
+        n_reads = args.reads
+    threads = args.host_threads or max(1, (os.cpu_count() or 8) // world)
+    if args.params == "bench":
+        cli = dict(index_seed=9, query_seed=14, read_len=read_len, mapper_samples=20, max_error_rate=0.6,
+                   distinguishability=0.5, average_base_quality=10)
+    else:
+        cli = dict(index_seed=9, query_seed=12, read_len=read_len, mapper_samples=15, max_error_rate=0.4,
+                   distinguishability=0.5, average_base_quality=25)
+
+    def log(msg):
+        if rank == 0:
+            print(f"[bench] {msg}", file=sys.stderr, flush=True)
+
+    # ---------------- synthetic inputs, identical on every rank except the reads
+    t0 = time.perf_counter()
+    lens = egu_like_record_lengths(total_bp) if args.workload != "ecoli" else [total_bp]
+    genome = host.Genome.synth(20240001, lens, threads)
+    nb = genome.awk_bucket_num(bucket_len)
+    log(f"genome: {len(lens)} records, {genome.total_length()} bp, NB={nb} ({time.perf_counter() - t0:.1f}s)")
+    t0 = time.perf_counter()
+    index = host.Index(genome, nb, bucket_len, read_len, q=cli["index_seed"], kmer_frac=1.0, threads=threads)
+    row_bytes = index.row_bytes
+    log(f"index: {index.num_rows} rows x {row_bytes} B = {index.num_rows * row_bytes / 1e6:.1f} MB "
+        f"({time.perf_counter() - t0:.1f}s)")
+    t0 = time.perf_counter()
+    reads = host.Reads(genome, bucket_len, read_len, read_len, n_reads, sub=0.002, ins=0.00025, dele=0.00025,
+                       seed=20240003 + 7919 * rank, threads=threads)
+    log(f"reads: {reads.n} x {read_len} bp ({time.perf_counter() - t0:.1f}s)")
+
+    # ---------------- GPU side
+    params = bma.Params.from_cli(nb, device=local_rank, **cli)
+    flt = bma.Filter(params)
+    t0 = time.perf_counter()
+    flt.load_index_ptr(index.rows_ptr, index.num_rows, index.k2i_ptr, index.num_kmers)
+    log(f"index in HBM ({time.perf_counter() - t0:.1f}s), kernel variant {flt.info()}")
+    batch = flt.batch(reads.bases, reads.quals, reads.offsets)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        flt.sync()
+
+    for _ in range(args.warmup):
+        batch.run()
+    barrier()
+    flt.profile_begin(args.steps)
+    t_start = time.perf_counter()
+    for _ in range(args.steps):
+        batch.run()
+    flt.sync()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t_start
+    ms_sample, ms_vote = flt.profile_end(args.steps)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        dist.barrier()
+
+    rows_anded = batch.rows_anded()
+    counts, buckets = batch.download()
+
+    # ---------------- correctness properties at full size (size-independent)
+    strand = reads.truth_rc.astype(np.int64)
+    idx = np.arange(reads.n)
+    own = buckets[idx, strand]                                   # candidate list on the true strand
+    valid = np.arange(own.shape[1])[None, :] < counts[idx, strand][:, None]
+    recovered = float(((own == reads.truth_bucket[:, None]) & valid).any(axis=1).mean())
+    mapped = float((counts.sum(axis=1) > 0).mean())
+
+    result = None
+    if rank == 0:
+        reads_per_s = world * reads.n * args.steps / elapsed
+        vote_ms = float(np.mean(ms_vote))
+        algo_bytes_vote = rows_anded * row_bytes                 # rows ANDed x ceil(NB/8)
+        algo_bytes_read = algo_bytes_vote + 2 * int(reads.offsets[-1])
+        achieved = algo_bytes_vote / (vote_ms * 1e-3) / 1e9
+        result = {
+            "metric": "mapped reads/sec (1M x 300bp, 65536-bp-bucket index)",
+            "value": reads_per_s, "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+            "config": {
+                "workload": f"{args.workload}-like synthetic genome {genome.total_length()} bp, bucket_len {bucket_len}, "
+                            f"NB={nb}, -f 1 index ({index.num_rows} rows x {row_bytes} B), {reads.n} x {read_len} bp "
+                            f"simulated reads per GPU (sub 0.002, ins=del 0.00025), params {args.params} "
+                            f"(k={params.k} q={params.q} S={params.num_samples} F={params.num_fault})",
+                "reads_per_gpu": int(reads.n), "global_reads_per_step": int(world * reads.n),
+                "parallelism": f"reads sharded over {world} GPU(s), index replicated, no collective",
+            },
+            "roofline": {
+                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                "kernel": "bmf_vote_kernel", "kernel_ms": vote_ms, "algorithmic_bytes_per_launch": int(algo_bytes_vote),
+                "bytes_per_read": algo_bytes_read / reads.n, "sample_kernel_ms": float(np.mean(ms_sample)),
+            },
+            "checks": {"reads_with_candidates": mapped, "source_bucket_recovered": recovered},
+        }
+
+        # ---------------- CPU baseline (oracle = port of the reference algorithm, 1 thread) + parity sample
+        if args.cpu_sample > 0:
+            from oracle import oracle_c
+            n_cpu = min(args.cpu_sample, reads.n)
+            ora = oracle_c.Index(oracle_c.params_from_cli(nb, **cli), rows_ptr=index.rows_ptr, n_rows=index.num_rows,
+                                 k2i_ptr=index.k2i_ptr, n_kmers=index.num_kmers)
+            t0 = time.perf_counter()
+            c_ref, b_ref, rows_ref = ora.map_windows(reads.bases, reads.quals, reads.offsets[: n_cpu + 1])
+            cpu_s = time.perf_counter() - t0
+            same = bool(np.array_equal(c_ref, counts[:n_cpu]))
+            mask = np.arange(b_ref.shape[-1])[None, None, :] < c_ref[:, :, None]
+            same = same and bool(np.array_equal(b_ref[mask], buckets[:n_cpu][mask]))
+            result["cpu_baseline"] = {"value": n_cpu / cpu_s, "unit": "reads/s", "cores": 1, "kind": "port",
+                                      "sample": f"first {n_cpu} reads of the same batch, oracle/bm_oracle.c -O3, "
+                                                f"{cpu_s:.1f} s, {cpu_s / n_cpu * 1e6:.1f} us/read"}
+            result["checks"]["gpu_equals_oracle_on_sample"] = same
+            result["checks"]["parity_sample_reads"] = int(n_cpu)
+        else:
+            result["cpu_baseline"] = None
+        print(json.dumps(result), flush=True)
+
+    batch.close()
+    flt.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,547 @@
+// bmf_api.hip -- C ABI (include/bmf.h) over the gfx950 kernels in bmf_kernels.hip.h.
+//
+// Host-side responsibilities only: parameter validation, HBM layout of the index
+// (rows at a 128-byte pitch + one all-ones row), the fp64 sampler table (utils.h:160-178), launches
+// and HIP-event timing.  There is deliberately no CPU implementation of the filter in this library.
+#include "bmf_kernels.hip.h"
+
+#include "../../include/bmf.h"
+
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                             \
+    do {                                                                                          \
+        hipError_t e_ = (expr);                                                                   \
+        if (e_ != hipSuccess)                                                                     \
+            return fail(BMF_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, \
+                        __LINE__);                                                                \
+    } while (0)
+
+// SeqAn3 dna4 assign_char folding; built once, uploaded per context.
+void build_dna4_lut(uint8_t *lut) {
+    memset(lut, 0, 256);
+    const char *m[4] = {"AaRrWwMmDdHhVv", "CcYySsBb", "GgKk", "TtUu"};
+    for (int r = 0; r < 4; r++)
+        for (const char *c = m[r]; *c; c++) lut[(uint8_t)*c] = (uint8_t)r;
+}
+
+template <typename T>
+hipError_t dev_alloc(T **p, size_t n) {
+    return hipMalloc(reinterpret_cast<void **>(p), (n ? n : 1) * sizeof(T));
+}
+
+using vote_fn = void (*)(bmf::DevParams, const uint8_t *, const uint32_t *, const uint32_t *, uint32_t *,
+                         uint32_t *);
+
+constexpr int depth_for(int cpl) { return cpl <= 2 ? 8 : (cpl <= 4 ? 4 : 2); }
+
+template <int CPL>
+vote_fn pick_planes(int planes) {
+    constexpr int D = depth_for(CPL);
+    switch (planes) {
+    case 2: return bmf::bmf_vote_kernel<CPL, 2, D>;
+    case 3: return bmf::bmf_vote_kernel<CPL, 3, D>;
+    case 4: return bmf::bmf_vote_kernel<CPL, 4, D>;
+    case 5: return bmf::bmf_vote_kernel<CPL, 5, D>;
+    }
+    return nullptr;
+}
+
+vote_fn pick_vote(int cpl, int planes) {
+    switch (cpl) {
+    case 1: return pick_planes<1>(planes);
+    case 2: return pick_planes<2>(planes);
+    case 3: return pick_planes<3>(planes);
+    case 4: return pick_planes<4>(planes);
+    case 5: return pick_planes<5>(planes);
+    case 6: return pick_planes<6>(planes);
+    case 7: return pick_planes<7>(planes);
+    case 8: return pick_planes<8>(planes);
+    }
+    return nullptr;
+}
+
+}  // namespace
+
+struct bmf_batch {
+    uint32_t n_windows = 0;
+    uint64_t n_bytes = 0;
+    uint8_t *d_bases = nullptr, *d_quals = nullptr;
+    uint64_t *d_win_off = nullptr;
+    uint32_t *d_lists = nullptr, *d_list_n = nullptr, *d_rows_anded = nullptr;
+    uint32_t *d_counts = nullptr, *d_buckets = nullptr;
+};
+
+struct bmf_ctx {
+    bmf_params p{};
+    bmf::DevParams dp{};
+    hipStream_t stream = nullptr;
+    // index in HBM
+    bool loaded = false;
+    uint64_t n_rows = 0;
+    uint8_t *d_rows = nullptr;       // (n_rows + 1) x pitch ; row n_rows is all ones
+    int32_t *d_k2i = nullptr;
+    uint32_t *d_zeros = nullptr;
+    uint32_t *d_qgram_ok = nullptr;  // bitmap over 4^q q-grams
+    // constants
+    uint8_t *d_lut = nullptr;
+    uint16_t *d_pos_table = nullptr;
+    // kernel variant
+    int cpl = 0, planes = 0, depth = 0;
+    vote_fn vote = nullptr;
+    size_t sample_lds = 0;
+    // profiling
+    bool profiling = false;
+    uint32_t prof_max = 0, prof_n = 0;
+    std::vector<hipEvent_t> ev;      // 3 per run: before sample, between, after vote
+};
+
+extern "C" {
+
+int bmf_abi_version(void) { return BMF_ABI_VERSION; }
+const char *bmf_last_error(void) { return g_err; }
+
+// main.cpp:207 -- unsigned * float is a float32 product, then ceil
+uint32_t bmf_fault_from_rate(uint32_t samples, float max_error_rate) {
+    volatile float prod = (float)samples * max_error_rate;
+    return (uint32_t)ceil((double)prod);
+}
+// q_gram_mapper.h:163
+uint32_t bmf_threshold(float distinguishability, uint32_t num_buckets) {
+    volatile float prod = distinguishability * (float)num_buckets;
+    return (uint32_t)prod;
+}
+// bucket_locator.h:419-420
+uint32_t bmf_ceil_mul_f32(float rate, uint32_t n) {
+    volatile float prod = rate * (float)n;
+    return (uint32_t)ceil((double)prod);
+}
+
+int bmf_create(const bmf_params *params, bmf_ctx **out) {
+    if (!params || !out) return fail(BMF_ERR_ARG, "bmf_create: null argument");
+    *out = nullptr;
+    const bmf_params &p = *params;
+    if (p.num_buckets == 0) return fail(BMF_ERR_ARG, "num_buckets must be > 0");
+    if (p.q == 0 || p.q > 15 || p.k < p.q || p.k > 16)
+        return fail(BMF_ERR_ARG, "need 1 <= q <= 15 and q <= k <= 16 (got q=%u k=%u)", p.q, p.k);
+    if (p.num_samples == 0 || p.num_samples > 64)
+        return fail(BMF_ERR_UNSUPPORTED, "num_samples must be in 1..64 (got %u)", p.num_samples);
+    if (p.num_fault == 0 || p.num_fault > 31)
+        return fail(BMF_ERR_UNSUPPORTED, "num_fault must be in 1..31 (got %u)", p.num_fault);
+    if (p.max_candidates == 0 || p.max_candidates > 64)
+        return fail(BMF_ERR_UNSUPPORTED, "max_candidates must be in 1..64 (got %u)", p.max_candidates);
+    if (p.read_len < p.k || p.read_len > 16384)
+        return fail(BMF_ERR_UNSUPPORTED, "read_len must be in k..16384 (got %u)", p.read_len);
+    if (p.k - p.q + 1 > 8) return fail(BMF_ERR_UNSUPPORTED, "k-q+1 must be <= 8");
+
+    const uint32_t row_bytes = (p.num_buckets + 7u) >> 3;
+    const uint32_t n_chunks = (row_bytes + 15u) / 16u;
+    const int cpl = (int)((n_chunks + 63u) / 64u);
+    if (cpl > 8) return fail(BMF_ERR_UNSUPPORTED, "num_buckets > 65536 is not supported yet (got %u)", p.num_buckets);
+    int planes = 0;
+    while (((1u << planes) - 1u) < p.num_fault) planes++;
+    if (planes < 2) planes = 2;
+
+    int n_dev = 0;
+    HIP_TRY(hipGetDeviceCount(&n_dev));
+    if (p.device < 0 || p.device >= n_dev)
+        return fail(BMF_ERR_HIP, "device %d not available (%d HIP devices)", p.device, n_dev);
+    HIP_TRY(hipSetDevice(p.device));
+
+    bmf_ctx *c = new bmf_ctx();
+    c->p = p;
+    c->cpl = cpl;
+    c->planes = planes;
+    c->depth = depth_for(cpl);
+    c->vote = pick_vote(cpl, planes);
+    if (!c->vote) {
+        delete c;
+        return fail(BMF_ERR_UNSUPPORTED, "no vote kernel for cpl=%d planes=%d", cpl, planes);
+    }
+    bmf::DevParams &d = c->dp;
+    d.nb = p.num_buckets;
+    d.k = p.k;
+    d.q = p.q;
+    d.G = p.k - p.q + 1;
+    d.S = p.num_samples;
+    d.F = p.num_fault;
+    d.qbits = (uint32_t)((1ull << (2 * p.q)) - 1ull);
+    d.minq = p.min_base_quality;
+    // q_gram_mapper.h:445: reject iff (double)size < 0.2 * num_samples
+    d.min_good = 0;
+    while ((double)d.min_good < 0.2 * (double)p.num_samples) d.min_good++;
+    // (size()-1 underflows in the reference when nothing is good and S == 0 only; S >= 1 here, but
+    //  n_good == 0 must never reach the sampler.)
+    if (d.min_good == 0) d.min_good = 1;
+    d.max_cand = p.max_candidates;
+    d.read_len = p.read_len;
+    d.max_kmers = p.read_len - p.k + 1;
+    d.list_len = d.S * d.G;
+    d.n_chunks = n_chunks;
+    d.pitch = (row_bytes + 127u) & ~127u;
+    d.ones_row = 0;
+    d.n_kmers = 0;
+    c->sample_lds = ((2 * (size_t)p.read_len + 256 + 3) & ~(size_t)3) + 4 * (size_t)d.max_kmers;
+
+    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        delete c;
+        return fail(BMF_ERR_HIP, "hipStreamCreate failed: %s", hipGetErrorString(e));
+    }
+    // Sampler::sample_deterministically (utils.h:160-178) tabulated for every possible number of
+    // good k-mers n (upper_bound = n-1), in fp64 on the host so device rounding can never differ.
+    // upper_bound == 0: the reference skips re-sampling and reads out of bounds; we define it as
+    // S zeros (see DESIGN.md "deviations").
+    std::vector<uint16_t> tab((size_t)(d.max_kmers + 1) * d.S, 0);
+    for (uint32_t n = 1; n <= d.max_kmers; n++) {
+        const uint32_t ub = n - 1;
+        double delta = 0.0;
+        if (d.S != 1) delta = (double)(ub + 1u) / (double)(d.S - 1u);
+        for (uint32_t i = 0; i + 1 < d.S; i++) tab[(size_t)n * d.S + i] = (uint16_t)floor((double)i * delta);
+        tab[(size_t)n * d.S + d.S - 1] = (uint16_t)ub;
+    }
+    uint8_t lut[256];
+    build_dna4_lut(lut);
+    if (dev_alloc(&c->d_pos_table, tab.size()) != hipSuccess || dev_alloc(&c->d_lut, 256) != hipSuccess ||
+        hipMemcpy(c->d_pos_table, tab.data(), tab.size() * sizeof(uint16_t), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(c->d_lut, lut, 256, hipMemcpyHostToDevice) != hipSuccess) {
+        bmf_destroy(c);
+        return fail(BMF_ERR_HIP, "uploading sampler table failed: %s", hipGetErrorString(hipGetLastError()));
+    }
+    if (c->sample_lds > 48 * 1024) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(bmf::bmf_sample_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->sample_lds);
+        if (e != hipSuccess) {
+            bmf_destroy(c);
+            return fail(BMF_ERR_HIP, "cannot reserve %zu B of LDS: %s", c->sample_lds, hipGetErrorString(e));
+        }
+    }
+    *out = c;
+    return BMF_OK;
+}
+
+static void free_index(bmf_ctx *c) {
+    (void)hipFree(c->d_rows);
+    (void)hipFree(c->d_k2i);
+    (void)hipFree(c->d_zeros);
+    (void)hipFree(c->d_qgram_ok);
+    c->d_rows = nullptr;
+    c->d_k2i = nullptr;
+    c->d_zeros = nullptr;
+    c->d_qgram_ok = nullptr;
+    c->n_rows = 0;
+    c->loaded = false;
+}
+
+void bmf_destroy(bmf_ctx *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->p.device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
+    free_index(c);
+    (void)hipFree(c->d_lut);
+    (void)hipFree(c->d_pos_table);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int bmf_load_index(bmf_ctx *c, const uint8_t *rows, uint64_t n_rows, const int32_t *kmer_to_index,
+                   uint64_t n_kmers) {
+    if (!c) return fail(BMF_ERR_ARG, "bmf_load_index: null context");
+    // q_gram_mapper.h:325-328: "The q-gram index is not empty. Terminating load."
+    if (c->loaded) return fail(BMF_ERR_STATE, "the q-gram index is not empty; call bmf_reset first");
+    if (n_rows && !rows) return fail(BMF_ERR_ARG, "rows is null");
+    if (n_kmers && !kmer_to_index) return fail(BMF_ERR_ARG, "kmer_to_index is null");
+    if (n_kmers != 0 && n_kmers != (1ull << (2 * c->p.q)))
+        return fail(BMF_ERR_ARG, "kmer_to_index must have 4^q = %llu entries (got %llu)",
+                    (unsigned long long)(1ull << (2 * c->p.q)), (unsigned long long)n_kmers);
+    if (n_rows >= 0x7FFFFFFFull) return fail(BMF_ERR_ARG, "too many rows");
+    for (uint64_t i = 0; i < n_kmers; i++)
+        if (kmer_to_index[i] >= 0 && (uint64_t)kmer_to_index[i] >= n_rows)
+            return fail(BMF_ERR_ARG, "kmer_to_index[%llu] = %d is not a row (n_rows = %llu)", (unsigned long long)i,
+                        kmer_to_index[i], (unsigned long long)n_rows);
+    HIP_TRY(hipSetDevice(c->p.device));
+    const uint32_t pitch = c->dp.pitch, row_bytes = (c->p.num_buckets + 7u) >> 3;
+    const uint64_t n_words = ((1ull << (2 * c->p.q)) + 31) / 32;
+    HIP_TRY(dev_alloc(&c->d_rows, (size_t)(n_rows + 1) * pitch));
+    HIP_TRY(dev_alloc(&c->d_k2i, (size_t)n_kmers));
+    HIP_TRY(dev_alloc(&c->d_zeros, (size_t)n_rows));
+    HIP_TRY(dev_alloc(&c->d_qgram_ok, (size_t)n_words));
+    HIP_TRY(hipMemsetAsync(c->d_rows, 0, (size_t)n_rows * pitch, c->stream));
+    HIP_TRY(hipMemsetAsync(c->d_rows + (size_t)n_rows * pitch, 0xFF, pitch, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (n_rows) {
+        HIP_TRY(hipMemcpy2D(c->d_rows, pitch, rows, row_bytes, row_bytes, (size_t)n_rows, hipMemcpyHostToDevice));
+    }
+    if (n_kmers) HIP_TRY(hipMemcpy(c->d_k2i, kmer_to_index, (size_t)n_kmers * sizeof(int32_t), hipMemcpyHostToDevice));
+    c->n_rows = n_rows;
+    c->dp.ones_row = (uint32_t)n_rows;
+    c->dp.n_kmers = (uint32_t)n_kmers;
+    if (n_rows) {
+        hipLaunchKernelGGL(bmf::bmf_sanitize_rows_kernel, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, c->stream,
+                           c->d_rows, n_rows, pitch, c->p.num_buckets);
+        hipLaunchKernelGGL(bmf::bmf_zeros_kernel, dim3((unsigned)n_rows), dim3(bmf::kWave), 0, c->stream, c->d_rows,
+                           n_rows, pitch, c->p.num_buckets, c->d_zeros);
+    }
+    hipLaunchKernelGGL(bmf::bmf_qgram_ok_kernel, dim3((unsigned)((n_words + 255) / 256)), dim3(256), 0, c->stream,
+                       c->d_k2i, n_kmers, c->d_zeros, c->p.threshold, c->d_qgram_ok, n_words);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->loaded = true;
+    return BMF_OK;
+}
+
+int bmf_load_index_files(bmf_ctx *c, const char *index_dir, const char *indicator) {
+    if (!c || !index_dir || !indicator) return fail(BMF_ERR_ARG, "bmf_load_index_files: null argument");
+    if (c->loaded) return fail(BMF_ERR_STATE, "the q-gram index is not empty; call bmf_reset first");
+    const std::string base = std::string(index_dir) + "/" + indicator;
+    const uint64_t n_kmers = 1ull << (2 * c->p.q);
+    // q_gram_mapper.h:331-342: text file, 4^q integers
+    std::vector<int32_t> k2i(n_kmers);
+    uint64_t sampled = 0;
+    {
+        FILE *f = fopen((base + ".kmers_index").c_str(), "r");
+        if (!f) return fail(BMF_ERR_IO, "cannot open %s.kmers_index", base.c_str());
+        for (uint64_t i = 0; i < n_kmers; i++) {
+            int v;
+            if (fscanf(f, "%d", &v) != 1) {
+                fclose(f);
+                return fail(BMF_ERR_IO, "%s.kmers_index ends after %llu of %llu entries", base.c_str(),
+                            (unsigned long long)i, (unsigned long long)n_kmers);
+            }
+            k2i[i] = v;
+            if (v >= 0) sampled++;
+        }
+        fclose(f);
+    }
+    // q_gram_mapper.h:345-358: `sampled` rows of ceil(NB/8) bytes
+    const uint32_t row_bytes = (c->p.num_buckets + 7u) >> 3;
+    std::vector<uint8_t> rows((size_t)sampled * row_bytes);
+    {
+        FILE *f = fopen((base + ".qgram").c_str(), "rb");
+        if (!f) return fail(BMF_ERR_IO, "cannot open %s.qgram", base.c_str());
+        size_t got = fread(rows.data(), row_bytes, (size_t)sampled, f);
+        fclose(f);
+        if (got != sampled)
+            return fail(BMF_ERR_IO, "%s.qgram holds %zu rows of %u bytes, expected %llu", base.c_str(), got, row_bytes,
+                        (unsigned long long)sampled);
+    }
+    return bmf_load_index(c, rows.data(), sampled, k2i.data(), n_kmers);
+}
+
+int bmf_reset(bmf_ctx *c) {
+    if (!c) return fail(BMF_ERR_ARG, "bmf_reset: null context");
+    HIP_TRY(hipSetDevice(c->p.device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    free_index(c);
+    return BMF_OK;
+}
+
+int bmf_index_zeros(bmf_ctx *c, uint32_t *out_zeros) {
+    if (!c || !out_zeros) return fail(BMF_ERR_ARG, "bmf_index_zeros: null argument");
+    if (!c->loaded) return fail(BMF_ERR_STATE, "no index loaded");
+    HIP_TRY(hipSetDevice(c->p.device));
+    HIP_TRY(hipMemcpy(out_zeros, c->d_zeros, (size_t)c->n_rows * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return BMF_OK;
+}
+
+void bmf_batch_destroy(bmf_ctx *c, bmf_batch *b) {
+    if (!b) return;
+    if (c) {
+        (void)hipSetDevice(c->p.device);
+        (void)hipStreamSynchronize(c->stream);
+    }
+    (void)hipFree(b->d_bases);
+    (void)hipFree(b->d_quals);
+    (void)hipFree(b->d_win_off);
+    (void)hipFree(b->d_lists);
+    (void)hipFree(b->d_list_n);
+    (void)hipFree(b->d_rows_anded);
+    (void)hipFree(b->d_counts);
+    (void)hipFree(b->d_buckets);
+    delete b;
+}
+
+int bmf_batch_create(bmf_ctx *c, const uint8_t *bases, const uint8_t *quals, const uint64_t *win_off,
+                     uint32_t n_windows, bmf_batch **out) {
+    if (!c || !out || !win_off) return fail(BMF_ERR_ARG, "bmf_batch_create: null argument");
+    *out = nullptr;
+    if (n_windows > 0x3FFFFFFFu) return fail(BMF_ERR_ARG, "too many windows");
+    for (uint32_t w = 0; w < n_windows; w++) {
+        if (win_off[w + 1] < win_off[w]) return fail(BMF_ERR_ARG, "win_off is not monotonic at window %u", w);
+        if (win_off[w + 1] - win_off[w] > c->p.read_len)
+            return fail(BMF_ERR_ARG, "window %u is %llu bases long, more than read_len = %u", w,
+                        (unsigned long long)(win_off[w + 1] - win_off[w]), c->p.read_len);
+    }
+    const uint64_t lo = win_off[0], hi = win_off[n_windows];
+    if (hi > lo && (!bases || !quals)) return fail(BMF_ERR_ARG, "bases/quals is null");
+    HIP_TRY(hipSetDevice(c->p.device));
+    bmf_batch *b = new bmf_batch();
+    b->n_windows = n_windows;
+    b->n_bytes = hi - lo;
+    const size_t n = n_windows;
+    hipError_t e = hipSuccess;
+    auto ok = [&](hipError_t r) { if (e == hipSuccess) e = r; };
+    ok(dev_alloc(&b->d_bases, (size_t)b->n_bytes));
+    ok(dev_alloc(&b->d_quals, (size_t)b->n_bytes));
+    ok(dev_alloc(&b->d_win_off, n + 1));
+    ok(dev_alloc(&b->d_lists, 2 * n * c->dp.list_len));
+    ok(dev_alloc(&b->d_list_n, n));
+    ok(dev_alloc(&b->d_rows_anded, n));
+    ok(dev_alloc(&b->d_counts, 2 * n));
+    ok(dev_alloc(&b->d_buckets, 2 * n * c->p.max_candidates));
+    if (e == hipSuccess && b->n_bytes) {
+        ok(hipMemcpy(b->d_bases, bases + lo, (size_t)b->n_bytes, hipMemcpyHostToDevice));
+        ok(hipMemcpy(b->d_quals, quals + lo, (size_t)b->n_bytes, hipMemcpyHostToDevice));
+    }
+    if (e == hipSuccess) {
+        // offsets relative to the uploaded slice
+        std::vector<uint64_t> rel(n + 1);
+        for (size_t w = 0; w <= n; w++) rel[w] = win_off[w] - lo;
+        ok(hipMemcpy(b->d_win_off, rel.data(), (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice));
+    }
+    if (e != hipSuccess) {
+        bmf_batch_destroy(c, b);
+        return fail(BMF_ERR_HIP, "bmf_batch_create: %s", hipGetErrorString(e));
+    }
+    *out = b;
+    return BMF_OK;
+}
+
+int bmf_batch_run(bmf_ctx *c, bmf_batch *b) {
+    if (!c || !b) return fail(BMF_ERR_ARG, "bmf_batch_run: null argument");
+    // q_gram_mapper.h:389-393: "The q-gram index is empty. Cannot accept query."
+    if (!c->loaded) return fail(BMF_ERR_STATE, "the q-gram index is empty; cannot accept query");
+    if (b->n_windows == 0) return BMF_OK;
+    HIP_TRY(hipSetDevice(c->p.device));
+    const bool prof = c->profiling && c->prof_n < c->prof_max;
+    hipEvent_t *ev = prof ? &c->ev[(size_t)3 * c->prof_n] : nullptr;
+    if (prof) HIP_TRY(hipEventRecord(ev[0], c->stream));
+    hipLaunchKernelGGL(bmf::bmf_sample_kernel, dim3(b->n_windows), dim3(bmf::kWave), c->sample_lds, c->stream, c->dp,
+                       b->d_bases, b->d_quals, b->d_win_off, c->d_lut, c->d_qgram_ok, c->d_k2i, c->d_pos_table,
+                       b->d_lists, b->d_list_n, b->d_rows_anded);
+    if (prof) HIP_TRY(hipEventRecord(ev[1], c->stream));
+    hipLaunchKernelGGL(c->vote, dim3(2 * b->n_windows), dim3(bmf::kWave), 0, c->stream, c->dp, c->d_rows, b->d_lists,
+                       b->d_list_n, b->d_counts, b->d_buckets);
+    if (prof) {
+        HIP_TRY(hipEventRecord(ev[2], c->stream));
+        c->prof_n++;
+    }
+    HIP_TRY(hipGetLastError());
+    return BMF_OK;
+}
+
+int bmf_sync(bmf_ctx *c) {
+    if (!c) return fail(BMF_ERR_ARG, "bmf_sync: null context");
+    HIP_TRY(hipSetDevice(c->p.device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return BMF_OK;
+}
+
+int bmf_batch_download(bmf_ctx *c, bmf_batch *b, uint32_t *out_counts, uint32_t *out_buckets) {
+    if (!c || !b || !out_counts || !out_buckets) return fail(BMF_ERR_ARG, "bmf_batch_download: null argument");
+    HIP_TRY(hipSetDevice(c->p.device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    const size_t n = b->n_windows;
+    if (n == 0) return BMF_OK;
+    HIP_TRY(hipMemcpy(out_counts, b->d_counts, 2 * n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    // The device buffer is dense (max_candidates slots per list); only `count` slots are defined, so
+    // copy through a staging buffer and hand over exactly the defined entries.
+    std::vector<uint32_t> tmp(2 * n * c->p.max_candidates);
+    HIP_TRY(hipMemcpy(tmp.data(), b->d_buckets, tmp.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    const uint32_t mc = c->p.max_candidates;
+    for (size_t i = 0; i < 2 * n; i++) {
+        if (out_counts[i] > mc) return fail(BMF_ERR_HIP, "device returned count %u > max_candidates", out_counts[i]);
+        memcpy(out_buckets + i * mc, tmp.data() + i * mc, out_counts[i] * sizeof(uint32_t));
+    }
+    return BMF_OK;
+}
+
+int bmf_batch_rows_anded(bmf_ctx *c, bmf_batch *b, uint64_t *out) {
+    if (!c || !b || !out) return fail(BMF_ERR_ARG, "bmf_batch_rows_anded: null argument");
+    HIP_TRY(hipSetDevice(c->p.device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    std::vector<uint32_t> tmp(b->n_windows);
+    if (b->n_windows)
+        HIP_TRY(hipMemcpy(tmp.data(), b->d_rows_anded, tmp.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    uint64_t s = 0;
+    for (uint32_t v : tmp) s += v;
+    *out = s;
+    return BMF_OK;
+}
+
+int bmf_map_windows(bmf_ctx *c, const uint8_t *bases, const uint8_t *quals, const uint64_t *win_off,
+                    uint32_t n_windows, uint32_t *out_counts, uint32_t *out_buckets) {
+    if (!c) return fail(BMF_ERR_ARG, "bmf_map_windows: null context");
+    if (!c->loaded) return fail(BMF_ERR_STATE, "the q-gram index is empty; cannot accept query");
+    if (n_windows == 0) return BMF_OK;
+    if (!out_counts || !out_buckets) return fail(BMF_ERR_ARG, "bmf_map_windows: null output");
+    bmf_batch *b = nullptr;
+    int rc = bmf_batch_create(c, bases, quals, win_off, n_windows, &b);
+    if (rc != BMF_OK) return rc;
+    rc = bmf_batch_run(c, b);
+    if (rc == BMF_OK) rc = bmf_batch_download(c, b, out_counts, out_buckets);
+    bmf_batch_destroy(c, b);
+    return rc;
+}
+
+int bmf_profile_begin(bmf_ctx *c, uint32_t max_runs) {
+    if (!c) return fail(BMF_ERR_ARG, "bmf_profile_begin: null context");
+    HIP_TRY(hipSetDevice(c->p.device));
+    while (c->ev.size() < (size_t)3 * max_runs) {
+        hipEvent_t e;
+        HIP_TRY(hipEventCreate(&e));
+        c->ev.push_back(e);
+    }
+    c->prof_max = max_runs;
+    c->prof_n = 0;
+    c->profiling = true;
+    return BMF_OK;
+}
+
+int bmf_profile_end(bmf_ctx *c, uint32_t *n_runs, float *ms_sample, float *ms_vote) {
+    if (!c || !n_runs) return fail(BMF_ERR_ARG, "bmf_profile_end: null argument");
+    HIP_TRY(hipSetDevice(c->p.device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->profiling = false;
+    *n_runs = c->prof_n;
+    for (uint32_t i = 0; i < c->prof_n; i++) {
+        float a = 0, b = 0;
+        HIP_TRY(hipEventElapsedTime(&a, c->ev[3 * i], c->ev[3 * i + 1]));
+        HIP_TRY(hipEventElapsedTime(&b, c->ev[3 * i + 1], c->ev[3 * i + 2]));
+        if (ms_sample) ms_sample[i] = a;
+        if (ms_vote) ms_vote[i] = b;
+    }
+    return BMF_OK;
+}
+
+int bmf_info(bmf_ctx *c, uint32_t *row_pitch_bytes, uint32_t *chunks_per_lane, uint32_t *planes,
+             uint32_t *rows_in_flight) {
+    if (!c) return fail(BMF_ERR_ARG, "bmf_info: null context");
+    if (row_pitch_bytes) *row_pitch_bytes = c->dp.pitch;
+    if (chunks_per_lane) *chunks_per_lane = (uint32_t)c->cpl;
+    if (planes) *planes = (uint32_t)c->planes;
+    if (rows_in_flight) *rows_in_flight = (uint32_t)c->depth;
+    return BMF_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,370 @@
+// bmf_kernels.hip.h -- gfx950 kernels of the candidate-bucket filter.
+//
+// Two kernels per batch of read windows:
+//   bmf_sample_kernel : one wave per window.  k-mer hashes, quality window sums, distinguishability +
+//                       quality filter, ordered compaction, deterministic sampling, q-gram -> row-id
+//                       lists for both orientations (reference: q_gram_mapper.h:431-469).
+//   bmf_vote_kernel   : one wave per (window, orientation).  Streams the S*G index rows of the list
+//                       through a DEPTH-deep register ring of 16-byte-per-lane loads, ANDs the G rows
+//                       of each sample, keeps the per-bucket miss count bit-sliced in VGPRs, then
+//                       finds the minimum and emits the ascending bucket ids
+//                       (reference: q_gram_mapper.h:380-412 + fault_tolerate_filter :59-102).
+//
+// Formulation (differs from the reference on purpose; SURVEY.md 3.3 proves equivalence): the
+// reference keeps F unary bit-planes lvl[i][b] == (misses(b) <= F-1-i).  Here misses(b) is kept as a
+// PLANES-bit binary counter per bucket, bit-sliced across PLANES registers and saturating at
+// 2^PLANES-1 >= F, so the result "buckets with the fewest misses, if that minimum is < F" is read off
+// with a most-significant-plane-first minimum search.  Integer / bit work only: no MFMA.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace bmf {
+
+constexpr int kWave = 64;
+
+struct DevParams {
+    uint32_t nb;         // NB
+    uint32_t k, q, G;    // G = k-q+1 q-grams per k-mer
+    uint32_t S, F;
+    uint32_t qbits;      // 4^q - 1
+    uint32_t minq;       // min_base_quality = b*k
+    uint32_t min_good;   // smallest #good k-mers that is NOT rejected by `size < 0.2*S` (fp64, host)
+    uint32_t max_cand;
+    uint32_t read_len;
+    uint32_t max_kmers;  // read_len - k + 1
+    uint32_t list_len;   // S*G : row ids per (window, orientation)
+    uint32_t n_chunks;   // ceil(ceil(NB/8)/16) : 16-byte chunks per row that hold buckets
+    uint32_t pitch;      // bytes between rows in HBM (multiple of 128)
+    uint32_t ones_row;   // id of the all-ones row appended after the index (for un-indexed q-grams)
+    uint32_t n_kmers;    // entries of kmer_to_index (4^q, or 0 when no .kmers_index was loaded)
+};
+
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, kWave);
+    return v;
+}
+
+// utils.h:291-302
+__device__ __forceinline__ uint32_t hash_reverse_complement(uint32_t h, uint32_t k) {
+    uint32_t rc = 0;
+    for (uint32_t i = 0; i < k; i++) {
+        rc = (rc << 2) | ((~h) & 3u);
+        h >>= 2;
+    }
+    return rc;
+}
+
+// --------------------------------------------------------------------------------------------------
+// index preparation (mapper::load side)
+// --------------------------------------------------------------------------------------------------
+
+// Clears the bits >= NB of the last index byte of every row (the reference's _bitset_from_bytes,
+// q_gram_mapper.h:238-248, never reads them) so popcounts and ANDs see exactly NB bits.
+__global__ void bmf_sanitize_rows_kernel(uint8_t *rows, uint64_t n_rows, uint32_t pitch, uint32_t nb) {
+    uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_rows || (nb & 7u) == 0) return;
+    uint32_t last = ((nb + 7u) >> 3) - 1u;
+    rows[r * pitch + last] &= (uint8_t)(0xFFu >> (8u - (nb & 7u)));
+}
+
+// distinguishability_filter::read (q_gram_mapper.h:171-187): zeros[row] = NB - popcount(row).
+// One wave per row, coalesced dword reads.
+__global__ __launch_bounds__(kWave) void bmf_zeros_kernel(const uint8_t *rows, uint64_t n_rows, uint32_t pitch,
+                                                         uint32_t nb, uint32_t *zeros) {
+    uint64_t r = blockIdx.x;
+    if (r >= n_rows) return;
+    const uint32_t *row = reinterpret_cast<const uint32_t *>(rows + r * pitch);
+    uint32_t n_dw = pitch >> 2, ones = 0;
+    for (uint32_t i = threadIdx.x; i < n_dw; i += kWave) ones += __popc(row[i]);
+    ones = wave_sum(ones);
+    if (threadIdx.x == 0) zeros[r] = nb - ones;   // ones == 0 -> NB, as the reference's special case
+}
+
+// Bitmap over all 4^q q-grams: bit g set iff the q-gram is indexed and its row has
+// zeros >= threshold (the per-q-gram half of is_highly_distinguishable, q_gram_mapper.h:189-196).
+__global__ void bmf_qgram_ok_kernel(const int32_t *k2i, uint64_t n_kmers, const uint32_t *zeros,
+                                    uint32_t threshold, uint32_t *bitmap, uint64_t n_words) {
+    uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= n_words) return;
+    uint32_t bits = 0;
+    for (uint32_t b = 0; b < 32; b++) {
+        uint64_t g = w * 32 + b;
+        if (g < n_kmers) {
+            int32_t idx = k2i[g];
+            if (idx >= 0 && zeros[idx] >= threshold) bits |= 1u << b;
+        }
+    }
+    bitmap[w] = bits;
+}
+
+// --------------------------------------------------------------------------------------------------
+// sample kernel: q_gram_mapper::query_sequence up to (not including) the two query() calls
+// --------------------------------------------------------------------------------------------------
+//
+// LDS layout (dynamic): lut[256] u8 | code[read_len] u8 | qrank[read_len] u8 | pad to 4 |
+//                       goodh[max_kmers] u32
+__global__ __launch_bounds__(kWave) void bmf_sample_kernel(
+    DevParams P, const uint8_t *__restrict__ bases, const uint8_t *__restrict__ quals,
+    const uint64_t *__restrict__ win_off, const uint8_t *__restrict__ dna4_lut,
+    const uint32_t *__restrict__ qgram_ok, const int32_t *__restrict__ k2i,
+    const uint16_t *__restrict__ pos_table, uint32_t *__restrict__ row_lists,
+    uint32_t *__restrict__ list_n, uint32_t *__restrict__ rows_anded) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint8_t *lut = smem;
+    uint8_t *code = smem + 256;
+    uint8_t *qrank = code + P.read_len;
+    uint32_t *goodh = reinterpret_cast<uint32_t *>(smem + ((2 * P.read_len + 256 + 3) & ~3u));
+
+    const uint32_t w = blockIdx.x;
+    const uint32_t lane = threadIdx.x;
+    const uint64_t off = win_off[w];
+    const uint32_t len = (uint32_t)(win_off[w + 1] - off);
+
+    reinterpret_cast<uint32_t *>(lut)[lane] = reinterpret_cast<const uint32_t *>(dna4_lut)[lane];
+    __syncthreads();
+    for (uint32_t i = lane; i < len; i += kWave) {
+        code[i] = lut[bases[off + i]];
+        qrank[i] = (uint8_t)(quals[off + i] - 33u);   // phred94 rank (utils.h:192-204)
+    }
+    __syncthreads();
+
+    // k-mers j = 0 .. len-k (views::kmer_hash: size max(len+1,k)-k), 64 per round
+    const uint32_t nk = len >= P.k ? len - P.k + 1 : 0;
+    uint32_t n_good = 0;
+    for (uint32_t base = 0; base < nk; base += kWave) {
+        const uint32_t j = base + lane;
+        bool good = false;
+        uint32_t h = 0;
+        if (j < nk) {
+            uint32_t qs = 0;
+            for (uint32_t t = 0; t < P.k; t++) {
+                h = (h << 2) | code[j + t];
+                qs += qrank[j + t];                     // quality_filter.h:611-621 (plain sum)
+            }
+            bool dist = false;                          // q_gram_mapper.h:189-196
+            for (uint32_t g = 0; g < P.G; g++) {
+                uint32_t qg = (h >> (2 * g)) & P.qbits;
+                dist = dist || ((qgram_ok[qg >> 5] >> (qg & 31u)) & 1u);
+            }
+            good = dist && qs >= P.minq;                // q_gram_mapper.h:437-438
+        }
+        const uint64_t m = __ballot(good);
+        if (good) goodh[n_good + __popcll(m & ((1ull << lane) - 1ull))] = h;   // ascending j
+        n_good += (uint32_t)__popcll(m);
+    }
+    __syncthreads();
+
+    // q_gram_mapper.h:445: too few good k-mers -> both candidate lists empty
+    if (n_good < P.min_good) {
+        if (lane == 0) {
+            list_n[w] = 0;
+            rows_anded[w] = 0;
+        }
+        return;
+    }
+
+    // q_gram_mapper.h:457-469: deterministic sample, then the reverse complements of the SAME
+    // sampled hashes in the same order; each sample expands to its G contained q-grams' rows.
+    uint32_t *list_fwd = row_lists + (size_t)(2 * w) * P.list_len;
+    uint32_t *list_rc = list_fwd + P.list_len;
+    uint32_t cnt = 0;
+    for (uint32_t s = lane; s < P.S; s += kWave) {
+        const uint32_t p = pos_table[(size_t)n_good * P.S + s];
+        const uint32_t h = goodh[p];
+        const uint32_t hr = hash_reverse_complement(h, P.k);
+        for (uint32_t g = 0; g < P.G; g++) {
+            const uint32_t g1 = (h >> (2 * g)) & P.qbits, g2 = (hr >> (2 * g)) & P.qbits;
+            const int32_t i1 = g1 < P.n_kmers ? k2i[g1] : -1;   // index_of_kmer, q_gram_mapper.h:374-377
+            const int32_t i2 = g2 < P.n_kmers ? k2i[g2] : -1;
+            list_fwd[s * P.G + g] = i1 >= 0 ? (uint32_t)i1 : P.ones_row;
+            list_rc[s * P.G + g] = i2 >= 0 ? (uint32_t)i2 : P.ones_row;
+            cnt += (i1 >= 0) + (i2 >= 0);
+        }
+    }
+    cnt = wave_sum(cnt);
+    if (lane == 0) {
+        list_n[w] = P.list_len;
+        rows_anded[w] = cnt;
+    }
+}
+
+// --------------------------------------------------------------------------------------------------
+// vote kernel
+// --------------------------------------------------------------------------------------------------
+
+struct u128 {
+    uint32_t v[4];
+};
+
+__device__ __forceinline__ u128 load_chunk(const uint8_t *p) {
+    const uint4 t = *reinterpret_cast<const uint4 *>(p);
+    u128 r;
+    r.v[0] = t.x; r.v[1] = t.y; r.v[2] = t.z; r.v[3] = t.w;
+    return r;
+}
+
+// CPL   : 16-byte chunks per lane (lane l owns chunks l, l+64, ...: every load is 1 KiB contiguous)
+// PLANES: bits of the saturating per-bucket miss counter, 2^PLANES-1 >= F
+// DEPTH : index rows in flight per wave (register ring)
+template <int CPL, int PLANES, int DEPTH>
+__global__ __launch_bounds__(kWave) void bmf_vote_kernel(DevParams P, const uint8_t *__restrict__ rows,
+                                                        const uint32_t *__restrict__ row_lists,
+                                                        const uint32_t *__restrict__ list_n,
+                                                        uint32_t *__restrict__ out_counts,
+                                                        uint32_t *__restrict__ out_buckets) {
+    const uint32_t item = blockIdx.x;          // 2*window + orientation
+    const uint32_t lane = threadIdx.x;
+    const uint32_t n = list_n[item >> 1];      // S*G, or 0 for a rejected window
+    if (n == 0) {
+        if (lane == 0) out_counts[item] = 0;
+        return;
+    }
+    const uint32_t *__restrict__ list = row_lists + (size_t)item * P.list_len;
+
+    uint32_t coff[CPL];
+    bool cval[CPL];
+#pragma unroll
+    for (int j = 0; j < CPL; j++) {
+        const uint32_t c = lane + kWave * j;
+        cval[j] = c < P.n_chunks;
+        coff[j] = c * 16u;
+    }
+
+    u128 ring[DEPTH][CPL];
+#pragma unroll
+    for (int d = 0; d < DEPTH; d++) {
+        if ((uint32_t)d < n) {
+            const uint8_t *rp = rows + (size_t)list[d] * P.pitch;
+#pragma unroll
+            for (int j = 0; j < CPL; j++)
+                if (cval[j]) ring[d][j] = load_chunk(rp + coff[j]);
+        }
+    }
+
+    u128 bf[CPL];             // AND of the current sample's rows (q_gram_mapper.h:400-406)
+    u128 cnt[PLANES][CPL];    // bit-sliced miss counters
+#pragma unroll
+    for (int j = 0; j < CPL; j++)
+#pragma unroll
+        for (int x = 0; x < 4; x++) {
+            bf[j].v[x] = 0xFFFFFFFFu;
+#pragma unroll
+            for (int p = 0; p < PLANES; p++) cnt[p][j].v[x] = 0;
+        }
+
+    uint32_t g = 0;
+    for (uint32_t i = 0; i < n; i += DEPTH) {
+#pragma unroll
+        for (int d = 0; d < DEPTH; d++) {
+            if (i + d < n) {
+                u128 cur[CPL];
+#pragma unroll
+                for (int j = 0; j < CPL; j++) cur[j] = ring[d][j];
+                // refill this ring slot with the row DEPTH positions ahead
+                if (i + d + DEPTH < n) {
+                    const uint8_t *rp = rows + (size_t)list[i + d + DEPTH] * P.pitch;
+#pragma unroll
+                    for (int j = 0; j < CPL; j++)
+                        if (cval[j]) ring[d][j] = load_chunk(rp + coff[j]);
+                }
+#pragma unroll
+                for (int j = 0; j < CPL; j++)
+#pragma unroll
+                    for (int x = 0; x < 4; x++) bf[j].v[x] &= cur[j].v[x];
+                if (++g == P.G) {
+                    // fault_tolerate_filter::read (q_gram_mapper.h:75-88) in counter form:
+                    // every bucket whose AND-ed bit is 0 takes one more miss (saturating).
+                    g = 0;
+#pragma unroll
+                    for (int j = 0; j < CPL; j++)
+#pragma unroll
+                        for (int x = 0; x < 4; x++) {
+                            uint32_t sat = cnt[0][j].v[x];
+#pragma unroll
+                            for (int p = 1; p < PLANES; p++) sat &= cnt[p][j].v[x];
+                            uint32_t carry = ~(bf[j].v[x] | sat);
+#pragma unroll
+                            for (int p = 0; p < PLANES; p++) {
+                                const uint32_t t = cnt[p][j].v[x] & carry;
+                                cnt[p][j].v[x] ^= carry;
+                                carry = t;
+                            }
+                            bf[j].v[x] = 0xFFFFFFFFu;
+                        }
+                }
+            }
+        }
+    }
+
+    // best_results (q_gram_mapper.h:90-102): buckets with the minimum miss count, if it is < F.
+    // Only bits < NB are buckets (std::bitset<NB>); lanes past the row hold nothing.
+    u128 cand[CPL];
+#pragma unroll
+    for (int j = 0; j < CPL; j++)
+#pragma unroll
+        for (int x = 0; x < 4; x++) {
+            const uint32_t b0 = (lane + kWave * j) * 128u + x * 32u;
+            uint32_t m = 0;
+            if (cval[j] && b0 < P.nb) m = (P.nb - b0 >= 32u) ? 0xFFFFFFFFu : ((1u << (P.nb - b0)) - 1u);
+            cand[j].v[x] = m;
+        }
+    uint32_t m_min = 0;
+#pragma unroll
+    for (int p = PLANES - 1; p >= 0; p--) {
+        uint32_t any = 0;
+#pragma unroll
+        for (int j = 0; j < CPL; j++)
+#pragma unroll
+            for (int x = 0; x < 4; x++) any |= cand[j].v[x] & ~cnt[p][j].v[x];
+        if (__ballot(any != 0) != 0) {   // some candidate has a 0 in this plane: the minimum does too
+#pragma unroll
+            for (int j = 0; j < CPL; j++)
+#pragma unroll
+                for (int x = 0; x < 4; x++) cand[j].v[x] &= ~cnt[p][j].v[x];
+        } else {
+            m_min |= 1u << p;
+        }
+    }
+
+    uint32_t pc[CPL], mine = 0;
+#pragma unroll
+    for (int j = 0; j < CPL; j++) {
+        pc[j] = __popc(cand[j].v[0]) + __popc(cand[j].v[1]) + __popc(cand[j].v[2]) + __popc(cand[j].v[3]);
+        mine += pc[j];
+    }
+    const uint32_t total = wave_sum(mine);
+    // m_min >= F: every level of the reference's filter is empty.  total > max_cand: cleared
+    // (q_gram_mapper.h:471-476).
+    if (m_min >= P.F || total > P.max_cand) {
+        if (lane == 0) out_counts[item] = 0;
+        return;
+    }
+    uint32_t *__restrict__ out = out_buckets + (size_t)item * P.max_cand;
+    uint32_t base = 0;
+#pragma unroll
+    for (int j = 0; j < CPL; j++) {
+        if (__ballot(pc[j] != 0) == 0) continue;
+        uint32_t incl = pc[j];
+#pragma unroll
+        for (int o = 1; o < kWave; o <<= 1) {
+            const uint32_t t = __shfl_up(incl, o, kWave);
+            if (lane >= (uint32_t)o) incl += t;
+        }
+        uint32_t pos = base + incl - pc[j];
+        base += __shfl(incl, kWave - 1, kWave);
+#pragma unroll
+        for (int x = 0; x < 4; x++) {
+            uint32_t bits = cand[j].v[x];
+            while (bits) {
+                out[pos++] = (lane + kWave * j) * 128u + x * 32u + (uint32_t)__builtin_ctz(bits);
+                bits &= bits - 1u;
+            }
+        }
+    }
+    if (lane == 0) out_counts[item] = total;
+}
+
+}  // namespace bmf

@@ -1,0 +1,118 @@
+// bm_host_api.cpp -- C ABI over the host plumbing (libbmhost.so): synthetic genomes, FASTA I/O, bucket
+// cutting, the host indexer and the read simulator.  Used by tests/ and bench.py through ctypes; the
+// C++ command-line tool links the same headers directly.  No GPU code here.
+#include "bm_genome.h"
+#include "bm_indexer.h"
+#include "bm_synth.h"
+
+#include <cstdarg>
+#include <cstdio>
+
+namespace {
+thread_local char g_err[512] = "";
+void set_err(const char *what) { snprintf(g_err, sizeof g_err, "%s", what); }
+}  // namespace
+
+struct bmh_genome { bm::Genome g; };
+struct bmh_index { bm::QgramIndex ix; };
+struct bmh_reads { bm::SimReads rd; };
+
+#define BMH_GUARD(ret_on_error, ...)                  \
+    try { __VA_ARGS__ } catch (const std::exception &e) { \
+        set_err(e.what());                            \
+        return ret_on_error;                          \
+    }
+
+extern "C" {
+
+const char *bmh_last_error(void) { return g_err; }
+
+bmh_genome *bmh_genome_synth(uint64_t seed, const uint64_t *record_lengths, uint32_t n_records, uint32_t threads) {
+    BMH_GUARD(nullptr, {
+        std::vector<uint64_t> lens(record_lengths, record_lengths + n_records);
+        auto *h = new bmh_genome();
+        h->g = bm::synth_genome(seed, lens, threads);
+        return h;
+    })
+}
+
+bmh_genome *bmh_genome_read_fasta(const char *path) {
+    BMH_GUARD(nullptr, {
+        auto *h = new bmh_genome();
+        h->g = bm::read_fasta(path);
+        return h;
+    })
+}
+
+int bmh_genome_write_fasta(const bmh_genome *g, const char *path) {
+    BMH_GUARD(1, { bm::write_fasta(g->g, path); return 0; })
+}
+
+void bmh_genome_free(bmh_genome *g) { delete g; }
+uint32_t bmh_genome_records(const bmh_genome *g) { return static_cast<uint32_t>(g->g.seqs.size()); }
+uint64_t bmh_genome_record_len(const bmh_genome *g, uint32_t i) { return g->g.seqs[i].size(); }
+const char *bmh_genome_record_id(const bmh_genome *g, uint32_t i) { return g->g.ids[i].c_str(); }
+const char *bmh_genome_record_seq(const bmh_genome *g, uint32_t i) { return g->g.seqs[i].data(); }
+
+// BM_BUCKET_NUM as bucket_map/CMakeLists.txt:13-46 computes it
+uint32_t bmh_awk_bucket_num(const bmh_genome *g, uint32_t bucket_len) { return bm::awk_bucket_num(g->g, bucket_len); }
+
+// utils.h:72-97.  out (may be NULL) receives 4 u32 per kept bucket: record, index, start, end.
+uint32_t bmh_cut_buckets(const bmh_genome *g, uint32_t bucket_len, uint32_t read_len, uint32_t *out) {
+    auto b = bm::cut_buckets(g->g, static_cast<int>(bucket_len), static_cast<int>(read_len));
+    if (out)
+        for (size_t i = 0; i < b.size(); i++) {
+            out[4 * i] = b[i].record; out[4 * i + 1] = b[i].index; out[4 * i + 2] = b[i].start; out[4 * i + 3] = b[i].end;
+        }
+    return static_cast<uint32_t>(b.size());
+}
+
+bmh_index *bmh_index_build(const bmh_genome *g, uint32_t num_buckets, uint32_t bucket_len, uint32_t read_len,
+                           uint32_t q, float kmer_frac, uint64_t hash_seed, uint32_t threads) {
+    BMH_GUARD(nullptr, {
+        auto *h = new bmh_index();
+        h->ix = bm::build_index(g->g, num_buckets, static_cast<int>(bucket_len), static_cast<int>(read_len), q,
+                                bm::FracMinHash::from_seed(hash_seed), kmer_frac, threads);
+        return h;
+    })
+}
+void bmh_index_free(bmh_index *ix) { delete ix; }
+uint64_t bmh_index_num_rows(const bmh_index *ix) { return ix->ix.num_rows; }
+uint32_t bmh_index_row_bytes(const bmh_index *ix) { return ix->ix.row_bytes; }
+const uint8_t *bmh_index_rows(const bmh_index *ix) { return ix->ix.rows.data(); }
+const int32_t *bmh_index_kmer_to_index(const bmh_index *ix) { return ix->ix.kmer_to_index.data(); }
+uint64_t bmh_index_num_kmers(const bmh_index *ix) { return ix->ix.kmer_to_index.size(); }
+int bmh_index_write(const bmh_index *ix, const char *dir, const char *indicator) {
+    BMH_GUARD(1, { bm::write_index(ix->ix, dir, indicator); return 0; })
+}
+
+// qmode: 0 = all 'E' (as the reference's simulator), 1 = noisy qualities
+bmh_reads *bmh_reads_simulate(const bmh_genome *g, uint32_t bucket_len, uint32_t index_read_len, uint32_t read_len,
+                              uint64_t n_reads, double sub_rate, double ins_rate, double del_rate, uint64_t seed,
+                              uint32_t qmode, uint32_t threads) {
+    BMH_GUARD(nullptr, {
+        auto buckets = bm::cut_buckets(g->g, static_cast<int>(bucket_len), static_cast<int>(index_read_len));
+        auto *h = new bmh_reads();
+        h->rd = bm::simulate_reads(g->g, buckets, read_len, n_reads, sub_rate, ins_rate, del_rate, seed,
+                                   qmode ? bm::QUAL_NOISY : bm::QUAL_ALL_E, threads);
+        return h;
+    })
+}
+void bmh_reads_free(bmh_reads *r) { delete r; }
+uint64_t bmh_reads_count(const bmh_reads *r) { return r->rd.size(); }
+const uint8_t *bmh_reads_bases(const bmh_reads *r) { return r->rd.bases.data(); }
+const uint8_t *bmh_reads_quals(const bmh_reads *r) { return r->rd.quals.data(); }
+const uint64_t *bmh_reads_offsets(const bmh_reads *r) { return r->rd.offsets.data(); }
+const uint32_t *bmh_reads_truth_bucket(const bmh_reads *r) { return r->rd.truth_bucket.data(); }
+const uint32_t *bmh_reads_truth_offset(const bmh_reads *r) { return r->rd.truth_offset.data(); }
+const uint8_t *bmh_reads_truth_rc(const bmh_reads *r) { return r->rd.truth_rc.data(); }
+int bmh_reads_write_fastq(const bmh_reads *r, const bmh_genome *g, uint32_t bucket_len, uint32_t index_read_len,
+                          const char *prefix) {
+    BMH_GUARD(1, {
+        auto buckets = bm::cut_buckets(g->g, static_cast<int>(bucket_len), static_cast<int>(index_read_len));
+        bm::write_fastq(r->rd, g->g, buckets, static_cast<int>(bucket_len), prefix);
+        return 0;
+    })
+}
+
+}  // extern "C"

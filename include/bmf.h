@@ -1,0 +1,129 @@
+/*
+ * bmf.h -- C ABI of the MI355X candidate-bucket filter ("bucket-map filter", libbmf.so).
+ *
+ * This is the drop-in boundary for BucketMap's per-read candidate-bucket filter.  It replaces what
+ * the reference's abstract `mapper` interface (bucket_map/mapper/mapper.h:4-34) hides behind
+ * `q_gram_mapper<NB>` (bucket_map/mapper/q_gram_mapper.h:204-646):
+ *
+ *   reference                                               this ABI
+ *   ------------------------------------------------------  -------------------------------------
+ *   q_gram_mapper<NB>::q_gram_mapper(...)   :281-308         bmf_create
+ *   mapper::load(index_dir, indicator)      :318-372         bmf_load_index_files / bmf_load_index
+ *   q_gram_mapper::query_sequence(seq,qual) :414-480         bmf_map_windows (batched, both strands)
+ *   mapper::reset()                         :638-645         bmf_reset
+ *   ~q_gram_mapper()                        :310-315         bmf_destroy
+ *
+ * `mapper::map(fastq)` (:483-557) itself -- FASTQ parsing, long-read windowing and the scatter of
+ * (read, window) pairs into per-bucket lists -- stays on the host in C++
+ * (bucket-map_amd/host/gpu_q_gram_mapper.h) and calls bmf_map_windows for the arithmetic.
+ *
+ * Conventions: plain C types only; every function returns 0 (BMF_OK) or a BMF_ERR_* code and never
+ * throws; one context per device, calls on one context are serialised by the caller; all buffers
+ * are caller-owned unless stated.  There is NO CPU fallback: every entry point that computes needs
+ * a gfx950 device and fails with BMF_ERR_HIP if none is usable.
+ */
+#ifndef BMF_H
+#define BMF_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BMF_ABI_VERSION 1
+
+enum {
+    BMF_OK = 0,
+    BMF_ERR_ARG = 1,         /* bad argument (null pointer, k<q, window longer than read_len ...) */
+    BMF_ERR_HIP = 2,         /* a HIP runtime call failed / no device                             */
+    BMF_ERR_STATE = 3,       /* e.g. map before load, load while an index is loaded               */
+    BMF_ERR_IO = 4,          /* index files missing or short                                      */
+    BMF_ERR_UNSUPPORTED = 5  /* parameter outside what the kernels were built for                 */
+};
+
+/* Run-time form of q_gram_mapper's constructor arguments (q_gram_mapper.h:281-286) plus NB, which
+ * is a compile-time template parameter in the reference (BM_BUCKET_NUM).  Derived values
+ * (num_fault, threshold, min_base_quality) are passed already derived, exactly as main.cpp:202-209
+ * and q_gram_mapper.h:163,303 compute them (float32!); helpers below do the derivation. */
+typedef struct bmf_params {
+    uint32_t num_buckets;         /* NB                                                          */
+    uint32_t q;                   /* index seed length (-k)                                      */
+    uint32_t k;                   /* query seed length (-l), q <= k <= 16                        */
+    uint32_t num_samples;         /* S (-s), 1..64                                               */
+    uint32_t num_fault;           /* F = ceil(S*e) in float32, 1..31                             */
+    uint32_t threshold;           /* (unsigned)(d*NB) in float32                                 */
+    uint32_t min_base_quality;    /* b*k                                                         */
+    uint32_t max_candidates;      /* 30 in the reference; 1..64                                  */
+    uint32_t read_len;            /* -r: longest window handed to bmf_map_windows                */
+    uint32_t num_segment_samples; /* 5 in the reference (used by the host wrapper only)          */
+    int32_t  device;              /* HIP device ordinal                                          */
+} bmf_params;
+
+typedef struct bmf_ctx bmf_ctx;
+typedef struct bmf_batch bmf_batch;
+
+/* float32 parameter derivations (main.cpp:207, q_gram_mapper.h:163, bucket_locator.h:419-420) */
+uint32_t bmf_fault_from_rate(uint32_t samples, float max_error_rate);
+uint32_t bmf_threshold(float distinguishability, uint32_t num_buckets);
+uint32_t bmf_ceil_mul_f32(float rate, uint32_t n);
+
+int  bmf_abi_version(void);
+/* Message of the last failure on this thread (create failures included). Never NULL. */
+const char *bmf_last_error(void);
+
+/* q_gram_mapper ctor (q_gram_mapper.h:281-308). Selects the device, creates the stream, uploads
+ * the sampler position table (utils.h:160-178 tabulated in fp64 on the host). */
+int  bmf_create(const bmf_params *params, bmf_ctx **out);
+void bmf_destroy(bmf_ctx *ctx);
+
+/* mapper::load (q_gram_mapper.h:318-372) from memory: `rows` = n_rows x ceil(NB/8) bytes in the
+ * .qgram layout (bucket j <-> byte j>>3, bit j&7), `kmer_to_index` = the .kmers_index table
+ * (n_kmers = 4^q entries, -1 = q-gram not indexed).  Uploads to HBM (rows padded to 128-byte
+ * pitch), computes per-row zero counts and the "highly distinguishable q-gram" bitmap on device
+ * (q_gram_mapper.h:171-196).  BMF_ERR_STATE if an index is already loaded (:325-328). */
+int  bmf_load_index(bmf_ctx *ctx, const uint8_t *rows, uint64_t n_rows, const int32_t *kmer_to_index,
+                    uint64_t n_kmers);
+/* Same, reading <index_dir>/<indicator>.kmers_index and .qgram (q_gram_mapper.h:331-358). */
+int  bmf_load_index_files(bmf_ctx *ctx, const char *index_dir, const char *indicator);
+/* mapper::reset (q_gram_mapper.h:638-645): frees the index in HBM; the context stays usable. */
+int  bmf_reset(bmf_ctx *ctx);
+/* Per-row zero counts as distinguishability_filter::read computes them (:171-187); n_rows u32. */
+int  bmf_index_zeros(bmf_ctx *ctx, uint32_t *out_zeros);
+
+/* q_gram_mapper::query_sequence (q_gram_mapper.h:414-480) for a batch of windows, host buffers.
+ * Window w = bases[win_off[w] .. win_off[w+1]) (ASCII, dna4 folding as SeqAn3) with qualities
+ * quals[...] (phred+33).  Every window must be <= read_len long.
+ *   out_counts[2w]   = number of candidate buckets, read as-is         (<= max_candidates)
+ *   out_counts[2w+1] = number of candidate buckets, reverse complement
+ *   out_buckets[(2w+o)*max_candidates + i] = i-th bucket id, ascending (entries >= count untouched)
+ * Synchronous: returns when the outputs are in host memory. */
+int  bmf_map_windows(bmf_ctx *ctx, const uint8_t *bases, const uint8_t *quals, const uint64_t *win_off,
+                     uint32_t n_windows, uint32_t *out_counts, uint32_t *out_buckets);
+
+/* Device-resident form (benchmarks, pipelines): upload once, run many times, download when needed. */
+int  bmf_batch_create(bmf_ctx *ctx, const uint8_t *bases, const uint8_t *quals, const uint64_t *win_off,
+                      uint32_t n_windows, bmf_batch **out);
+int  bmf_batch_run(bmf_ctx *ctx, bmf_batch *batch);            /* async on the context's stream */
+int  bmf_batch_download(bmf_ctx *ctx, bmf_batch *batch, uint32_t *out_counts, uint32_t *out_buckets);
+/* Number of index rows ANDed by the last run (reference row reads, q_gram_mapper.h:405, both
+ * orientations, all windows) -- the unit of the algorithmic-bytes figure. Synchronises. */
+int  bmf_batch_rows_anded(bmf_ctx *ctx, bmf_batch *batch, uint64_t *out);
+void bmf_batch_destroy(bmf_ctx *ctx, bmf_batch *batch);
+int  bmf_sync(bmf_ctx *ctx);
+
+/* HIP-event profiling of bmf_batch_run on the context's own stream: after bmf_profile_begin every
+ * run records events around the sample kernel and the vote kernel; bmf_profile_end synchronises
+ * and returns per-run kernel durations in milliseconds (arrays of max_runs floats). */
+int  bmf_profile_begin(bmf_ctx *ctx, uint32_t max_runs);
+int  bmf_profile_end(bmf_ctx *ctx, uint32_t *n_runs, float *ms_sample, float *ms_vote);
+
+/* Introspection for DESIGN.md / bench: bytes per padded row in HBM, kernel variant chosen. */
+int  bmf_info(bmf_ctx *ctx, uint32_t *row_pitch_bytes, uint32_t *chunks_per_lane, uint32_t *planes,
+              uint32_t *rows_in_flight);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,373 @@
+/*
+ * bm_oracle.c -- CPU restatement of BucketMap's candidate-bucket filter.  TEST INFRASTRUCTURE ONLY
+ * (see bm_oracle.h: "PARITY UNPINNED" -- pinned by hand-derived KATs, not by reference outputs).
+ *
+ * Deliberately naive: bit vectors are plain uint64_t arrays, the fault-tolerant filter keeps the
+ * reference's F unary levels and applies its update rule literally, one sample at a time.
+ * The product (bucket-map_amd/csrc) uses a different formulation (binary bit-sliced miss counters);
+ * agreement between the two is what the parity tests check.
+ */
+#include "bm_oracle.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+struct bmo_index {
+    bmo_params p;
+    uint32_t   nw;          /* 64-bit words per NB-bit vector                       */
+    uint32_t   row_bytes;   /* ceil(NB/8), on-disk row width                         */
+    uint64_t   n_rows;
+    uint64_t   n_kmers;     /* entries of kmer_to_index (4^q when loaded, else 0)    */
+    uint64_t  *rows;        /* n_rows x nw, bits >= NB cleared                       */
+    int32_t   *kmer_to_index;
+    uint32_t  *zeros;       /* per row: NB - popcount (q_gram_mapper.h:171-187)      */
+    uint32_t   q_bits;      /* 4^q - 1 (q_gram_mapper.h:293)                         */
+};
+
+/* ------------------------------------------------------------------------------------------ */
+/* parameter derivation (float32)                                                             */
+/* ------------------------------------------------------------------------------------------ */
+
+/* main.cpp:207: ceil(args.mapper_sample_size * args.allowed_seed_miss_rate): unsigned*float is a
+ * float product (rounded to float32 before ceil). volatile keeps gcc from widening it. */
+uint32_t bmo_fault_from_rate(uint32_t samples, float max_error_rate) {
+    volatile float prod = (float)samples * max_error_rate;
+    return (uint32_t)ceil((double)prod);
+}
+
+/* q_gram_mapper.h:163: threshold = (unsigned int)(distinguishability * NUM_BUCKETS) */
+uint32_t bmo_threshold(float distinguishability, uint32_t num_buckets) {
+    volatile float prod = distinguishability * (float)num_buckets;
+    return (uint32_t)prod;
+}
+
+/* bucket_locator.h:419-420: ceil(rate * unsigned) with a float32 product */
+uint32_t bmo_ceil_mul_f32(float a, uint32_t b) {
+    volatile float prod = a * (float)b;
+    return (uint32_t)ceil((double)prod);
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* small pure functions                                                                       */
+/* ------------------------------------------------------------------------------------------ */
+
+/* utils.h:160-178 (Sampler::sample_deterministically) */
+void bmo_sample_positions(uint32_t n, uint32_t upper_bound, uint32_t *out) {
+    if (n == 0) return;
+    double delta = 0.0;
+    if (n != 1) delta = (double)(upper_bound + 1u) / (double)(n - 1u);
+    for (uint32_t i = 0; i + 1 < n; i++) out[i] = (uint32_t)floor((double)i * delta);
+    out[n - 1] = upper_bound;
+}
+
+/* utils.h:291-302 */
+uint32_t bmo_hash_reverse_complement(uint32_t hash, uint32_t k) {
+    uint32_t orig = hash, rc = 0;
+    for (uint32_t i = 0; i < k; i++) {
+        rc |= (~orig) & 3u;
+        if (i != k - 1) {
+            rc <<= 2;
+            orig >>= 2;
+        }
+    }
+    return rc;
+}
+
+/* SeqAn3 dna4 assign_char: case-insensitive, U->T, IUPAC codes fold to a fixed
+ * base, anything else (incl. N) -> A. */
+uint8_t bmo_dna4_rank(uint8_t c) {
+    switch (c) {
+    case 'A': case 'a': return 0;
+    case 'C': case 'c': return 1;
+    case 'G': case 'g': return 2;
+    case 'T': case 't': case 'U': case 'u': return 3;
+    case 'R': case 'r': return 0;
+    case 'Y': case 'y': return 1;
+    case 'S': case 's': return 1;
+    case 'W': case 'w': return 0;
+    case 'K': case 'k': return 2;
+    case 'M': case 'm': return 0;
+    case 'B': case 'b': return 1;
+    case 'D': case 'd': return 0;
+    case 'H': case 'h': return 0;
+    case 'V': case 'v': return 0;
+    default: return 0;
+    }
+}
+
+/* views::kmer_hash(ungapped{k}): hash = sum rank(base_i) * 4^(k-1-i); size max(len+1,k)-k */
+uint32_t bmo_kmer_hashes(const uint8_t *bases, uint32_t len, uint32_t k, uint32_t *out) {
+    if (k == 0 || len < k) return 0;
+    uint32_t n = len - k + 1;
+    for (uint32_t j = 0; j < n; j++) {
+        uint32_t h = 0;
+        for (uint32_t t = 0; t < k; t++) h = (h << 2) | bmo_dna4_rank(bases[j + t]);
+        out[j] = h;
+    }
+    return n;
+}
+
+/* quality_filter.h:611-621 + :531-534: plain sum of phred ranks (char - '!') over k bases */
+uint32_t bmo_kmer_qualities(const uint8_t *quals, uint32_t len, uint32_t k, uint32_t *out) {
+    if (k == 0 || len < k) return 0;
+    uint32_t n = len - k + 1;
+    for (uint32_t j = 0; j < n; j++) {
+        uint32_t s = 0;
+        for (uint32_t t = 0; t < k; t++) s += (uint32_t)quals[j + t] - 33u;
+        out[j] = s;
+    }
+    return n;
+}
+
+/* q_gram_mapper.h:510-516 */
+uint32_t bmo_window_starts(uint32_t record_len, uint32_t read_len, uint32_t n_seg, uint32_t *out) {
+    if ((uint64_t)record_len > 2ull * read_len) {
+        bmo_sample_positions(n_seg, record_len - read_len - 1u, out);
+        return n_seg;
+    }
+    out[0] = 0;
+    return 1;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* index                                                                                      */
+/* ------------------------------------------------------------------------------------------ */
+
+static uint32_t popcount_vec(const uint64_t *v, uint32_t nw) {
+    uint32_t c = 0;
+    for (uint32_t i = 0; i < nw; i++) c += (uint32_t)__builtin_popcountll(v[i]);
+    return c;
+}
+
+bmo_index *bmo_index_create(const bmo_params *p, const uint8_t *rows, uint64_t n_rows,
+                            const int32_t *kmer_to_index, uint64_t n_kmers) {
+    if (!p || p->num_buckets == 0 || p->num_fault == 0 || p->q == 0 || p->q > 15 || p->k < p->q ||
+        p->k > 16)
+        return NULL;
+    bmo_index *ix = (bmo_index *)calloc(1, sizeof(*ix));
+    if (!ix) return NULL;
+    ix->p = *p;
+    ix->nw = (p->num_buckets + 63u) / 64u;
+    ix->row_bytes = (p->num_buckets + 7u) >> 3;
+    ix->n_rows = n_rows;
+    ix->n_kmers = n_kmers;
+    ix->q_bits = (uint32_t)((1ull << (2 * p->q)) - 1ull);
+    ix->rows = (uint64_t *)calloc((size_t)(n_rows ? n_rows : 1) * ix->nw, sizeof(uint64_t));
+    ix->kmer_to_index = (int32_t *)malloc((size_t)(n_kmers ? n_kmers : 1) * sizeof(int32_t));
+    ix->zeros = (uint32_t *)malloc((size_t)(n_rows ? n_rows : 1) * sizeof(uint32_t));
+    if (!ix->rows || !ix->kmer_to_index || !ix->zeros) {
+        bmo_index_destroy(ix);
+        return NULL;
+    }
+    if (n_kmers) memcpy(ix->kmer_to_index, kmer_to_index, (size_t)n_kmers * sizeof(int32_t));
+    /* q_gram_mapper.h:238-248: bit j of the bitset = (byte[j>>3] >> (j&7)) & 1, j < NB only */
+    for (uint64_t r = 0; r < n_rows; r++) {
+        uint64_t *dst = ix->rows + r * ix->nw;
+        const uint8_t *src = rows + r * ix->row_bytes;
+        /* (little-endian host: a byte copy places bit j at word j>>6, bit j&63; bits >= NB of the
+         *  last byte are never read by the reference, so they are masked off) */
+        memcpy(dst, src, ix->row_bytes);
+        if (p->num_buckets & 63u) dst[ix->nw - 1] &= (1ull << (p->num_buckets & 63u)) - 1ull;
+        /* q_gram_mapper.h:171-187 */
+        uint32_t ones = popcount_vec(dst, ix->nw);
+        ix->zeros[r] = (ones == 0) ? p->num_buckets : p->num_buckets - ones;
+    }
+    return ix;
+}
+
+bmo_index *bmo_index_load(const bmo_params *p, const char *dir, const char *indicator) {
+    char path[4096];
+    uint64_t n_kmers = 1ull << (2 * p->q);
+    int32_t *k2i = (int32_t *)malloc(n_kmers * sizeof(int32_t));
+    if (!k2i) return NULL;
+    snprintf(path, sizeof path, "%s/%s.kmers_index", dir, indicator);
+    FILE *f = fopen(path, "r");
+    if (!f) { free(k2i); return NULL; }
+    uint64_t sampled = 0;
+    for (uint64_t i = 0; i < n_kmers; i++) {
+        int v;
+        if (fscanf(f, "%d", &v) != 1) { fclose(f); free(k2i); return NULL; }
+        k2i[i] = v;
+        if (v >= 0) sampled++;
+    }
+    fclose(f);
+    uint32_t row_bytes = (p->num_buckets + 7u) >> 3;
+    uint8_t *rows = (uint8_t *)malloc((size_t)(sampled ? sampled : 1) * row_bytes);
+    if (!rows) { free(k2i); return NULL; }
+    snprintf(path, sizeof path, "%s/%s.qgram", dir, indicator);
+    f = fopen(path, "rb");
+    if (!f || fread(rows, row_bytes, (size_t)sampled, f) != sampled) {
+        if (f) fclose(f);
+        free(rows); free(k2i);
+        return NULL;
+    }
+    fclose(f);
+    bmo_index *ix = bmo_index_create(p, rows, sampled, k2i, n_kmers);
+    free(rows); free(k2i);
+    return ix;
+}
+
+void bmo_index_destroy(bmo_index *ix) {
+    if (!ix) return;
+    free(ix->rows);
+    free(ix->kmer_to_index);
+    free(ix->zeros);
+    free(ix);
+}
+
+uint64_t bmo_index_rows(const bmo_index *ix) { return ix->n_rows; }
+const uint32_t *bmo_index_zeros(const bmo_index *ix) { return ix->zeros; }
+
+/* q_gram_mapper.h:374-377 / :149-152 */
+static int32_t index_of_kmer(const bmo_index *ix, uint32_t h) {
+    if ((uint64_t)h < ix->n_kmers) return ix->kmer_to_index[h];
+    return -1;
+}
+
+/* q_gram_mapper.h:189-196 */
+int bmo_is_highly_distinguishable(const bmo_index *ix, uint32_t kmer_hash) {
+    for (uint32_t i = 0; i <= ix->p.k - ix->p.q; i++) {
+        uint32_t h = (kmer_hash >> (2 * i)) & ix->q_bits;
+        int32_t idx = index_of_kmer(ix, h);
+        if (idx >= 0 && ix->zeros[idx] >= ix->p.threshold) return 1;
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* the vote                                                                                   */
+/* ------------------------------------------------------------------------------------------ */
+
+static void vec_set_all(uint64_t *v, uint32_t nw, uint32_t nb) {
+    for (uint32_t i = 0; i < nw; i++) v[i] = ~0ull;
+    if (nb & 63u) v[nw - 1] = (1ull << (nb & 63u)) - 1ull;   /* std::bitset<NB>::set() */
+}
+
+static uint64_t query_impl(const bmo_index *ix, const uint32_t *hashes, uint32_t n, uint32_t *out,
+                           uint32_t *n_out) {
+    const uint32_t nw = ix->nw, nb = ix->p.num_buckets, F = ix->p.num_fault;
+    uint64_t rows_anded = 0;
+    *n_out = 0;
+    /* q_gram_mapper.h:389-393: empty index -> error + empty result */
+    if (ix->n_rows == 0) return 0;
+    uint64_t *lvl = (uint64_t *)malloc((size_t)(F + 1) * nw * sizeof(uint64_t));
+    uint64_t *bf = lvl + (size_t)F * nw;
+    /* fault_tolerate_filter::reset, q_gram_mapper.h:69-73 */
+    for (uint32_t i = 0; i < F; i++) vec_set_all(lvl + (size_t)i * nw, nw, nb);
+    for (uint32_t s = 0; s < n; s++) {
+        /* q_gram_mapper.h:398-406 */
+        vec_set_all(bf, nw, nb);
+        for (uint32_t i = 0; i <= ix->p.k - ix->p.q; i++) {
+            uint32_t g = (hashes[s] >> (2 * i)) & ix->q_bits;
+            int32_t idx = index_of_kmer(ix, g);
+            if (idx >= 0) {
+                const uint64_t *row = ix->rows + (size_t)idx * nw;
+                for (uint32_t w = 0; w < nw; w++) bf[w] &= row[w];
+                rows_anded++;
+            }
+        }
+        /* fault_tolerate_filter::read, q_gram_mapper.h:83-87 (ascending i: lvl[i+1] is the old value) */
+        for (uint32_t i = 0; i + 1 < F; i++) {
+            uint64_t *a = lvl + (size_t)i * nw, *b = lvl + (size_t)(i + 1) * nw;
+            for (uint32_t w = 0; w < nw; w++) a[w] &= (b[w] | bf[w]);
+        }
+        {
+            uint64_t *a = lvl + (size_t)(F - 1) * nw;
+            for (uint32_t w = 0; w < nw; w++) a[w] &= bf[w];
+        }
+    }
+    /* best_results, q_gram_mapper.h:90-102 + _set_bits :39-56 */
+    for (int i = (int)F - 1; i >= 0; i--) {
+        const uint64_t *a = lvl + (size_t)i * nw;
+        uint32_t c = 0;
+        for (uint32_t w = 0; w < nw; w++) {
+            uint64_t x = a[w];
+            while (x) {
+                out[c++] = w * 64u + (uint32_t)__builtin_ctzll(x);
+                x &= x - 1;
+            }
+        }
+        if (c) { *n_out = c; break; }
+    }
+    free(lvl);
+    return rows_anded;
+}
+
+uint32_t bmo_query(const bmo_index *ix, const uint32_t *kmer_hashes, uint32_t n, uint32_t *out) {
+    uint32_t c;
+    query_impl(ix, kmer_hashes, n, out, &c);
+    return c;
+}
+
+static uint64_t query_sequence_impl(const bmo_index *ix, const uint8_t *bases, const uint8_t *quals,
+                                    uint32_t len, uint32_t *out_fwd, uint32_t *n_fwd,
+                                    uint32_t *out_rc, uint32_t *n_rc, uint32_t *dbg_samples,
+                                    uint32_t *dbg_n_good) {
+    const bmo_params *p = &ix->p;
+    uint64_t rows_anded = 0;
+    *n_fwd = 0;
+    *n_rc = 0;
+    if (dbg_n_good) *dbg_n_good = 0;
+    uint32_t cap = len ? len : 1;
+    uint32_t *hashes = (uint32_t *)malloc(sizeof(uint32_t) * cap * 3 + sizeof(uint32_t) * 3 * (p->num_samples + 1));
+    uint32_t *qual = hashes + cap, *good = qual + cap;
+    uint32_t *pos = good + cap, *smp = pos + p->num_samples + 1, *smp_rc = smp + p->num_samples + 1;
+    uint32_t *tmp = (uint32_t *)malloc(sizeof(uint32_t) * p->num_buckets);
+    /* q_gram_mapper.h:431-442 */
+    uint32_t nk = bmo_kmer_hashes(bases, len, p->k, hashes);
+    bmo_kmer_qualities(quals, len, p->k, qual);
+    uint32_t n_good = 0;
+    for (uint32_t j = 0; j < nk; j++)
+        if (bmo_is_highly_distinguishable(ix, hashes[j]) && qual[j] >= p->min_base_quality)
+            good[n_good++] = hashes[j];
+    if (dbg_n_good) *dbg_n_good = n_good;
+    /* q_gram_mapper.h:445: size() < 0.2 * num_samples, compared in double */
+    if ((double)n_good < 0.2 * (double)p->num_samples) goto done;
+    /* q_gram_mapper.h:457-460 */
+    bmo_sample_positions(p->num_samples, n_good - 1u, pos);
+    for (uint32_t s = 0; s < p->num_samples; s++) {
+        smp[s] = good[pos[s]];
+        smp_rc[s] = bmo_hash_reverse_complement(smp[s], p->k);   /* :465-468 */
+        if (dbg_samples) dbg_samples[s] = smp[s];
+    }
+    {
+        uint32_t c;
+        rows_anded += query_impl(ix, smp, p->num_samples, tmp, &c);       /* :462 */
+        if (c <= p->max_candidates) {                                      /* :471-473 */
+            memcpy(out_fwd, tmp, c * sizeof(uint32_t));
+            *n_fwd = c;
+        }
+        rows_anded += query_impl(ix, smp_rc, p->num_samples, tmp, &c);    /* :469 */
+        if (c <= p->max_candidates) {                                      /* :474-476 */
+            memcpy(out_rc, tmp, c * sizeof(uint32_t));
+            *n_rc = c;
+        }
+    }
+done:
+    free(tmp);
+    free(hashes);
+    return rows_anded;
+}
+
+void bmo_query_sequence(const bmo_index *ix, const uint8_t *bases, const uint8_t *quals, uint32_t len,
+                        uint32_t *out_fwd, uint32_t *n_fwd, uint32_t *out_rc, uint32_t *n_rc,
+                        uint32_t *dbg_samples, uint32_t *dbg_n_good) {
+    query_sequence_impl(ix, bases, quals, len, out_fwd, n_fwd, out_rc, n_rc, dbg_samples, dbg_n_good);
+}
+
+uint64_t bmo_map_windows(const bmo_index *ix, const uint8_t *bases, const uint8_t *quals,
+                         const uint64_t *win_off, uint32_t n_windows, uint32_t *out_counts,
+                         uint32_t *out_buckets) {
+    const uint32_t mc = ix->p.max_candidates;
+    uint64_t rows_anded = 0;
+    for (uint32_t w = 0; w < n_windows; w++) {
+        uint32_t len = (uint32_t)(win_off[w + 1] - win_off[w]);
+        rows_anded += query_sequence_impl(ix, bases + win_off[w], quals + win_off[w], len,
+                                          out_buckets + (size_t)(2 * w) * mc, &out_counts[2 * w],
+                                          out_buckets + (size_t)(2 * w + 1) * mc, &out_counts[2 * w + 1],
+                                          NULL, NULL);
+    }
+    return rows_anded;
+}

@@ -1,0 +1,237 @@
+"""Parity of the HIP path (through the C ABI, libbmf.so) with the CPU oracle.  Needs an MI355X.
+
+Bar: bit-exact -- identical candidate counts and identical bucket ids in identical order, for both
+orientations of every window.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import Case, assert_same_candidates
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _compare(case, n=None, what=""):
+    rd = case.reads
+    n = rd.n if n is None else min(n, rd.n)
+    off = rd.offsets[: n + 1]
+    ix = case.oracle_index()
+    flt = case.gpu_filter()
+    c_ref, b_ref, rows_ref = ix.map_windows(rd.bases, rd.quals, off)
+    c_got, b_got = flt.map_windows(rd.bases, rd.quals, off)
+    assert_same_candidates(c_ref, b_ref, c_got, b_got, what)
+    # the device's row count is the unit of the algorithmic-bytes figure: must equal the oracle's
+    batch = flt.batch(rd.bases, rd.quals, off)
+    batch.run()
+    assert batch.rows_anded() == rows_ref
+    c2, b2 = batch.download()
+    assert_same_candidates(c_ref, b_ref, c2, b2, what + " (batch)")
+    batch.close()
+    # self-consistency: most reads find their source bucket
+    truth = np.where(rd.truth_rc[:n] == 1, 1, 0)
+    hit = sum(int(rd.truth_bucket[i] in b_got[i, truth[i], : c_got[i, truth[i]]]) for i in range(n))
+    flt.close()
+    return hit / max(n, 1), c_got
+
+
+def test_ecoli_like(ecoli_like):
+    frac, _ = _compare(ecoli_like, what="ecoli-like")
+    assert frac > 0.9
+
+
+@pytest.mark.parametrize("nb_target,samples,err,k,q", [
+    (700, 15, 0.4, 10, 7),        # 1 chunk per lane, partially filled
+    (8192, 15, 0.4, 10, 7),       # exactly 64 chunks: CPL 1 full
+    (8200, 15, 0.4, 10, 7),       # CPL 2, second round nearly empty
+    (20000, 15, 0.4, 10, 7),      # CPL 3
+    (26507, 15, 0.4, 10, 7),      # Egu geometry (CPL 4), P-default
+    (26507, 20, 0.6, 12, 7),      # Egu geometry, P-bench (S=20, F=12, G=6)
+    (46789, 15, 0.4, 10, 7),      # GRCh38 geometry (CPL 6)
+    (65536, 15, 0.4, 9, 7),       # largest supported NB (CPL 8)
+])
+def test_geometries(nb_target, samples, err, k, q):
+    bucket_len = 256
+    case = Case(record_lengths=[nb_target * bucket_len - 17], bucket_len=bucket_len, read_len=100, n_reads=300, q=q,
+                k=k, samples=samples, error_rate=err, sub=0.01, seed=20240100 + nb_target)
+    assert case.num_buckets == nb_target
+    frac, _ = _compare(case, what=f"NB={nb_target} S={samples}")
+    assert frac > 0.85
+
+
+def test_fracminhash_index_has_unindexed_qgrams():
+    # -f 0.25: most q-grams are not indexed (kmer_to_index == -1), reverse-complement samples can have
+    # no indexed q-gram at all -> all-ones vector
+    case = Case(record_lengths=[300_000, 41_000], bucket_len=1024, read_len=120, n_reads=300, q=7, k=10,
+                kmer_frac=0.25, extra_buckets=3, seed=77)
+    assert (case.index.kmer_to_index() < 0).mean() > 0.5
+    _compare(case, what="kmer_frac=0.25")
+
+
+def test_noisy_qualities_and_quality_filter():
+    case = Case(record_lengths=[200_000], bucket_len=2048, read_len=150, n_reads=300, noisy_quals=True,
+                base_quality=33, seed=78)
+    _, counts = _compare(case, what="noisy quals")
+    assert (counts.sum(axis=1) == 0).any()      # some reads are rejected by the quality filter
+
+
+def test_repeats_overflow_max_candidates():
+    # 40 identical records -> a read matches > 30 buckets equally well -> list cleared (q_gram_mapper.h:471-476)
+    from bucket_map_amd import host
+    g1 = host.Genome.synth(5, [3000])
+    seq = bytes(g1.record_seq(0))
+    path = "/tmp/bm_repeat_genome.fa"
+    with open(path, "w") as f:
+        for i in range(40):
+            f.write(f">rep{i}\n{seq.decode()}\n")
+    case = Case.__new__(Case)
+    case.genome = host.Genome.read_fasta(path)
+    case.bucket_len, case.read_len = 4096, 100
+    case.num_buckets = case.genome.awk_bucket_num(4096)
+    case.index = host.Index(case.genome, case.num_buckets, 4096, 100, q=7)
+    case.reads = host.Reads(case.genome, 4096, 100, 100, 100, seed=9)
+    case.cli = dict(index_seed=7, query_seed=10, read_len=100, mapper_samples=15, max_error_rate=0.4,
+                    distinguishability=0.0, average_base_quality=25)
+    _, counts = _compare(case, what="repeats")
+    assert counts.max() == 0
+
+
+def test_ragged_and_degenerate_windows(ecoli_like):
+    case = ecoli_like
+    rd = case.reads
+    rng = np.random.default_rng(5)
+    pieces_b, pieces_q, off = [], [], [0]
+    for r in range(120):
+        o0, o1 = int(rd.offsets[r]), int(rd.offsets[r + 1])
+        b, q = rd.bases[o0:o1].copy(), rd.quals[o0:o1].copy()
+        mode = r % 8
+        if mode == 1:
+            b, q = b[:0], q[:0]                                 # empty window
+        elif mode == 2:
+            b, q = b[:11], q[:11]                               # shorter than k
+        elif mode == 3:
+            b, q = b[:12], q[:12]                               # exactly one k-mer
+        elif mode == 4:
+            n = int(rng.integers(13, len(b)))
+            b, q = b[:n], q[:n]                                 # ragged
+        elif mode == 5:
+            q[:] = ord("#")                                     # all low quality
+        elif mode == 6:
+            b[20:60] = ord("N")                                 # ambiguity codes
+        elif mode == 7:
+            b = np.frombuffer(bytes(b).lower(), np.uint8).copy()  # lower case
+        pieces_b.append(b); pieces_q.append(q); off.append(off[-1] + len(b))
+    bases, quals, off = np.concatenate(pieces_b), np.concatenate(pieces_q), np.array(off, np.uint64)
+    ix, flt = case.oracle_index(), case.gpu_filter()
+    c_ref, b_ref, _ = ix.map_windows(bases, quals, off)
+    c_got, b_got = flt.map_windows(bases, quals, off)
+    assert_same_candidates(c_ref, b_ref, c_got, b_got, "ragged")
+    # zero windows is a no-op
+    c0, b0 = flt.map_windows(bases[:0], quals[:0], np.zeros(1, np.uint64))
+    assert c0.shape == (0, 2)
+    flt.close()
+
+
+def test_golden_reads_on_gpu():
+    import bucket_map_amd as bma
+    with open(os.path.join(GOLDEN, "reads_small.json")) as f:
+        g = json.load(f)
+    p = bma.Params(num_buckets=g["num_buckets"], q=g["q"], k=g["k"], num_samples=g["S"], num_fault=g["F"],
+                   threshold=g["threshold"], min_base_quality=g["min_base_quality"], read_len=g["read_len"])
+    flt = bma.Filter(p)
+    flt.load_index(np.array(g["rows"], np.uint8), np.array(g["kmer_to_index"], np.int32))
+    bases = np.frombuffer("".join(r["bases"] for r in g["reads"]).encode(), np.uint8)
+    quals = np.frombuffer("".join(r["quals"] for r in g["reads"]).encode(), np.uint8)
+    off = np.cumsum([0] + [len(r["bases"]) for r in g["reads"]]).astype(np.uint64)
+    counts, buckets = flt.map_windows(bases, quals, off)
+    for i, r in enumerate(g["reads"]):
+        assert list(buckets[i, 0, : counts[i, 0]]) == r["fwd"], i
+        assert list(buckets[i, 1, : counts[i, 1]]) == r["rc"], i
+    flt.close()
+
+
+def test_golden_tiny_index_on_gpu():
+    # q == k is not reachable from reads with distinct samples, so drive the vote through windows whose
+    # k-mers ARE the wanted hashes: k=3 windows of exactly 3 bases give one k-mer = one sample (S=1).
+    import bucket_map_amd as bma
+    with open(os.path.join(GOLDEN, "tiny_index.json")) as f:
+        g = json.load(f)
+    case = g["cases"][0]
+    assert case["S"] == 1
+    p = bma.Params(num_buckets=g["num_buckets"], q=g["q"], k=g["k"], num_samples=1, num_fault=case["F"], threshold=0,
+                   min_base_quality=0, read_len=8, max_candidates=64)
+    flt = bma.Filter(p)
+    flt.load_index(np.array(g["rows"], np.uint8), np.array(g["kmer_to_index"], np.int32))
+    letters = b"ACGT"
+    wins = []
+    for (h,) in case["hashes"]:
+        wins.append(bytes(letters[(h >> (2 * (g["k"] - 1 - i))) & 3] for i in range(g["k"])))
+    bases = np.frombuffer(b"".join(wins), np.uint8)
+    quals = np.full(len(bases), ord("E"), np.uint8)
+    off = (np.arange(len(wins) + 1) * g["k"]).astype(np.uint64)
+    counts, buckets = flt.map_windows(bases, quals, off)
+    # a k-mer none of whose q-grams is indexed is not 'good': the window is then rejected, and the
+    # oracle says so too -- so compare through the oracle first
+    from oracle import oracle_c as oc
+    ix = oc.Index(oc.make_params(g["num_buckets"], q=g["q"], k=g["k"], num_samples=1, num_fault=case["F"],
+                                 threshold=0, min_base_quality=0, max_candidates=64, read_len=8),
+                  np.array(g["rows"], np.uint8), np.array(g["kmer_to_index"], np.int32))
+    c_ref, b_ref, _ = ix.map_windows(bases, quals, off)
+    assert_same_candidates(c_ref, b_ref, counts, buckets, "tiny index")
+    # and where the window was accepted, the forward list is the committed expectation
+    for i, want in enumerate(case["expected"]):
+        if c_ref[i].sum() and len(want) <= 64:
+            assert list(buckets[i, 0, : counts[i, 0]]) == want
+    flt.close()
+
+
+def test_error_behaviour():
+    import bucket_map_amd as bma
+    p = bma.Params.from_cli(100, read_len=50)
+    flt = bma.Filter(p)
+    bases = np.frombuffer(b"ACGT" * 10, np.uint8)
+    quals = np.full(40, ord("E"), np.uint8)
+    off = np.array([0, 40], np.uint64)
+    with pytest.raises(bma.BmfError) as e:           # query before load: q_gram_mapper.h:389-393
+        flt.map_windows(bases, quals, off)
+    assert e.value.code == bma.BMF_ERR_STATE
+    rows = np.zeros((4 ** 9, 13), np.uint8)
+    flt.load_index(rows, np.arange(4 ** 9, dtype=np.int32))
+    with pytest.raises(bma.BmfError) as e:           # second load: q_gram_mapper.h:325-328
+        flt.load_index(rows, np.arange(4 ** 9, dtype=np.int32))
+    assert e.value.code == bma.BMF_ERR_STATE
+    with pytest.raises(bma.BmfError) as e:           # window longer than read_len
+        flt.map_windows(np.tile(bases, 2), np.tile(quals, 2), np.array([0, 80], np.uint64))
+    assert e.value.code == bma.BMF_ERR_ARG
+    flt.reset()                                      # mapper::reset frees the index, context stays usable
+    flt.load_index(rows, np.arange(4 ** 9, dtype=np.int32))
+    c, _ = flt.map_windows(bases, quals, off)
+    assert c.sum() == 0                              # all-zero index: every bucket misses every sample
+    flt.close()
+    with pytest.raises(bma.BmfError):
+        bma.Filter(bma.Params.from_cli(70000))       # NB > 65536 unsupported in this round
+
+
+def test_zeros_match_oracle(ecoli_like):
+    ix, flt = ecoli_like.oracle_index(), ecoli_like.gpu_filter()
+    assert np.array_equal(flt.zeros(), ix.zeros())
+    flt.close()
+
+
+def test_determinism_and_batch_invariance(ecoli_like):
+    case = ecoli_like
+    rd = case.reads
+    flt = case.gpu_filter()
+    c1, b1 = flt.map_windows(rd.bases, rd.quals, rd.offsets)
+    c2, b2 = flt.map_windows(rd.bases, rd.quals, rd.offsets)
+    assert_same_candidates(c1, b1, c2, b2, "idempotence")
+    # splitting the batch must not change any window's result
+    h = rd.n // 3
+    ca, ba = flt.map_windows(rd.bases, rd.quals, rd.offsets[: h + 1])
+    cb, bb = flt.map_windows(rd.bases, rd.quals, rd.offsets[h:])
+    assert_same_candidates(c1, b1, np.concatenate([ca, cb]), np.concatenate([ba, bb]), "batch split")
+    flt.close()
