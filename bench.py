@@ -124,7 +124,9 @@ def main():
     t0 = time.perf_counter()
     flt.load_index_ptr(index.rows_ptr, index.num_rows, index.k2i_ptr, index.num_kmers)
     log(f"index in HBM ({time.perf_counter() - t0:.1f}s), kernel variant {flt.info()}")
-    batch = flt.batch(reads.bases, reads.quals, reads.offsets)
+    # mapper::map's windowing: one window [0, min(read_len, len)) per short read
+    win_start, win_len, _, _ = bma.windows_for_reads(reads.offsets, read_len)
+    batch = flt.batch(reads.bases, reads.quals, win_start, win_len)
 
     def barrier():
         if world > 1:
@@ -165,7 +167,7 @@ def main():
         reads_per_s = world * reads.n * args.steps / elapsed
         vote_ms = float(np.mean(ms_vote))
         algo_bytes_vote = rows_anded * row_bytes                 # rows ANDed x ceil(NB/8)
-        algo_bytes_read = algo_bytes_vote + 2 * int(reads.offsets[-1])
+        algo_bytes_read = algo_bytes_vote + 2 * int(win_len.sum())
         achieved = algo_bytes_vote / (vote_ms * 1e-3) / 1e9
         result = {
             "metric": "mapped reads/sec (1M x 300bp, 65536-bp-bucket index)",
@@ -196,7 +198,7 @@ def main():
             ora = oracle_c.Index(oracle_c.params_from_cli(nb, **cli), rows_ptr=index.rows_ptr, n_rows=index.num_rows,
                                  k2i_ptr=index.k2i_ptr, n_kmers=index.num_kmers)
             t0 = time.perf_counter()
-            c_ref, b_ref, rows_ref = ora.map_windows(reads.bases, reads.quals, reads.offsets[: n_cpu + 1])
+            c_ref, b_ref, rows_ref = ora.map_windows(reads.bases, reads.quals, win_start[:n_cpu], win_len[:n_cpu])
             cpu_s = time.perf_counter() - t0
             same = bool(np.array_equal(c_ref, counts[:n_cpu]))
             mask = np.arange(b_ref.shape[-1])[None, None, :] < c_ref[:, :, None]

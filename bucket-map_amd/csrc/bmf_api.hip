@@ -86,7 +86,8 @@ struct bmf_batch {
     uint32_t n_windows = 0;
     uint64_t n_bytes = 0;
     uint8_t *d_bases = nullptr, *d_quals = nullptr;
-    uint64_t *d_win_off = nullptr;
+    uint64_t *d_win_start = nullptr;
+    uint32_t *d_win_len = nullptr;
     uint32_t *d_lists = nullptr, *d_list_n = nullptr, *d_rows_anded = nullptr;
     uint32_t *d_counts = nullptr, *d_buckets = nullptr;
 };
@@ -129,6 +130,19 @@ uint32_t bmf_fault_from_rate(uint32_t samples, float max_error_rate) {
 uint32_t bmf_threshold(float distinguishability, uint32_t num_buckets) {
     volatile float prod = distinguishability * (float)num_buckets;
     return (uint32_t)prod;
+}
+// q_gram_mapper.h:510-516 (Sampler: utils.h:160-178)
+uint32_t bmf_window_starts(uint32_t record_len, uint32_t read_len, uint32_t n_seg, uint32_t *out) {
+    if ((uint64_t)record_len > 2ull * read_len && n_seg > 0) {
+        const uint32_t ub = record_len - read_len - 1u;
+        double delta = 0.0;
+        if (n_seg != 1) delta = (double)(ub + 1u) / (double)(n_seg - 1u);
+        for (uint32_t i = 0; i + 1 < n_seg; i++) out[i] = (uint32_t)floor((double)i * delta);
+        out[n_seg - 1] = ub;
+        return n_seg;
+    }
+    out[0] = 0;
+    return 1;
 }
 // bucket_locator.h:419-420
 uint32_t bmf_ceil_mul_f32(float rate, uint32_t n) {
@@ -372,7 +386,8 @@ void bmf_batch_destroy(bmf_ctx *c, bmf_batch *b) {
     }
     (void)hipFree(b->d_bases);
     (void)hipFree(b->d_quals);
-    (void)hipFree(b->d_win_off);
+    (void)hipFree(b->d_win_start);
+    (void)hipFree(b->d_win_len);
     (void)hipFree(b->d_lists);
     (void)hipFree(b->d_list_n);
     (void)hipFree(b->d_rows_anded);
@@ -381,43 +396,43 @@ void bmf_batch_destroy(bmf_ctx *c, bmf_batch *b) {
     delete b;
 }
 
-int bmf_batch_create(bmf_ctx *c, const uint8_t *bases, const uint8_t *quals, const uint64_t *win_off,
-                     uint32_t n_windows, bmf_batch **out) {
-    if (!c || !out || !win_off) return fail(BMF_ERR_ARG, "bmf_batch_create: null argument");
+int bmf_batch_create(bmf_ctx *c, const uint8_t *bases, const uint8_t *quals, uint64_t n_bytes,
+                     const uint64_t *win_start, const uint32_t *win_len, uint32_t n_windows, bmf_batch **out) {
+    if (!c || !out) return fail(BMF_ERR_ARG, "bmf_batch_create: null argument");
     *out = nullptr;
+    if (n_windows && (!win_start || !win_len)) return fail(BMF_ERR_ARG, "win_start/win_len is null");
     if (n_windows > 0x3FFFFFFFu) return fail(BMF_ERR_ARG, "too many windows");
+    if (n_bytes && (!bases || !quals)) return fail(BMF_ERR_ARG, "bases/quals is null");
     for (uint32_t w = 0; w < n_windows; w++) {
-        if (win_off[w + 1] < win_off[w]) return fail(BMF_ERR_ARG, "win_off is not monotonic at window %u", w);
-        if (win_off[w + 1] - win_off[w] > c->p.read_len)
-            return fail(BMF_ERR_ARG, "window %u is %llu bases long, more than read_len = %u", w,
-                        (unsigned long long)(win_off[w + 1] - win_off[w]), c->p.read_len);
+        if (win_len[w] > c->p.read_len)
+            return fail(BMF_ERR_ARG, "window %u is %u bases long, more than read_len = %u", w, win_len[w], c->p.read_len);
+        if (win_start[w] > n_bytes || win_len[w] > n_bytes - win_start[w])
+            return fail(BMF_ERR_ARG, "window %u [%llu, +%u) lies outside the %llu-byte read buffer", w,
+                        (unsigned long long)win_start[w], win_len[w], (unsigned long long)n_bytes);
     }
-    const uint64_t lo = win_off[0], hi = win_off[n_windows];
-    if (hi > lo && (!bases || !quals)) return fail(BMF_ERR_ARG, "bases/quals is null");
     HIP_TRY(hipSetDevice(c->p.device));
     bmf_batch *b = new bmf_batch();
     b->n_windows = n_windows;
-    b->n_bytes = hi - lo;
+    b->n_bytes = n_bytes;
     const size_t n = n_windows;
     hipError_t e = hipSuccess;
     auto ok = [&](hipError_t r) { if (e == hipSuccess) e = r; };
-    ok(dev_alloc(&b->d_bases, (size_t)b->n_bytes));
-    ok(dev_alloc(&b->d_quals, (size_t)b->n_bytes));
-    ok(dev_alloc(&b->d_win_off, n + 1));
+    ok(dev_alloc(&b->d_bases, (size_t)n_bytes));
+    ok(dev_alloc(&b->d_quals, (size_t)n_bytes));
+    ok(dev_alloc(&b->d_win_start, n));
+    ok(dev_alloc(&b->d_win_len, n));
     ok(dev_alloc(&b->d_lists, 2 * n * c->dp.list_len));
     ok(dev_alloc(&b->d_list_n, n));
     ok(dev_alloc(&b->d_rows_anded, n));
     ok(dev_alloc(&b->d_counts, 2 * n));
     ok(dev_alloc(&b->d_buckets, 2 * n * c->p.max_candidates));
-    if (e == hipSuccess && b->n_bytes) {
-        ok(hipMemcpy(b->d_bases, bases + lo, (size_t)b->n_bytes, hipMemcpyHostToDevice));
-        ok(hipMemcpy(b->d_quals, quals + lo, (size_t)b->n_bytes, hipMemcpyHostToDevice));
+    if (e == hipSuccess && n_bytes) {
+        ok(hipMemcpy(b->d_bases, bases, (size_t)n_bytes, hipMemcpyHostToDevice));
+        ok(hipMemcpy(b->d_quals, quals, (size_t)n_bytes, hipMemcpyHostToDevice));
     }
-    if (e == hipSuccess) {
-        // offsets relative to the uploaded slice
-        std::vector<uint64_t> rel(n + 1);
-        for (size_t w = 0; w <= n; w++) rel[w] = win_off[w] - lo;
-        ok(hipMemcpy(b->d_win_off, rel.data(), (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice));
+    if (e == hipSuccess && n) {
+        ok(hipMemcpy(b->d_win_start, win_start, n * sizeof(uint64_t), hipMemcpyHostToDevice));
+        ok(hipMemcpy(b->d_win_len, win_len, n * sizeof(uint32_t), hipMemcpyHostToDevice));
     }
     if (e != hipSuccess) {
         bmf_batch_destroy(c, b);
@@ -437,7 +452,7 @@ int bmf_batch_run(bmf_ctx *c, bmf_batch *b) {
     hipEvent_t *ev = prof ? &c->ev[(size_t)3 * c->prof_n] : nullptr;
     if (prof) HIP_TRY(hipEventRecord(ev[0], c->stream));
     hipLaunchKernelGGL(bmf::bmf_sample_kernel, dim3(b->n_windows), dim3(bmf::kWave), c->sample_lds, c->stream, c->dp,
-                       b->d_bases, b->d_quals, b->d_win_off, c->d_lut, c->d_qgram_ok, c->d_k2i, c->d_pos_table,
+                       b->d_bases, b->d_quals, b->d_win_start, b->d_win_len, c->d_lut, c->d_qgram_ok, c->d_k2i, c->d_pos_table,
                        b->d_lists, b->d_list_n, b->d_rows_anded);
     if (prof) HIP_TRY(hipEventRecord(ev[1], c->stream));
     hipLaunchKernelGGL(c->vote, dim3(2 * b->n_windows), dim3(bmf::kWave), 0, c->stream, c->dp, c->d_rows, b->d_lists,
@@ -489,14 +504,15 @@ int bmf_batch_rows_anded(bmf_ctx *c, bmf_batch *b, uint64_t *out) {
     return BMF_OK;
 }
 
-int bmf_map_windows(bmf_ctx *c, const uint8_t *bases, const uint8_t *quals, const uint64_t *win_off,
-                    uint32_t n_windows, uint32_t *out_counts, uint32_t *out_buckets) {
+int bmf_map_windows(bmf_ctx *c, const uint8_t *bases, const uint8_t *quals, uint64_t n_bytes,
+                    const uint64_t *win_start, const uint32_t *win_len, uint32_t n_windows,
+                    uint32_t *out_counts, uint32_t *out_buckets) {
     if (!c) return fail(BMF_ERR_ARG, "bmf_map_windows: null context");
     if (!c->loaded) return fail(BMF_ERR_STATE, "the q-gram index is empty; cannot accept query");
     if (n_windows == 0) return BMF_OK;
     if (!out_counts || !out_buckets) return fail(BMF_ERR_ARG, "bmf_map_windows: null output");
     bmf_batch *b = nullptr;
-    int rc = bmf_batch_create(c, bases, quals, win_off, n_windows, &b);
+    int rc = bmf_batch_create(c, bases, quals, n_bytes, win_start, win_len, n_windows, &b);
     if (rc != BMF_OK) return rc;
     rc = bmf_batch_run(c, b);
     if (rc == BMF_OK) rc = bmf_batch_download(c, b, out_counts, out_buckets);

@@ -108,7 +108,8 @@ __global__ void bmf_qgram_ok_kernel(const int32_t *k2i, uint64_t n_kmers, const 
 //                       goodh[max_kmers] u32
 __global__ __launch_bounds__(kWave) void bmf_sample_kernel(
     DevParams P, const uint8_t *__restrict__ bases, const uint8_t *__restrict__ quals,
-    const uint64_t *__restrict__ win_off, const uint8_t *__restrict__ dna4_lut,
+    const uint64_t *__restrict__ win_start, const uint32_t *__restrict__ win_len,
+    const uint8_t *__restrict__ dna4_lut,
     const uint32_t *__restrict__ qgram_ok, const int32_t *__restrict__ k2i,
     const uint16_t *__restrict__ pos_table, uint32_t *__restrict__ row_lists,
     uint32_t *__restrict__ list_n, uint32_t *__restrict__ rows_anded) {
@@ -120,8 +121,8 @@ __global__ __launch_bounds__(kWave) void bmf_sample_kernel(
 
     const uint32_t w = blockIdx.x;
     const uint32_t lane = threadIdx.x;
-    const uint64_t off = win_off[w];
-    const uint32_t len = (uint32_t)(win_off[w + 1] - off);
+    const uint64_t off = win_start[w];
+    const uint32_t len = win_len[w];
 
     reinterpret_cast<uint32_t *>(lut)[lane] = reinterpret_cast<const uint32_t *>(dna4_lut)[lane];
     __syncthreads();

@@ -53,8 +53,10 @@ SYMBOLS = {
     "bmf_load_index_files": (C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p]),
     "bmf_reset": (C.c_int, [C.c_void_p]),
     "bmf_index_zeros": (C.c_int, [C.c_void_p, _u32p]),
-    "bmf_map_windows": (C.c_int, [C.c_void_p, _u8p, _u8p, _u64p, C.c_uint32, _u32p, _u32p]),
-    "bmf_batch_create": (C.c_int, [C.c_void_p, _u8p, _u8p, _u64p, C.c_uint32, C.POINTER(C.c_void_p)]),
+    "bmf_window_starts": (C.c_uint32, [C.c_uint32, C.c_uint32, C.c_uint32, _u32p]),
+    "bmf_map_windows": (C.c_int, [C.c_void_p, _u8p, _u8p, C.c_uint64, _u64p, _u32p, C.c_uint32, _u32p, _u32p]),
+    "bmf_batch_create": (C.c_int, [C.c_void_p, _u8p, _u8p, C.c_uint64, _u64p, _u32p, C.c_uint32,
+                                   C.POINTER(C.c_void_p)]),
     "bmf_batch_run": (C.c_int, [C.c_void_p, C.c_void_p]),
     "bmf_batch_download": (C.c_int, [C.c_void_p, C.c_void_p, _u32p, _u32p]),
     "bmf_batch_rows_anded": (C.c_int, [C.c_void_p, C.c_void_p, _u64p]),
@@ -126,18 +128,50 @@ class Params:
                        self.device)
 
 
+def windows_for_reads(offsets, read_len: int, n_seg: int = 5):
+    """q_gram_mapper::map's windowing (q_gram_mapper.h:510-523) for reads stored back to back:
+    read r = [offsets[r], offsets[r+1]).  Returns (win_start u64, win_len u32, read_id u32,
+    start_in_read u32): one window [0, min(read_len, len)) per read, or n_seg windows at
+    Sampler(n_seg) positions for reads longer than 2*read_len."""
+    offsets = np.asarray(offsets, dtype=np.uint64)
+    lens = np.diff(offsets).astype(np.int64)
+    n = len(lens)
+    long_reads = np.nonzero(lens > 2 * read_len)[0]
+    if long_reads.size == 0:
+        return (offsets[:-1].copy(), np.minimum(lens, read_len).astype(np.uint32), np.arange(n, dtype=np.uint32),
+                np.zeros(n, dtype=np.uint32))
+    ws, wl, rid, sir = [], [], [], []
+    buf = (C.c_uint32 * max(n_seg, 1))()
+    is_long = np.zeros(n, bool)
+    is_long[long_reads] = True
+    for r in range(n):
+        if is_long[r]:
+            m = lib().bmf_window_starts(int(lens[r]), read_len, n_seg, buf)
+            starts = [buf[i] for i in range(m)]
+        else:
+            starts = [0]
+        for st in starts:
+            ws.append(int(offsets[r]) + st)
+            wl.append(min(st + read_len, int(lens[r])) - st)
+            rid.append(r)
+            sir.append(st)
+    return (np.array(ws, np.uint64), np.array(wl, np.uint32), np.array(rid, np.uint32), np.array(sir, np.uint32))
+
+
 class Batch:
     """Device-resident batch of windows (bmf_batch)."""
 
-    def __init__(self, flt: "Filter", bases, quals, win_off):
+    def __init__(self, flt: "Filter", bases, quals, win_start, win_len):
         self._flt = flt
-        self.n_windows = len(win_off) - 1
+        self.n_windows = len(win_start)
         bases = np.ascontiguousarray(bases, dtype=np.uint8)
         quals = np.ascontiguousarray(quals, dtype=np.uint8)
-        win_off = np.ascontiguousarray(win_off, dtype=np.uint64)
+        win_start = np.ascontiguousarray(win_start, dtype=np.uint64)
+        win_len = np.ascontiguousarray(win_len, dtype=np.uint32)
+        assert len(win_len) == self.n_windows and len(quals) == len(bases)
         h = C.c_void_p()
-        _check(lib().bmf_batch_create(flt._h, _ptr(bases, _u8p), _ptr(quals, _u8p), _ptr(win_off, _u64p),
-                                      self.n_windows, C.byref(h)))
+        _check(lib().bmf_batch_create(flt._h, _ptr(bases, _u8p), _ptr(quals, _u8p), len(bases),
+                                      _ptr(win_start, _u64p), _ptr(win_len, _u32p), self.n_windows, C.byref(h)))
         self._h = h
 
     def run(self) -> None:
@@ -210,21 +244,24 @@ class Filter:
         _check(lib().bmf_index_zeros(self._h, _ptr(out, _u32p)))
         return out
 
-    def map_windows(self, bases, quals, win_off):
+    def map_windows(self, bases, quals, win_start, win_len):
         """query_sequence for every window; returns (counts[n,2], buckets[n,2,max_candidates])."""
         bases = np.ascontiguousarray(bases, dtype=np.uint8)
         quals = np.ascontiguousarray(quals, dtype=np.uint8)
-        win_off = np.ascontiguousarray(win_off, dtype=np.uint64)
-        n = len(win_off) - 1
+        win_start = np.ascontiguousarray(win_start, dtype=np.uint64)
+        win_len = np.ascontiguousarray(win_len, dtype=np.uint32)
+        n = len(win_start)
+        assert len(win_len) == n and len(quals) == len(bases)
         mc = self.params.max_candidates
         counts = np.zeros((n, 2), dtype=np.uint32)
         buckets = np.zeros((n, 2, mc), dtype=np.uint32)
-        _check(lib().bmf_map_windows(self._h, _ptr(bases, _u8p), _ptr(quals, _u8p), _ptr(win_off, _u64p), n,
+        _check(lib().bmf_map_windows(self._h, _ptr(bases, _u8p), _ptr(quals, _u8p), len(bases),
+                                     _ptr(win_start, _u64p), _ptr(win_len, _u32p), n,
                                      _ptr(counts, _u32p), _ptr(buckets, _u32p)))
         return counts, buckets
 
-    def batch(self, bases, quals, win_off) -> Batch:
-        return Batch(self, bases, quals, win_off)
+    def batch(self, bases, quals, win_start, win_len) -> Batch:
+        return Batch(self, bases, quals, win_start, win_len)
 
     def sync(self) -> None:
         _check(lib().bmf_sync(self._h))

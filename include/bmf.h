@@ -92,19 +92,27 @@ int  bmf_reset(bmf_ctx *ctx);
 /* Per-row zero counts as distinguishability_filter::read computes them (:171-187); n_rows u32. */
 int  bmf_index_zeros(bmf_ctx *ctx, uint32_t *out_zeros);
 
+/* q_gram_mapper::map's windowing rule (q_gram_mapper.h:510-516): a record longer than 2*read_len is cut
+ * into n_seg windows starting at Sampler(n_seg) positions over [0, len-read_len-1]; otherwise one
+ * window at 0.  Writes the window starts, returns their number (1 or n_seg).  Pure host helper. */
+uint32_t bmf_window_starts(uint32_t record_len, uint32_t read_len, uint32_t n_seg, uint32_t *out);
+
 /* q_gram_mapper::query_sequence (q_gram_mapper.h:414-480) for a batch of windows, host buffers.
- * Window w = bases[win_off[w] .. win_off[w+1]) (ASCII, dna4 folding as SeqAn3) with qualities
- * quals[...] (phred+33).  Every window must be <= read_len long.
+ * `bases` (ASCII, dna4 folding as SeqAn3) and `quals` (phred+33) hold n_bytes bytes of reads; window w
+ * is the view [win_start[w], win_start[w] + win_len[w]) of both.  Windows may overlap (the 5 windows
+ * of a long read) or be shorter than their read (truncation to read_len, q_gram_mapper.h:521); every
+ * window must be <= read_len long and lie inside the buffers.
  *   out_counts[2w]   = number of candidate buckets, read as-is         (<= max_candidates)
  *   out_counts[2w+1] = number of candidate buckets, reverse complement
  *   out_buckets[(2w+o)*max_candidates + i] = i-th bucket id, ascending (entries >= count untouched)
  * Synchronous: returns when the outputs are in host memory. */
-int  bmf_map_windows(bmf_ctx *ctx, const uint8_t *bases, const uint8_t *quals, const uint64_t *win_off,
-                     uint32_t n_windows, uint32_t *out_counts, uint32_t *out_buckets);
+int  bmf_map_windows(bmf_ctx *ctx, const uint8_t *bases, const uint8_t *quals, uint64_t n_bytes,
+                     const uint64_t *win_start, const uint32_t *win_len, uint32_t n_windows,
+                     uint32_t *out_counts, uint32_t *out_buckets);
 
 /* Device-resident form (benchmarks, pipelines): upload once, run many times, download when needed. */
-int  bmf_batch_create(bmf_ctx *ctx, const uint8_t *bases, const uint8_t *quals, const uint64_t *win_off,
-                      uint32_t n_windows, bmf_batch **out);
+int  bmf_batch_create(bmf_ctx *ctx, const uint8_t *bases, const uint8_t *quals, uint64_t n_bytes,
+                      const uint64_t *win_start, const uint32_t *win_len, uint32_t n_windows, bmf_batch **out);
 int  bmf_batch_run(bmf_ctx *ctx, bmf_batch *batch);            /* async on the context's stream */
 int  bmf_batch_download(bmf_ctx *ctx, bmf_batch *batch, uint32_t *out_counts, uint32_t *out_buckets);
 /* Number of index rows ANDed by the last run (reference row reads, q_gram_mapper.h:405, both

@@ -358,13 +358,13 @@ void bmo_query_sequence(const bmo_index *ix, const uint8_t *bases, const uint8_t
 }
 
 uint64_t bmo_map_windows(const bmo_index *ix, const uint8_t *bases, const uint8_t *quals,
-                         const uint64_t *win_off, uint32_t n_windows, uint32_t *out_counts,
-                         uint32_t *out_buckets) {
+                         const uint64_t *win_start, const uint32_t *win_len, uint32_t n_windows,
+                         uint32_t *out_counts, uint32_t *out_buckets) {
     const uint32_t mc = ix->p.max_candidates;
     uint64_t rows_anded = 0;
     for (uint32_t w = 0; w < n_windows; w++) {
-        uint32_t len = (uint32_t)(win_off[w + 1] - win_off[w]);
-        rows_anded += query_sequence_impl(ix, bases + win_off[w], quals + win_off[w], len,
+        uint32_t len = win_len[w];
+        rows_anded += query_sequence_impl(ix, bases + win_start[w], quals + win_start[w], len,
                                           out_buckets + (size_t)(2 * w) * mc, &out_counts[2 * w],
                                           out_buckets + (size_t)(2 * w + 1) * mc, &out_counts[2 * w + 1],
                                           NULL, NULL);

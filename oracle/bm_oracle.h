@@ -83,13 +83,13 @@ void bmo_query_sequence(const bmo_index *ix, const uint8_t *bases_ascii, const u
                         uint32_t len, uint32_t *out_fwd, uint32_t *n_fwd, uint32_t *out_rc,
                         uint32_t *n_rc, uint32_t *dbg_samples, uint32_t *dbg_n_good);
 
-/* Batch form with the same buffer layout as bmf_map_windows (include/bmf.h): window w is
- * bases[win_off[w] .. win_off[w+1]).  out_counts[2w]=fwd count, [2w+1]=rc count;
+/* Batch form with the same buffer layout as bmf_map_windows (include/bmf.h): window w is the view
+ * [win_start[w], win_start[w]+win_len[w]) of bases/quals.  out_counts[2w]=fwd count, [2w+1]=rc count;
  * out_buckets[(2w+o)*max_candidates + i].  Also returns the number of index rows ANDed
  * (the reference's row reads, both orientations) for the algorithmic-bytes figure. */
 uint64_t bmo_map_windows(const bmo_index *ix, const uint8_t *bases, const uint8_t *quals,
-                         const uint64_t *win_off, uint32_t n_windows, uint32_t *out_counts,
-                         uint32_t *out_buckets);
+                         const uint64_t *win_start, const uint32_t *win_len, uint32_t n_windows,
+                         uint32_t *out_counts, uint32_t *out_buckets);
 
 #ifdef __cplusplus
 }

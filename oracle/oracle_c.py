@@ -53,7 +53,7 @@ def lib() -> C.CDLL:
             "bmo_is_highly_distinguishable": (C.c_int, [vp, u32]),
             "bmo_query": (u32, [vp, _u32p, u32, _u32p]),
             "bmo_query_sequence": (None, [vp, _u8p, _u8p, u32, _u32p, _u32p, _u32p, _u32p, _u32p, _u32p]),
-            "bmo_map_windows": (C.c_uint64, [vp, _u8p, _u8p, _u64p, u32, _u32p, _u32p]),
+            "bmo_map_windows": (C.c_uint64, [vp, _u8p, _u8p, _u64p, _u32p, u32, _u32p, _u32p]),
         }
         for name, (res, args) in sig.items():
             fn = getattr(L, name)
@@ -152,15 +152,18 @@ class Index:
                                  C.byref(nr), _p(smp, _u32p), C.byref(ng))
         return of[: nf.value].copy(), orc[: nr.value].copy(), smp, ng.value
 
-    def map_windows(self, bases, quals, win_off):
+    def map_windows(self, bases, quals, win_start, win_len):
         b = np.ascontiguousarray(bases, np.uint8)
         q = np.ascontiguousarray(quals, np.uint8)
-        off = np.ascontiguousarray(win_off, np.uint64)
-        n = len(off) - 1
+        ws = np.ascontiguousarray(win_start, np.uint64)
+        wl = np.ascontiguousarray(win_len, np.uint32)
+        n = len(ws)
+        assert len(wl) == n
         mc = self.params.max_candidates
         counts = np.zeros((n, 2), np.uint32)
         buckets = np.zeros((n, 2, mc), np.uint32)
-        rows = lib().bmo_map_windows(self._h, _p(b, _u8p), _p(q, _u8p), _p(off, _u64p), n, _p(counts, _u32p), _p(buckets, _u32p))
+        rows = lib().bmo_map_windows(self._h, _p(b, _u8p), _p(q, _u8p), _p(ws, _u64p), _p(wl, _u32p), n,
+                                     _p(counts, _u32p), _p(buckets, _u32p))
         return counts, buckets, int(rows)
 
     def __del__(self):
