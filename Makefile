@@ -1,5 +1,6 @@
-# Build of the product libraries (HIP gfx950 filter + C++ host plumbing) and of the test oracle (C).
-# `python -c "import __graft_entry__ as g; g.build()"` drives the same targets.
+# Build of the product (HIP gfx950 filter, C++ host plumbing, `bucketmap` CLI) and of the test
+# infrastructure (C oracle, oracle-backed CLI).  `python -c "import __graft_entry__ as g; g.build()"`
+# drives the same targets.  The reference itself cannot be built here (SeqAn3/Sharg absent): no _ref.
 HIPCC   ?= /opt/rocm/bin/hipcc
 ARCH    ?= gfx950
 HIPFLAGS = --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -shared -Wall -Wno-unused-function
@@ -12,7 +13,10 @@ PKG  = bucket-map_amd
 HOST = $(PKG)/host
 HOST_HDRS = $(wildcard $(HOST)/*.h) include/bmf.h
 
-all: $(PKG)/libbmf.so $(PKG)/libbmhost.so oracle/libbm_oracle.so
+PRODUCT = $(PKG)/libbmf.so $(PKG)/libbmhost.so $(PKG)/bucketmap
+TESTINFRA = oracle/libbm_oracle.so tests/cpp/bucketmap_oracle
+
+all: $(PRODUCT) $(TESTINFRA)
 
 $(PKG)/libbmf.so: $(PKG)/csrc/bmf_api.hip $(PKG)/csrc/bmf_kernels.hip.h include/bmf.h
 	$(HIPCC) $(HIPFLAGS) -o $@ $(PKG)/csrc/bmf_api.hip
@@ -20,10 +24,18 @@ $(PKG)/libbmf.so: $(PKG)/csrc/bmf_api.hip $(PKG)/csrc/bmf_kernels.hip.h include/
 $(PKG)/libbmhost.so: $(HOST)/bm_host_api.cpp $(HOST_HDRS)
 	$(CXX) $(CXXFLAGS) -shared -o $@ $(HOST)/bm_host_api.cpp
 
+# the command-line tool: GPU mapper behind bm::mapper
+$(PKG)/bucketmap: $(HOST)/main.cpp $(HOST)/make_mapper_gpu.cpp $(HOST_HDRS) $(PKG)/libbmf.so
+	$(CXX) $(CXXFLAGS) -o $@ $(HOST)/main.cpp $(HOST)/make_mapper_gpu.cpp -L$(PKG) -lbmf -Wl,-rpath,'$$ORIGIN'
+
 oracle/libbm_oracle.so: oracle/bm_oracle.c oracle/bm_oracle.h
 	$(CC) $(CFLAGS) -o $@ oracle/bm_oracle.c -lm
 
+# TEST ONLY: same main.cpp / locator / SAM code with the CPU oracle plugged in behind bm::mapper
+tests/cpp/bucketmap_oracle: $(HOST)/main.cpp tests/cpp/make_mapper_oracle.cpp oracle/bm_oracle.c oracle/bm_oracle.h $(HOST_HDRS) $(PKG)/libbmf.so
+	$(CXX) $(CXXFLAGS) -o $@ $(HOST)/main.cpp tests/cpp/make_mapper_oracle.cpp oracle/bm_oracle.c -L$(PKG) -lbmf -Wl,-rpath,'$$ORIGIN/../../$(PKG)' -lm
+
 clean:
-	rm -f $(PKG)/libbmf.so $(PKG)/libbmhost.so oracle/libbm_oracle.so
+	rm -f $(PRODUCT) $(TESTINFRA)
 
 .PHONY: all clean

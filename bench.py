@@ -34,7 +34,12 @@ WORKLOADS = {
     "egu": (1_701_312_507, 65536, 300, 1_000_000),        # BASELINE.json configs[1] (headline)
     "ecoli": (4_641_652, 65536, 150, 10_000),             # configs[0] geometry (plumbing)
     "mini": (40_000_000, 65536, 300, 100_000),            # quick rehearsal
+    "grch38": (3_100_000_000, 65536, 150, 1_000_000),     # configs[3] geometry (secondary data point)
 }
+
+# GRCh38 chromosome lengths in Mbp (1..22, X, Y): only their RATIOS are used
+GRCH38_MBP = [248.96, 242.19, 198.30, 190.21, 181.54, 170.81, 159.35, 145.14, 138.39, 133.80, 135.09, 133.28,
+              114.36, 107.04, 101.99, 90.34, 83.26, 80.37, 58.62, 64.44, 46.71, 50.82, 156.04, 57.23]
 
 
 def egu_like_record_lengths(total):
@@ -104,7 +109,12 @@ def main():
 
     # ---------------- synthetic inputs, identical on every rank except the reads
     t0 = time.perf_counter()
-    lens = egu_like_record_lengths(total_bp) if args.workload != "ecoli" else [total_bp]
+    if args.workload == "ecoli":
+        lens = [total_bp]
+    elif args.workload == "grch38":
+        lens = [int(total_bp * m / sum(GRCH38_MBP)) for m in GRCH38_MBP]
+    else:
+        lens = egu_like_record_lengths(total_bp)
     genome = host.Genome.synth(20240001, lens, threads)
     nb = genome.awk_bucket_num(bucket_len)
     log(f"genome: {len(lens)} records, {genome.total_length()} bp, NB={nb} ({time.perf_counter() - t0:.1f}s)")

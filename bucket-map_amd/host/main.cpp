@@ -1,0 +1,99 @@
+// main.cpp -- the `bucketmap` command-line tool (bucket_map/main.cpp:135-234), MI355X edition.
+//
+//   bucketmap -x -i <name> --genome ref.fa                       index only (writes into the cwd)
+//   bucketmap -i <name> -q reads.fq -o out.sam --genome ref.fa    map (indexes first if needed)
+//
+// Same flags, same stderr tags, same exit codes as the reference; the candidate-bucket filter runs on
+// the GPU(s) given by --gpus (default device 0) through bm::mapper.  Which mapper sits behind the
+// interface is decided by bm_make_mapper (make_mapper_gpu.cpp for the product).
+#include "bucket_locator.h"
+#include "cli.h"
+#include "bm_indexer.h"
+#include "mapper.h"
+
+#include <iostream>
+#include <memory>
+
+// Defined per build: the product links make_mapper_gpu.cpp.
+std::unique_ptr<bm::mapper> bm_make_mapper(const bm::cmd_arguments &args, unsigned int num_buckets, unsigned int fault);
+
+int main(int argc, char **argv) {
+    bm::cmd_arguments args;
+    try {
+        args = bm::parse_arguments(argc, argv);
+    } catch (bm::parser_error const &ext) {
+        std::cerr << "[ERROR]\t\t" << ext.what() << "\n";   // main.cpp:148-155
+        return -1;
+    }
+    std::cerr << "[INFO]\t\tNot using Smith-Waterman for alignment verifications.\n";
+    if (args.genome_path.empty()) {
+        // the reference prints this when BM_* are not defined at build time (main.cpp:227-231)
+        std::cerr << "[ERROR]\t\tThe definition of BM_BUCKET_NUM, BM_BUCKET_LEN or BM_GENOME_FILE is not found. "
+                     "Pass --genome (and optionally --bucket-len / --num-buckets).\n";
+        return -1;
+    }
+    try {
+        bm::Genome genome = bm::read_fasta(args.genome_path.string());
+        const unsigned int num_buckets = args.num_buckets ? args.num_buckets : bm::awk_bucket_num(genome, args.bucket_len);
+        std::cerr << "[INFO]\t\tInitializing indexer and mapper with bucket length: " << args.bucket_len
+                  << ", and number of buckets: " << num_buckets << ".\n";
+        const std::filesystem::path cwd = std::filesystem::current_path();
+
+        // locator::initialize -> indexer::index (locator.h:33-34, bucket_indexer.h:170-216): build the
+        // index files unless they exist already (the reference then prints an error and carries on).
+        auto run_indexer = [&]() {
+            if (bm::index_file_exists(cwd, args.index_indicator + ".qgram")) {
+                std::cerr << "[ERROR]\t\tThe specified file already exists in directory: "
+                          << (cwd / (args.index_indicator + ".qgram")) << ".\n";
+                return;
+            }
+            std::cerr << "[INFO]\t\tSet index seed length to be: " << static_cast<int>(args.index_seed_length) << ".\n";
+            auto t0 = std::chrono::steady_clock::now();
+            bm::QgramIndex ix = bm::build_index(genome, num_buckets, static_cast<int>(args.bucket_len),
+                                                static_cast<int>(args.max_read_length), args.index_seed_length,
+                                                bm::FracMinHash::from_seed(args.hash_seed), args.frac_min_hash,
+                                                args.host_threads);
+            std::cerr << "[INFO]\t\tNumber of remaining k-mers after FracMinHash is " << ix.num_rows << " out of "
+                      << ix.kmer_to_index.size() << " (" << static_cast<float>(ix.num_rows) / ix.kmer_to_index.size() * 100
+                      << "%).\n";
+            bm::write_index(ix, cwd, args.index_indicator);
+            std::cerr << "[INFO]\t\tThe bucket q-gram index is stored in: " << (cwd / (args.index_indicator + ".qgram")) << ".\n";
+            std::cerr << "[INFO]\t\tThe number of buckets: " << ix.bucket_id.size() << ".\n";
+            std::cerr << "[INFO]\t\tThe bucket ids are stored in: " << (cwd / (args.index_indicator + ".bucket_id")) << ".\n";
+            std::cerr << "[INFO]\t\tThe kmer indexes are stored in: " << (cwd / (args.index_indicator + ".kmers_index")) << ".\n";
+            std::cerr << "[BENCHMARK]\tElapsed time for creating and storing index files: "
+                      << std::chrono::duration<float>(std::chrono::steady_clock::now() - t0).count() << " s.\n";
+        };
+
+        if (args.only_indexer) {   // main.cpp:186-189
+            run_indexer();
+            return 0;
+        }
+        if (args.output_sam_path.empty()) {
+            std::cerr << "[ERROR]\t\tThe output sam file is not set. Please set the output path using '-o' option.\n";
+            return 1;
+        }
+        if (args.query_seed_length < args.index_seed_length) {
+            std::cerr << "[ERROR]\t\tThe query seed length (currently set to " << static_cast<int>(args.query_seed_length)
+                      << ") should be larger thanthe index seed length (currently set to "
+                      << static_cast<int>(args.index_seed_length) << ").\n";
+            return 1;
+        }
+
+        // main.cpp:202-209: fault = ceil(S * e) with a float32 product
+        const unsigned int fault = bm::ceil_mul_f32(args.allowed_seed_miss_rate, args.mapper_sample_size);
+        std::unique_ptr<bm::mapper> map = bm_make_mapper(args, num_buckets, fault);
+        // main.cpp:211-218 (the locator receives -b, not -u, as its quality threshold)
+        bm::bucket_locator loc(map.get(), args.bucket_len, args.max_read_length, args.query_seed_length,
+                               args.allowed_seed_miss_rate, args.locator_allowed_indel_rate,
+                               static_cast<unsigned int>(args.locator_sample_size), args.average_base_quality);
+        run_indexer();
+        loc.initialize(genome, cwd, args.index_indicator);                                    // main.cpp:221
+        loc.locate(args.fastq_path.string(), cwd / (args.index_indicator + ".bucket_id"),     // main.cpp:224
+                   args.output_sam_path, args.locator_quality_threshold);
+    } catch (const std::exception &e) {
+        std::cerr << "[ERROR]\t\t" << e.what() << "\n";
+        return 2;
+    }
+    return 0;
+}

@@ -19,7 +19,8 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     # Build in-tree libraries if they are missing (the GPU box receives them prebuilt).
     need = [os.path.join(ROOT, "bucket-map_amd", "libbmf.so"), os.path.join(ROOT, "bucket-map_amd", "libbmhost.so"),
-            os.path.join(ROOT, "oracle", "libbm_oracle.so")]
+            os.path.join(ROOT, "oracle", "libbm_oracle.so"), os.path.join(ROOT, "bucket-map_amd", "bucketmap"),
+            os.path.join(ROOT, "tests", "cpp", "bucketmap_oracle")]
     if not all(os.path.exists(p) for p in need):
         subprocess.run(["make", "-C", ROOT], check=True, stdout=subprocess.DEVNULL)
 

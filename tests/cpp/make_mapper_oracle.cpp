@@ -1,0 +1,56 @@
+// make_mapper_oracle.cpp -- TEST INFRASTRUCTURE: the CPU oracle behind bm::mapper.
+//
+// Links oracle/bm_oracle.c into the same `bucketmap` main as the product, so that (a) the host plumbing
+// (FASTQ loop, windowing, scatter, locator, SAM) can be exercised without a GPU and (b) the SAM file of
+// the GPU build can be compared with the SAM file of an oracle-backed build on the same inputs.
+// Never shipped: built only by tests/ into tests/cpp/bucketmap_oracle.
+#include "../../bucket-map_amd/host/cli.h"
+#include "../../bucket-map_amd/host/gpu_q_gram_mapper.h"   // for bm::batched_mapper (host half of map())
+#include "../../oracle/bm_oracle.h"
+
+#include <memory>
+
+namespace {
+
+class oracle_mapper : public bm::batched_mapper {
+    bmo_params p_{};
+    bmo_index *ix_ = nullptr;
+
+protected:
+    bool index_loaded() const override { return ix_ != nullptr; }
+    bool query_windows(const uint8_t *bases, const uint8_t *quals, uint64_t, const uint64_t *win_start,
+                       const uint32_t *win_len, uint32_t n, uint32_t *counts, uint32_t *buckets) override {
+        bmo_map_windows(ix_, bases, quals, win_start, win_len, n, counts, buckets);
+        return true;
+    }
+
+public:
+    oracle_mapper(const bm::cmd_arguments &a, unsigned int num_buckets, unsigned int fault)
+        : bm::batched_mapper(num_buckets, a.max_read_length, 30, 5) {
+        p_.num_buckets = num_buckets;
+        p_.q = a.index_seed_length;
+        p_.k = a.query_seed_length;
+        p_.num_samples = a.mapper_sample_size;
+        p_.num_fault = fault;
+        p_.threshold = bmo_threshold(a.mapper_distinguishability_threshold, num_buckets);
+        p_.min_base_quality = a.average_base_quality * a.query_seed_length;
+        p_.max_candidates = 30;
+        p_.read_len = a.max_read_length;
+        p_.num_segment_samples = 5;
+    }
+    ~oracle_mapper() override { bmo_index_destroy(ix_); }
+    void load(std::filesystem::path const &dir, const std::string &indicator) override {
+        if (ix_) return;
+        ix_ = bmo_index_load(&p_, dir.string().c_str(), indicator.c_str());
+    }
+    void reset() override {
+        bmo_index_destroy(ix_);
+        ix_ = nullptr;
+    }
+};
+
+}  // namespace
+
+std::unique_ptr<bm::mapper> bm_make_mapper(const bm::cmd_arguments &args, unsigned int num_buckets, unsigned int fault) {
+    return std::make_unique<oracle_mapper>(args, num_buckets, fault);
+}

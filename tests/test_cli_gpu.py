@@ -1,0 +1,104 @@
+"""End to end on the GPU: the `bucketmap` tool (GPU mapper behind bm::mapper) must write the SAME SAM
+file as the same tool with the CPU oracle behind bm::mapper -- candidate buckets feed the locator, so
+identical SAM means identical candidate sets AND identical mapping positions (north_star).  Also
+covers the multi-context split of one batch (the code path used with several GPUs) and full-size
+properties of the filter at the BASELINE geometry."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import Case, assert_same_candidates
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+GPU_CLI = os.path.join(ROOT, "bucket-map_amd", "bucketmap")
+ORACLE_CLI = os.path.join(ROOT, "tests", "cpp", "bucketmap_oracle")
+
+
+def _run(exe, args, cwd):
+    r = subprocess.run([exe, *args], cwd=str(cwd), capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    return r.stderr
+
+
+@pytest.mark.parametrize("gpus,long_reads", [("0", False), ("0,0", False), ("0,0,0", True)])
+def test_sam_identical_to_oracle_backed_run(tmp_path, gpus, long_reads):
+    from bucket_map_amd import host
+    g = host.Genome.synth(21, [400_000, 150_000, 30_000])
+    g.write_fasta(str(tmp_path / "g.fa"))
+    rd = host.Reads(g, 8192, 150, 900 if long_reads else 150, 400 if long_reads else 3000, sub=0.01, seed=6)
+    rd.write_fastq(str(tmp_path / "reads"))
+    common = ["-i", "idx", "--genome", "g.fa", "--bucket-len", "8192", "-r", "150", "-f", "1", "-q", "reads.fastq"]
+    _run(GPU_CLI, ["-x", "-i", "idx", "--genome", "g.fa", "--bucket-len", "8192", "-r", "150", "-f", "1"], tmp_path)
+    err = _run(GPU_CLI, [*common, "-o", "gpu.sam", "--gpus", gpus], tmp_path)
+    assert "Elapsed time for bucket mapping" in err
+    _run(ORACLE_CLI, [*common, "-o", "cpu.sam"], tmp_path)
+    gpu_sam, cpu_sam = (tmp_path / "gpu.sam").read_bytes(), (tmp_path / "cpu.sam").read_bytes()
+    assert gpu_sam == cpu_sam
+    assert gpu_sam.count(b"\n") > 0.9 * rd.n
+
+
+def test_cli_without_index_files_builds_them(tmp_path):
+    # locator::initialize indexes first when the files are missing (locator.h:33-34)
+    from bucket_map_amd import host
+    g = host.Genome.synth(22, [100_000])
+    g.write_fasta(str(tmp_path / "g.fa"))
+    host.Reads(g, 8192, 150, 150, 200, seed=7).write_fastq(str(tmp_path / "reads"))
+    _run(GPU_CLI, ["-i", "fresh", "--genome", "g.fa", "--bucket-len", "8192", "-r", "150", "-f", "1", "-q", "reads.fastq",
+                   "-o", "o.sam"], tmp_path)
+    assert (tmp_path / "fresh.qgram").exists() and (tmp_path / "o.sam").stat().st_size > 0
+
+
+def test_full_size_properties():
+    """BASELINE configs[1] geometry (Egu-like 1.70 Gbp, NB ~ 26.4 k, -f 1 index, 300 bp reads) with a
+    reduced read count: oracle parity on a sample, source bucket recovered, idempotence, permutation
+    and batch-split invariance -- properties that do not depend on the batch size."""
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    import bucket_map_amd as bma
+    from bucket_map_amd import host
+    from oracle import oracle_c
+
+    genome = host.Genome.synth(20240001, bench.egu_like_record_lengths(1_701_312_507))
+    nb = genome.awk_bucket_num(65536)
+    assert 26_000 < nb < 27_000
+    index = host.Index(genome, nb, 65536, 300, q=9)
+    reads = host.Reads(genome, 65536, 300, 300, 200_000, seed=20240003)
+    cli = dict(read_len=300)
+    flt = bma.Filter(bma.Params.from_cli(nb, **cli))
+    flt.load_index_ptr(index.rows_ptr, index.num_rows, index.k2i_ptr, index.num_kmers)
+    ws, wl, _, _ = bma.windows_for_reads(reads.offsets, 300)
+    c, b = flt.map_windows(reads.bases, reads.quals, ws, wl)
+    # (a) parity with the oracle on a sample
+    n = 1500
+    ora = oracle_c.Index(oracle_c.params_from_cli(nb, **cli), rows_ptr=index.rows_ptr, n_rows=index.num_rows,
+                         k2i_ptr=index.k2i_ptr, n_kmers=index.num_kmers)
+    c_ref, b_ref, _ = ora.map_windows(reads.bases, reads.quals, ws[:n], wl[:n])
+    assert_same_candidates(c_ref, b_ref, c[:n], b[:n], "full-size sample")
+    # (b) reads recover their source bucket on their strand, as the reference's logs report (95-99 %)
+    s = reads.truth_rc.astype(np.int64)
+    i = np.arange(reads.n)
+    own = b[i, s]
+    valid = np.arange(own.shape[1])[None, :] < c[i, s][:, None]
+    assert ((own == reads.truth_bucket[:, None]) & valid).any(axis=1).mean() > 0.97
+    # (c) lists are ascending and within range
+    for o in (0, 1):
+        lst = b[:, o, :].astype(np.int64)
+        m = np.arange(lst.shape[1])[None, :] < c[:, o][:, None]
+        assert (lst[m] < nb).all()
+        asc = (np.diff(lst, axis=1) > 0) | ~m[:, 1:]
+        assert asc.all()
+    # (d) idempotence, permutation, batch split
+    c2, b2 = flt.map_windows(reads.bases, reads.quals, ws, wl)
+    assert_same_candidates(c, b, c2, b2, "idempotence")
+    perm = np.random.default_rng(3).permutation(len(ws))
+    cp, bp = flt.map_windows(reads.bases, reads.quals, ws[perm], wl[perm])
+    assert_same_candidates(c[perm], b[perm], cp, bp, "permutation")
+    h = 77_777
+    ca, ba = flt.map_windows(reads.bases, reads.quals, ws[:h], wl[:h])
+    assert_same_candidates(c[:h], b[:h], ca, ba, "batch split")
+    flt.close()

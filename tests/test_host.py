@@ -1,0 +1,201 @@
+"""Host plumbing either side of the filter (no GPU): bucket cutting, the host indexer and its three
+file formats, the read simulator, the `bucketmap` command line, the locator and the SAM writer.
+
+The command-line tests drive tests/cpp/bucketmap_oracle: the SAME main.cpp / locator / SAM code as the
+product, with the CPU oracle plugged in behind bm::mapper (test infrastructure, never shipped), so the
+plumbing is exercised without a GPU.  tests/test_cli_gpu.py repeats the run with the real GPU mapper and
+requires an identical SAM file.
+"""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from bucket_map_amd import host
+from oracle import bm_oracle_np as onp
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+ORACLE_CLI = os.path.join(ROOT, "tests", "cpp", "bucketmap_oracle")
+
+
+def build_oracle_cli():
+    src = [os.path.join(ROOT, "bucket-map_amd", "host", "main.cpp"), os.path.join(ROOT, "tests", "cpp", "make_mapper_oracle.cpp"),
+           os.path.join(ROOT, "oracle", "bm_oracle.c")]
+    newest = max(os.path.getmtime(p) for p in src + [os.path.join(ROOT, "bucket-map_amd", "host", f)
+                                                      for f in os.listdir(os.path.join(ROOT, "bucket-map_amd", "host"))])
+    if not os.path.exists(ORACLE_CLI) or os.path.getmtime(ORACLE_CLI) < newest:
+        subprocess.run(["g++", "-O2", "-std=c++17", "-pthread", "-o", ORACLE_CLI, *src, "-L" + os.path.join(ROOT, "bucket-map_amd"),
+                        "-lbmf", "-Wl,-rpath," + os.path.join(ROOT, "bucket-map_amd"), "-lm"], check=True)
+    return ORACLE_CLI
+
+
+# ------------------------------------------------------------------ bucket cutting (utils.h:60-102)
+
+def test_bucket_cutting_rules():
+    g = host.Genome.synth(1, [65536 * 2 + 100, 65536 + 301, 500, 300])
+    b = g.cut_buckets(65536, 300)
+    # record 0: 3 buckets by ceil, the third is 100 bases <= read_len -> skipped
+    # record 1: 2 buckets, the second is 301 > 300 -> kept;  record 2: 1 bucket of 500;  record 3: 300 <= 300 skipped
+    assert [tuple(x) for x in b] == [(0, 0, 0, 65836), (0, 1, 65536, 131172), (1, 0, 0, 65836), (1, 1, 65536, 65837),
+                                     (2, 0, 0, 500)]
+    # BM_BUCKET_NUM by the CMake awk rule counts the skipped tails too
+    assert g.awk_bucket_num(65536) == 3 + 2 + 1 + 1
+    # overlap: every bucket but the last of a record extends read_len bases into the next
+    assert b[0][3] - b[0][2] == 65536 + 300
+
+
+def test_fasta_roundtrip(tmp_path):
+    g = host.Genome.synth(2, [1000, 61, 60, 1])
+    p = str(tmp_path / "g.fa")
+    g.write_fasta(p)
+    h = host.Genome.read_fasta(p)
+    assert h.n_records == 4
+    for i in range(4):
+        assert h.record_id(i) == g.record_id(i)
+        assert bytes(h.record_seq(i)) == bytes(g.record_seq(i))
+    # lower case, U and ambiguity codes: FASTA is read as dna5 then folded to dna4 (N and IUPAC -> A)
+    (tmp_path / "x.fa").write_text(">r1 some description\nacgtUNRY\nnnAC\n")
+    x = host.Genome.read_fasta(str(tmp_path / "x.fa"))
+    assert x.record_id(0) == "r1 some description"
+    assert bytes(x.record_seq(0)) == b"ACGTTAAAAAAC"
+
+
+# ------------------------------------------------------------------ indexer (bucket_indexer.h:49-127,138-216)
+
+def test_index_against_bruteforce_and_file_formats(tmp_path):
+    g = host.Genome.synth(3, [9000, 2500])
+    bl, rl, q = 1024, 100, 5
+    nb = g.awk_bucket_num(bl) + 2                       # two padding buckets
+    ix = host.Index(g, nb, bl, rl, q=q, kmer_frac=1.0, threads=3)
+    buckets = g.cut_buckets(bl, rl)
+    want = np.zeros((4 ** q, nb), bool)
+    for b, (rec, _, s, e) in enumerate(buckets):
+        want[onp.kmer_hashes(g.record_seq(rec)[s:e], q), b] = True
+    got = onp.unpack_rows(ix.rows(), nb)
+    assert np.array_equal(got, want)
+    assert np.array_equal(ix.kmer_to_index(), np.arange(4 ** q))
+    # files: SURVEY App. B.2
+    ix.write(str(tmp_path), "t")
+    raw = (tmp_path / "t.qgram").read_bytes()
+    assert len(raw) == 4 ** q * ((nb + 7) // 8) and raw == ix.rows().tobytes()
+    lines = (tmp_path / "t.kmers_index").read_text().split("\n")
+    assert lines[-1] == "" and [int(v) for v in lines[:-1]] == list(range(4 ** q))
+    ids = (tmp_path / "t.bucket_id").read_text().split("\n")
+    assert ids[:-1] == [g.record_id(int(rec)) for rec, *_ in buckets]
+
+
+def test_fracminhash_row_selection():
+    g = host.Genome.synth(4, [5000])
+    ix = host.Index(g, 6, 1024, 100, q=6, kmer_frac=0.25, hash_seed=99)
+    k2i = ix.kmer_to_index()
+    kept = k2i >= 0
+    assert 0.2 < kept.mean() < 0.32                      # threshold 2500 of 10000 hash values, "<="
+    assert np.array_equal(k2i[kept], np.arange(kept.sum()))   # rows numbered in ascending q-gram hash
+    assert ix.num_rows == kept.sum()
+    # same seed -> same selection (the reference seeds from time(); ours is reproducible)
+    assert np.array_equal(host.Index(g, 6, 1024, 100, q=6, kmer_frac=0.25, hash_seed=99).kmer_to_index(), k2i)
+
+
+# ------------------------------------------------------------------ simulator (short_read_simulator.h:157-240)
+
+def test_simulator_is_seeded_and_truthful():
+    g = host.Genome.synth(5, [50_000, 20_000])
+    a = host.Reads(g, 4096, 150, 150, 500, sub=0, ins=0, dele=0, seed=7, threads=1)
+    b = host.Reads(g, 4096, 150, 150, 500, sub=0, ins=0, dele=0, seed=7, threads=4)
+    assert np.array_equal(a.bases, b.bases) and np.array_equal(a.truth_bucket, b.truth_bucket)   # thread-count independent
+    buckets = g.cut_buckets(4096, 150)
+    comp = bytes.maketrans(b"ACGT", b"TGCA")
+    for r in range(200):
+        rec, _, s, e = (int(x) for x in buckets[a.truth_bucket[r]])
+        o = int(a.truth_offset[r])
+        ref = bytes(g.record_seq(rec)[s + o: min(s + o + 150, e)])
+        got = bytes(a.bases[int(a.offsets[r]): int(a.offsets[r + 1])])
+        assert got == (ref.translate(comp)[::-1] if a.truth_rc[r] else ref)
+    assert 0.35 < a.truth_rc.mean() < 0.65
+    assert (a.quals == ord("E")).all()
+    c = host.Reads(g, 4096, 150, 150, 500, sub=0.02, ins=0.005, dele=0.005, seed=7)
+    lens = np.diff(c.offsets.astype(np.int64))
+    assert lens.min() < 150 < lens.max()                  # indels change read lengths
+
+
+# ------------------------------------------------------------------ command line + locator + SAM
+
+@pytest.fixture(scope="module")
+def cli_case(tmp_path_factory):
+    d = tmp_path_factory.mktemp("cli")
+    g = host.Genome.synth(11, [300_000, 120_000, 40_000])
+    g.write_fasta(str(d / "g.fa"))
+    rd = host.Reads(g, 8192, 150, 150, 1500, seed=5)
+    rd.write_fastq(str(d / "reads"))
+    return d, g, rd
+
+
+def run_cli(exe, args, cwd):
+    return subprocess.run([exe, *args], cwd=str(cwd), capture_output=True, text=True)
+
+
+def parse_sam(path):
+    header, recs = [], []
+    for line in open(path):
+        if line.startswith("@"):
+            header.append(line.rstrip("\n"))
+        else:
+            f = line.rstrip("\n").split("\t")
+            assert len(f) == 11
+            recs.append((f[0], int(f[1]), f[2], int(f[3]), int(f[4]), f[5], f[9], f[10]))
+    return header, recs
+
+
+def test_cli_index_then_map(cli_case):
+    d, g, rd = cli_case
+    exe = build_oracle_cli()
+    common = ["-i", "idx", "--genome", "g.fa", "--bucket-len", "8192", "-r", "150", "-f", "1"]
+    r = run_cli(exe, ["-x", *common], d)
+    assert r.returncode == 0, r.stderr
+    for ext in ("qgram", "kmers_index", "bucket_id"):
+        assert (d / f"idx.{ext}").exists()
+    r = run_cli(exe, [*common, "-q", "reads.fastq", "-o", "out.sam", "--version-check", "0"], d)
+    assert r.returncode == 0, r.stderr
+    assert "[BENCHMARK]\tElapsed time for bucket mapping:" in r.stderr
+    assert "already exists" in r.stderr                   # the indexer refuses to overwrite, then carries on
+    header, recs = parse_sam(d / "out.sam")
+    assert header[0] == "@HD\tVN:1.6"
+    # @SQ: name up to the first space, LN = #buckets * bucket_len (upper bound, bucket_locator.h:491)
+    assert header[1:] == ["@SQ\tSN:synth1\tLN:303104", "@SQ\tSN:synth2\tLN:122880", "@SQ\tSN:synth3\tLN:40960"]
+    truth = [l.split() for l in open(d / "reads.position_ground_truth")]
+    by_read = {}
+    for qname, flag, rname, pos, mapq, cigar, seq, qual in recs:
+        assert cigar == "*" and flag in (0, 16) and 0 <= mapq <= 60
+        by_read.setdefault(int(qname), []).append((flag, rname, pos))
+    correct = 0
+    for i, t in enumerate(truth):
+        ref, pos, rc = int(t[0]), int(t[1]), int(t[2])
+        for flag, rname, p in by_read.get(i, []):
+            if rname == f"synth{ref + 1}" and abs(p - pos) <= 6 and (flag == 16) == bool(rc):
+                correct += 1
+                break
+    assert correct > 0.97 * len(truth), f"{correct}/{len(truth)} reads at their true position"
+    # reads whose exact start is bucket offset 0 are dropped by `offset > 0` -- unmapped
+    # reads produce no record at all
+    assert len(by_read) <= len(truth)
+
+
+def test_cli_error_behaviour(cli_case):
+    d, _, _ = cli_case
+    exe = build_oracle_cli()
+    r = run_cli(exe, ["--genome", "g.fa"], d)
+    assert r.returncode == 255 and "[ERROR]" in r.stderr and "required" in r.stderr      # -i missing -> -1
+    r = run_cli(exe, ["-i", "idx", "--genome", "g.fa", "-q", "reads.fastq"], d)
+    assert r.returncode == 1 and "output sam file is not set" in r.stderr                # main.cpp:190-193
+    r = run_cli(exe, ["-i", "idx", "--genome", "g.fa", "-q", "reads.fastq", "-o", "o2.sam", "-l", "8"], d)
+    assert r.returncode == 1 and "query seed length" in r.stderr                          # main.cpp:194-198
+    r = run_cli(exe, ["-i", "idx", "--genome", "g.fa", "-q", "reads.txt", "-o", "o2.sam"], d)
+    assert r.returncode == 255                                                            # wrong extension
+    (d / "exists.sam").write_text("")
+    r = run_cli(exe, ["-i", "idx", "--genome", "g.fa", "-q", "reads.fastq", "-o", "exists.sam"], d)
+    assert r.returncode == 255 and "already exists" in r.stderr                           # output_file_validator
+    r = run_cli(exe, ["-i", "idx", "-q", "reads.fastq", "-o", "o3.sam"], d)
+    assert r.returncode == 255 and "BM_BUCKET_NUM" in r.stderr                            # no genome configured
+    r = run_cli(exe, ["-i", "idx", "--genome", "g.fa", "--bogus", "1"], d)
+    assert r.returncode == 255
