@@ -66,8 +66,15 @@ def main():
     ap.add_argument("--reads", type=int, default=0, help="reads per GPU (default: the workload's)")
     ap.add_argument("--params", default="default", choices=["default", "bench"],
                     help="default = CLI defaults (k12 q9 S15 F6); bench = benchmark_map.sh (-s 20 -e 0.6 -l 14 -b 10)")
-    ap.add_argument("--cpu-sample", type=int, default=20000, help="reads timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=200000, help="reads timed on the CPU oracle (0 = skip)")
     ap.add_argument("--host-threads", type=int, default=0)
+    ap.add_argument("--early-exit", action="store_true",
+                    help="BMF_FLAG_EARLY_EXIT: identical outputs, fewer rows actually read (off by default so "
+                         "that the roofline line prices exactly the reference's row reads)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend for the barrier / max-over-ranks (nccl = RCCL)")
+    ap.add_argument("--device-override", type=int, default=-1,
+                    help="rehearsal only: put every rank on this device (use with --backend gloo)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -84,10 +91,14 @@ def main():
     import torch.distributed as dist
     import numpy as np
 
-    torch.cuda.set_device(local_rank)
+    device = local_rank if args.device_override < 0 else args.device_override
+    torch.cuda.set_device(device)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", device))
+        else:
+            dist.init_process_group(backend="gloo")
 
     import bucket_map_amd as bma
     from bucket_map_amd import host
@@ -129,7 +140,7 @@ def main():
     log(f"reads: {reads.n} x {read_len} bp ({time.perf_counter() - t0:.1f}s)")
 
     # ---------------- GPU side
-    params = bma.Params.from_cli(nb, device=local_rank, **cli)
+    params = bma.Params.from_cli(nb, device=device, flags=bma.BMF_FLAG_EARLY_EXIT if args.early_exit else 0, **cli)
     flt = bma.Filter(params)
     t0 = time.perf_counter()
     flt.load_index_ptr(index.rows_ptr, index.num_rows, index.k2i_ptr, index.num_kmers)
@@ -156,7 +167,7 @@ def main():
     elapsed = time.perf_counter() - t_start
     ms_sample, ms_vote = flt.profile_end(args.steps)
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
         dist.barrier()
@@ -191,15 +202,29 @@ def main():
                             f"(k={params.k} q={params.q} S={params.num_samples} F={params.num_fault})",
                 "reads_per_gpu": int(reads.n), "global_reads_per_step": int(world * reads.n),
                 "parallelism": f"reads sharded over {world} GPU(s), index replicated, no collective",
+                "early_exit": bool(args.early_exit),
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                "frac": achieved / HBM_PEAK_GBPS, "traffic": None, "traffic_source": None,
                 "kernel": "bmf_vote_kernel", "kernel_ms": vote_ms, "algorithmic_bytes_per_launch": int(algo_bytes_vote),
                 "bytes_per_read": algo_bytes_read / reads.n, "sample_kernel_ms": float(np.mean(ms_sample)),
             },
             "checks": {"reads_with_candidates": mapped, "source_bucket_recovered": recovered},
         }
+
+        # HBM-side traffic of the vote kernel: PMC counters cannot be read in-process, so the value comes
+        # from the committed rocprofv3 --pmc FETCH_SIZE pass of the SAME workload (tools/profile.sh),
+        # corrected as MI355X_MICROARCH.md prescribes (KiB -> bytes, x2 on gfx950); null if none matches.
+        try:
+            with open(os.path.join(ROOT, "profiles", "pmc_latest.json")) as f:
+                pmc = json.load(f)
+            if (pmc.get("workload") == args.workload and pmc.get("params") == args.params
+                    and pmc.get("reads") == int(reads.n) and not args.early_exit):
+                result["roofline"]["traffic"] = pmc["vote_kernel_traffic_bytes"]
+                result["roofline"]["traffic_source"] = pmc["source"]
+        except (OSError, ValueError, KeyError):
+            pass
 
         # ---------------- CPU baseline (oracle = port of the reference algorithm, 1 thread) + parity sample
         if args.cpu_sample > 0:

@@ -209,11 +209,13 @@ int bmf_create(const bmf_params *params, bmf_ctx **out) {
     d.max_cand = p.max_candidates;
     d.read_len = p.read_len;
     d.max_kmers = p.read_len - p.k + 1;
-    d.list_len = d.S * d.G;
+    // S*G row ids, rounded up to the ring depth, plus one ring of padding (all-ones rows)
+    d.list_len = (d.S * d.G + (uint32_t)c->depth - 1u) / (uint32_t)c->depth * (uint32_t)c->depth + (uint32_t)c->depth;
     d.n_chunks = n_chunks;
     d.pitch = (row_bytes + 127u) & ~127u;
     d.ones_row = 0;
     d.n_kmers = 0;
+    d.early_exit = (p.flags & BMF_FLAG_EARLY_EXIT) ? 1u : 0u;
     c->sample_lds = ((2 * (size_t)p.read_len + 256 + 3) & ~(size_t)3) + 4 * (size_t)d.max_kmers;
 
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);

@@ -34,11 +34,12 @@ struct DevParams {
     uint32_t max_cand;
     uint32_t read_len;
     uint32_t max_kmers;  // read_len - k + 1
-    uint32_t list_len;   // S*G : row ids per (window, orientation)
+    uint32_t list_len;   // row ids per (window, orientation): S*G rounded up to the ring depth, + depth (padding)
     uint32_t n_chunks;   // ceil(ceil(NB/8)/16) : 16-byte chunks per row that hold buckets
     uint32_t pitch;      // bytes between rows in HBM (multiple of 128)
     uint32_t ones_row;   // id of the all-ones row appended after the index (for un-indexed q-grams)
     uint32_t n_kmers;    // entries of kmer_to_index (4^q, or 0 when no .kmers_index was loaded)
+    uint32_t early_exit; // 1 = stop streaming rows once no bucket can have < F misses (BMF_FLAG_EARLY_EXIT)
 };
 
 __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
@@ -185,9 +186,14 @@ __global__ __launch_bounds__(kWave) void bmf_sample_kernel(
             cnt += (i1 >= 0) + (i2 >= 0);
         }
     }
+    // pad both lists with the all-ones row (see bmf_vote_kernel)
+    for (uint32_t t = P.S * P.G + lane; t < P.list_len; t += kWave) {
+        list_fwd[t] = P.ones_row;
+        list_rc[t] = P.ones_row;
+    }
     cnt = wave_sum(cnt);
     if (lane == 0) {
-        list_n[w] = P.list_len;
+        list_n[w] = P.S * P.G;
         rows_anded[w] = cnt;
     }
 }
@@ -207,111 +213,67 @@ __device__ __forceinline__ u128 load_chunk(const uint8_t *p) {
     return r;
 }
 
-// CPL   : 16-byte chunks per lane (lane l owns chunks l, l+64, ...: every load is 1 KiB contiguous)
-// PLANES: bits of the saturating per-bucket miss counter, 2^PLANES-1 >= F
-// DEPTH : index rows in flight per wave (register ring)
-template <int CPL, int PLANES, int DEPTH>
-__global__ __launch_bounds__(kWave) void bmf_vote_kernel(DevParams P, const uint8_t *__restrict__ rows,
-                                                        const uint32_t *__restrict__ row_lists,
-                                                        const uint32_t *__restrict__ list_n,
-                                                        uint32_t *__restrict__ out_counts,
-                                                        uint32_t *__restrict__ out_buckets) {
-    const uint32_t item = blockIdx.x;          // 2*window + orientation
-    const uint32_t lane = threadIdx.x;
-    const uint32_t n = list_n[item >> 1];      // S*G, or 0 for a rejected window
-    if (n == 0) {
-        if (lane == 0) out_counts[item] = 0;
-        return;
-    }
-    const uint32_t *__restrict__ list = row_lists + (size_t)item * P.list_len;
-
-    uint32_t coff[CPL];
-    bool cval[CPL];
-#pragma unroll
-    for (int j = 0; j < CPL; j++) {
-        const uint32_t c = lane + kWave * j;
-        cval[j] = c < P.n_chunks;
-        coff[j] = c * 16u;
-    }
-
-    u128 ring[DEPTH][CPL];
-#pragma unroll
-    for (int d = 0; d < DEPTH; d++) {
-        if ((uint32_t)d < n) {
-            const uint8_t *rp = rows + (size_t)list[d] * P.pitch;
-#pragma unroll
-            for (int j = 0; j < CPL; j++)
-                if (cval[j]) ring[d][j] = load_chunk(rp + coff[j]);
-        }
-    }
-
-    u128 bf[CPL];             // AND of the current sample's rows (q_gram_mapper.h:400-406)
-    u128 cnt[PLANES][CPL];    // bit-sliced miss counters
+// fault_tolerate_filter::read (q_gram_mapper.h:75-88) in counter form: every bucket whose AND-ed bit
+// is 0 takes one more miss; the PLANES-bit counter saturates at all ones (>= F).  Resets bf to all ones.
+template <int CPL, int PLANES>
+__device__ __forceinline__ void count_misses(u128 (&bf)[CPL], u128 (&cnt)[PLANES][CPL]) {
 #pragma unroll
     for (int j = 0; j < CPL; j++)
 #pragma unroll
         for (int x = 0; x < 4; x++) {
-            bf[j].v[x] = 0xFFFFFFFFu;
+            uint32_t sat = cnt[0][j].v[x];
 #pragma unroll
-            for (int p = 0; p < PLANES; p++) cnt[p][j].v[x] = 0;
-        }
-
-    uint32_t g = 0;
-    for (uint32_t i = 0; i < n; i += DEPTH) {
+            for (int p = 1; p < PLANES; p++) sat &= cnt[p][j].v[x];
+            uint32_t carry = ~(bf[j].v[x] | sat);
 #pragma unroll
-        for (int d = 0; d < DEPTH; d++) {
-            if (i + d < n) {
-                u128 cur[CPL];
-#pragma unroll
-                for (int j = 0; j < CPL; j++) cur[j] = ring[d][j];
-                // refill this ring slot with the row DEPTH positions ahead
-                if (i + d + DEPTH < n) {
-                    const uint8_t *rp = rows + (size_t)list[i + d + DEPTH] * P.pitch;
-#pragma unroll
-                    for (int j = 0; j < CPL; j++)
-                        if (cval[j]) ring[d][j] = load_chunk(rp + coff[j]);
-                }
-#pragma unroll
-                for (int j = 0; j < CPL; j++)
-#pragma unroll
-                    for (int x = 0; x < 4; x++) bf[j].v[x] &= cur[j].v[x];
-                if (++g == P.G) {
-                    // fault_tolerate_filter::read (q_gram_mapper.h:75-88) in counter form:
-                    // every bucket whose AND-ed bit is 0 takes one more miss (saturating).
-                    g = 0;
-#pragma unroll
-                    for (int j = 0; j < CPL; j++)
-#pragma unroll
-                        for (int x = 0; x < 4; x++) {
-                            uint32_t sat = cnt[0][j].v[x];
-#pragma unroll
-                            for (int p = 1; p < PLANES; p++) sat &= cnt[p][j].v[x];
-                            uint32_t carry = ~(bf[j].v[x] | sat);
-#pragma unroll
-                            for (int p = 0; p < PLANES; p++) {
-                                const uint32_t t = cnt[p][j].v[x] & carry;
-                                cnt[p][j].v[x] ^= carry;
-                                carry = t;
-                            }
-                            bf[j].v[x] = 0xFFFFFFFFu;
-                        }
-                }
+            for (int p = 0; p < PLANES; p++) {
+                const uint32_t t = cnt[p][j].v[x] & carry;
+                cnt[p][j].v[x] ^= carry;
+                carry = t;
             }
+            bf[j].v[x] = 0xFFFFFFFFu;
+        }
+}
+
+// Bits of a lane's 32-bit word that are buckets: only bits < NB exist (std::bitset<NB>), and lanes past
+// the end of the row hold nothing.
+__device__ __forceinline__ uint32_t bucket_mask(const DevParams &P, uint32_t chunk, int x) {
+    const uint32_t b0 = chunk * 128u + (uint32_t)x * 32u;
+    if (chunk >= P.n_chunks || b0 >= P.nb) return 0;
+    return (P.nb - b0 >= 32u) ? 0xFFFFFFFFu : ((1u << (P.nb - b0)) - 1u);
+}
+
+// Bit-sliced "miss count >= F" for one word of PLANES-bit counters (F is wave-uniform).
+template <int CPL, int PLANES>
+__device__ __forceinline__ uint32_t count_ge(const u128 (&cnt)[PLANES][CPL], int j, int x, uint32_t F) {
+    uint32_t ge = 0, eq = 0xFFFFFFFFu;
+#pragma unroll
+    for (int p = PLANES - 1; p >= 0; p--) {
+        const uint32_t c = cnt[p][j].v[x];
+        if ((F >> p) & 1u) {
+            eq &= c;
+        } else {
+            ge |= eq & c;
+            eq &= ~c;
         }
     }
+    return ge | eq;
+}
 
-    // best_results (q_gram_mapper.h:90-102): buckets with the minimum miss count, if it is < F.
-    // Only bits < NB are buckets (std::bitset<NB>); lanes past the row hold nothing.
+// best_results (q_gram_mapper.h:90-102) + the > max_candidates rule (:471-476): buckets with the
+// minimum miss count if that minimum is < F, emitted as ascending ids.  Non-bucket bits carry a
+// saturated counter from the start (see the kernel), so they can never be in the minimum set unless
+// the minimum itself is saturated (>= F), in which case the result is empty anyway.
+template <int CPL, int PLANES>
+__device__ __forceinline__ void emit_best(const DevParams &P, const u128 (&cnt)[PLANES][CPL], uint32_t item,
+                                          uint32_t lane, uint32_t *__restrict__ out_counts,
+                                          uint32_t *__restrict__ out_buckets) {
     u128 cand[CPL];
 #pragma unroll
     for (int j = 0; j < CPL; j++)
 #pragma unroll
-        for (int x = 0; x < 4; x++) {
-            const uint32_t b0 = (lane + kWave * j) * 128u + x * 32u;
-            uint32_t m = 0;
-            if (cval[j] && b0 < P.nb) m = (P.nb - b0 >= 32u) ? 0xFFFFFFFFu : ((1u << (P.nb - b0)) - 1u);
-            cand[j].v[x] = m;
-        }
+        for (int x = 0; x < 4; x++) cand[j].v[x] = 0xFFFFFFFFu;
+    // most-significant plane first: if some candidate has a 0 in this plane, so does the minimum
     uint32_t m_min = 0;
 #pragma unroll
     for (int p = PLANES - 1; p >= 0; p--) {
@@ -320,7 +282,7 @@ __global__ __launch_bounds__(kWave) void bmf_vote_kernel(DevParams P, const uint
         for (int j = 0; j < CPL; j++)
 #pragma unroll
             for (int x = 0; x < 4; x++) any |= cand[j].v[x] & ~cnt[p][j].v[x];
-        if (__ballot(any != 0) != 0) {   // some candidate has a 0 in this plane: the minimum does too
+        if (__ballot(any != 0) != 0) {
 #pragma unroll
             for (int j = 0; j < CPL; j++)
 #pragma unroll
@@ -329,7 +291,6 @@ __global__ __launch_bounds__(kWave) void bmf_vote_kernel(DevParams P, const uint
             m_min |= 1u << p;
         }
     }
-
     uint32_t pc[CPL], mine = 0;
 #pragma unroll
     for (int j = 0; j < CPL; j++) {
@@ -337,8 +298,7 @@ __global__ __launch_bounds__(kWave) void bmf_vote_kernel(DevParams P, const uint
         mine += pc[j];
     }
     const uint32_t total = wave_sum(mine);
-    // m_min >= F: every level of the reference's filter is empty.  total > max_cand: cleared
-    // (q_gram_mapper.h:471-476).
+    // m_min >= F: every level of the reference's filter is empty.  total > max_cand: cleared.
     if (m_min >= P.F || total > P.max_cand) {
         if (lane == 0) out_counts[item] = 0;
         return;
@@ -366,6 +326,92 @@ __global__ __launch_bounds__(kWave) void bmf_vote_kernel(DevParams P, const uint
         }
     }
     if (lane == 0) out_counts[item] = total;
+}
+
+// CPL   : 16-byte chunks per lane (lane l owns chunks l, l+64, ...: every load is 1 KiB contiguous)
+// PLANES: bits of the saturating per-bucket miss counter, 2^PLANES-1 >= F
+// DEPTH : index rows in flight per wave (register ring)
+//
+// Branch-free row stream: the row-id list is padded with the all-ones row up to a multiple of DEPTH
+// plus DEPTH (a row of ones ANDs as the identity and, landing on a sample boundary, adds no miss), and
+// lanes past the end of the row re-read the row's last chunk, so every load is unconditional and the
+// compiler can wait for exactly the oldest row in flight (counted vmcnt) instead of draining the ring.
+template <int CPL, int PLANES, int DEPTH>
+__global__ __launch_bounds__(kWave) void bmf_vote_kernel(DevParams P, const uint8_t *__restrict__ rows,
+                                                        const uint32_t *__restrict__ row_lists,
+                                                        const uint32_t *__restrict__ list_n,
+                                                        uint32_t *__restrict__ out_counts,
+                                                        uint32_t *__restrict__ out_buckets) {
+    const uint32_t item = blockIdx.x;          // 2*window + orientation
+    const uint32_t lane = threadIdx.x;
+    if (list_n[item >> 1] == 0) {              // window rejected by the sample kernel
+        if (lane == 0) out_counts[item] = 0;
+        return;
+    }
+    const uint32_t *__restrict__ list = row_lists + (size_t)item * P.list_len;
+    const uint32_t n_iter = P.list_len - DEPTH;     // rows to consume, a multiple of DEPTH
+
+    uint32_t coff[CPL];
+#pragma unroll
+    for (int j = 0; j < CPL; j++) {
+        const uint32_t c = lane + kWave * j;
+        coff[j] = (c < P.n_chunks ? c : P.n_chunks - 1u) * 16u;
+    }
+
+    u128 ring[DEPTH][CPL];
+#pragma unroll
+    for (int d = 0; d < DEPTH; d++) {
+        const uint8_t *rp = rows + (size_t)list[d] * P.pitch;
+#pragma unroll
+        for (int j = 0; j < CPL; j++) ring[d][j] = load_chunk(rp + coff[j]);
+    }
+
+    u128 bf[CPL];             // AND of the current sample's rows (q_gram_mapper.h:400-406)
+    u128 cnt[PLANES][CPL];    // bit-sliced miss counters
+#pragma unroll
+    for (int j = 0; j < CPL; j++)
+#pragma unroll
+        for (int x = 0; x < 4; x++) {
+            bf[j].v[x] = 0xFFFFFFFFu;
+            // bits that are not buckets start with a saturated (>= F) counter: never candidates
+            const uint32_t dead = ~bucket_mask(P, lane + kWave * j, x);
+#pragma unroll
+            for (int p = 0; p < PLANES; p++) cnt[p][j].v[x] = dead;
+        }
+
+    uint32_t g = 0, samples_done = 0;
+    for (uint32_t i = 0; i < n_iter; i += DEPTH) {
+#pragma unroll
+        for (int d = 0; d < DEPTH; d++) {
+#pragma unroll
+            for (int j = 0; j < CPL; j++)
+#pragma unroll
+                for (int x = 0; x < 4; x++) bf[j].v[x] &= ring[d][j].v[x];
+            // refill this ring slot with the row DEPTH positions ahead (list is padded: always valid)
+            const uint8_t *rp = rows + (size_t)list[i + d + DEPTH] * P.pitch;
+#pragma unroll
+            for (int j = 0; j < CPL; j++) ring[d][j] = load_chunk(rp + coff[j]);
+            if (++g == P.G) {
+                g = 0;
+                count_misses<CPL, PLANES>(bf, cnt);
+                ++samples_done;
+                // Optional early exit (same result, fewer row reads): once every bucket has >= F misses
+                // the reference's filter is empty at every level whatever the remaining samples are.
+                if (P.early_exit && samples_done >= P.F && samples_done < P.S) {
+                    uint32_t alive = 0;
+#pragma unroll
+                    for (int j2 = 0; j2 < CPL; j2++)
+#pragma unroll
+                        for (int x = 0; x < 4; x++) alive |= ~count_ge<CPL, PLANES>(cnt, j2, x, P.F);
+                    if (__ballot(alive != 0) == 0) {
+                        if (lane == 0) out_counts[item] = 0;
+                        return;
+                    }
+                }
+            }
+        }
+    }
+    emit_best<CPL, PLANES>(P, cnt, item, lane, out_counts, out_buckets);
 }
 
 }  // namespace bmf

@@ -161,7 +161,7 @@ public:
                       uint8_t query_seed_length, uint8_t index_seed_length, unsigned int samples, unsigned int fault,
                       float distinguishability, unsigned int quality_threshold = 35,
                       unsigned int num_candidate_buckets = 30, unsigned int num_segment_samples = 5,
-                      std::vector<int> devices = {0})
+                      std::vector<int> devices = {0}, unsigned int flags = 0)
         : batched_mapper(num_buckets, read_len, num_candidate_buckets, num_segment_samples) {
         (void)bucket_len;
         std::cerr << "[INFO]\t\tSet query seed length to be " << static_cast<int>(query_seed_length)
@@ -177,6 +177,7 @@ public:
         p.max_candidates = num_candidate_buckets;
         p.read_len = read_len;
         p.num_segment_samples = num_segment_samples;
+        p.flags = flags;
         for (int dev : devices) {
             p.device = dev;
             bmf_ctx *c = nullptr;

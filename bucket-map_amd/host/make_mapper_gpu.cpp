@@ -10,5 +10,5 @@ std::unique_ptr<bm::mapper> bm_make_mapper(const bm::cmd_arguments &args, unsign
                                                    args.query_seed_length, args.index_seed_length,
                                                    args.mapper_sample_size, fault,
                                                    args.mapper_distinguishability_threshold, args.average_base_quality,
-                                                   30, 5, args.gpus);
+                                                   30, 5, args.gpus, args.early_exit ? BMF_FLAG_EARLY_EXIT : 0u);
 }

@@ -16,6 +16,7 @@ _PKG_ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), "..", ".."))
 REPO_ROOT = os.path.abspath(os.path.join(_PKG_ROOT, ".."))
 LIBBMF_PATH = os.path.join(_PKG_ROOT, "libbmf.so")
 
+BMF_FLAG_EARLY_EXIT = 1
 BMF_OK, BMF_ERR_ARG, BMF_ERR_HIP, BMF_ERR_STATE, BMF_ERR_IO, BMF_ERR_UNSUPPORTED = range(6)
 
 
@@ -30,7 +31,7 @@ class _Params(C.Structure):
         ("num_buckets", C.c_uint32), ("q", C.c_uint32), ("k", C.c_uint32), ("num_samples", C.c_uint32),
         ("num_fault", C.c_uint32), ("threshold", C.c_uint32), ("min_base_quality", C.c_uint32),
         ("max_candidates", C.c_uint32), ("read_len", C.c_uint32), ("num_segment_samples", C.c_uint32),
-        ("device", C.c_int32),
+        ("device", C.c_int32), ("flags", C.c_uint32),
     ]
 
 
@@ -110,22 +111,23 @@ class Params:
     read_len: int = 300
     num_segment_samples: int = 5
     device: int = 0
+    flags: int = 0
 
     @classmethod
     def from_cli(cls, num_buckets: int, *, index_seed: int = 9, query_seed: int = 12, read_len: int = 300,
                  mapper_samples: int = 15, max_error_rate: float = 0.4, distinguishability: float = 0.5,
-                 average_base_quality: int = 25, device: int = 0) -> "Params":
+                 average_base_quality: int = 25, device: int = 0, flags: int = 0) -> "Params":
         """Derives F, threshold and min_base_quality exactly as main.cpp:202-209 does (float32)."""
         L = lib()
         return cls(num_buckets=num_buckets, q=index_seed, k=query_seed, num_samples=mapper_samples,
                    num_fault=L.bmf_fault_from_rate(mapper_samples, max_error_rate),
                    threshold=L.bmf_threshold(distinguishability, num_buckets),
-                   min_base_quality=average_base_quality * query_seed, read_len=read_len, device=device)
+                   min_base_quality=average_base_quality * query_seed, read_len=read_len, device=device, flags=flags)
 
     def to_c(self) -> _Params:
         return _Params(self.num_buckets, self.q, self.k, self.num_samples, self.num_fault, self.threshold,
                        self.min_base_quality, self.max_candidates, self.read_len, self.num_segment_samples,
-                       self.device)
+                       self.device, self.flags)
 
 
 def windows_for_reads(offsets, read_len: int, n_seg: int = 5):

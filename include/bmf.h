@@ -59,7 +59,13 @@ typedef struct bmf_params {
     uint32_t read_len;            /* -r: longest window handed to bmf_map_windows                */
     uint32_t num_segment_samples; /* 5 in the reference (used by the host wrapper only)          */
     int32_t  device;              /* HIP device ordinal                                          */
+    uint32_t flags;               /* BMF_FLAG_* (0 = behave byte for byte like round 1's default)  */
 } bmf_params;
+
+/* Stop reading index rows for a (window, orientation) as soon as every bucket has >= F misses: the
+ * reference's filter is then empty at every level whatever the remaining samples are, so the outputs
+ * are identical; only the number of rows actually read (not the algorithmic row count) drops. */
+#define BMF_FLAG_EARLY_EXIT 1u
 
 typedef struct bmf_ctx bmf_ctx;
 typedef struct bmf_batch bmf_batch;

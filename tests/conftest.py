@@ -62,9 +62,9 @@ class Case:
         return oracle_c.Index(p, rows_ptr=self.index.rows_ptr, n_rows=self.index.num_rows,
                               k2i_ptr=self.index.k2i_ptr, n_kmers=self.index.num_kmers)
 
-    def gpu_filter(self):
+    def gpu_filter(self, flags=0):
         import bucket_map_amd as bma
-        f = bma.Filter(bma.Params.from_cli(self.num_buckets, **self.cli))
+        f = bma.Filter(bma.Params.from_cli(self.num_buckets, flags=flags, **self.cli))
         f.load_index_ptr(self.index.rows_ptr, self.index.num_rows, self.index.k2i_ptr, self.index.num_kmers)
         return f
 

@@ -25,6 +25,7 @@ def _windows(case, n=None):
 
 
 def _compare(case, n=None, what=""):
+    import bucket_map_amd as bma
     rd = case.reads
     ws, wl, rid = _windows(case, n)
     ix = case.oracle_index()
@@ -32,6 +33,11 @@ def _compare(case, n=None, what=""):
     c_ref, b_ref, rows_ref = ix.map_windows(rd.bases, rd.quals, ws, wl)
     c_got, b_got = flt.map_windows(rd.bases, rd.quals, ws, wl)
     assert_same_candidates(c_ref, b_ref, c_got, b_got, what)
+    # the opt-in early exit must not change a single output
+    fe = case.gpu_filter(flags=bma.BMF_FLAG_EARLY_EXIT)
+    c_e, b_e = fe.map_windows(rd.bases, rd.quals, ws, wl)
+    assert_same_candidates(c_ref, b_ref, c_e, b_e, what + " (early exit)")
+    fe.close()
     # the device's row count is the unit of the algorithmic-bytes figure: must equal the oracle's
     batch = flt.batch(rd.bases, rd.quals, ws, wl)
     batch.run()
