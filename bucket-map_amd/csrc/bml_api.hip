@@ -1,0 +1,268 @@
+// bml_api.hip -- C ABI (include/bml.h) over the locator-scan kernels in bml_kernels.hip.h.
+// Host side only: chunking of candidates per bucket, buffers, the occurrence sort (hipCUB radix sort,
+// a library primitive) and the automatic re-run when the occurrence buffer was too small.
+#include "bml_kernels.hip.h"
+
+#include "../../include/bml.h"
+
+#include <hipcub/hipcub.hpp>
+
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <vector>
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                                  \
+    do {                                                                                               \
+        hipError_t e_ = (expr);                                                                        \
+        if (e_ != hipSuccess)                                                                          \
+            return fail(BML_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+void build_dna4_lut(uint8_t *lut) {
+    memset(lut, 0, 256);
+    const char *m[4] = {"AaRrWwMmDdHhVv", "CcYySsBb", "GgKk", "TtUu"};
+    for (int r = 0; r < 4; r++)
+        for (const char *c = m[r]; *c; c++) lut[(uint8_t)*c] = (uint8_t)r;
+}
+
+// Device buffer that only grows.
+template <typename T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t cap = 0;
+    hipError_t need(size_t n) {
+        if (n <= cap) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        hipError_t e = hipMalloc(reinterpret_cast<void **>(&p), (n ? n : 1) * sizeof(T));
+        if (e == hipSuccess) cap = n;
+        return e;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+}  // namespace
+
+struct bml_ctx {
+    bml_params p{};
+    bml::LocParams lp{};
+    hipStream_t stream = nullptr;
+    size_t scan_lds = 0;
+    uint32_t max_pairs_per_chunk = 0;
+    // genome
+    bool loaded = false;
+    uint32_t n_buckets = 0;
+    std::vector<uint32_t> h_bucket_len;
+    DevBuf<uint8_t> genome, lut, pair_rc, sort_tmp;
+    DevBuf<uint64_t> bucket_start, occ_a, occ_b;
+    DevBuf<uint32_t> bucket_len, sample_hash, seg_len, pair_window, prop_votes, out_votes;
+    DevBuf<uint16_t> sample_pos;
+    DevBuf<int32_t> prop_key, out_offset;
+    DevBuf<bml::Chunk> chunks;
+    DevBuf<unsigned long long> occ_count;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    float ms[3] = {0, 0, 0};
+    uint64_t last_occ = 0;
+};
+
+extern "C" {
+
+const char *bml_last_error(void) { return g_err; }
+
+int bml_create(const bml_params *params, bml_ctx **out) {
+    if (!params || !out) return fail(BML_ERR_ARG, "bml_create: null argument");
+    *out = nullptr;
+    const bml_params &p = *params;
+    if (p.k == 0 || p.k > 16) return fail(BML_ERR_ARG, "k must be in 1..16 (got %u)", p.k);
+    if (p.num_samples == 0 || p.num_samples > 64) return fail(BML_ERR_UNSUPPORTED, "num_samples must be in 1..64");
+    if (p.max_bucket_bases == 0) return fail(BML_ERR_ARG, "max_bucket_bases must be > 0");
+    const uint32_t max_words = (p.max_bucket_bases + 15u) / 16u;
+    const size_t lds = bml::scan_lds_bytes(max_words);
+    if (lds > 160 * 1024) return fail(BML_ERR_UNSUPPORTED, "buckets of %u bases do not fit the 160 KiB LDS", p.max_bucket_bases);
+    int n_dev = 0;
+    HIP_TRY(hipGetDeviceCount(&n_dev));
+    if (p.device < 0 || p.device >= n_dev) return fail(BML_ERR_HIP, "device %d not available (%d HIP devices)", p.device, n_dev);
+    HIP_TRY(hipSetDevice(p.device));
+    bml_ctx *c = new bml_ctx();
+    c->p = p;
+    c->lp.k = p.k;
+    c->lp.p = p.num_samples;
+    c->lp.allowed_mismatch = p.allowed_mismatch;
+    c->lp.allowed_indel = p.allowed_indel;
+    c->lp.max_words = max_words;
+    c->scan_lds = lds;
+    c->max_pairs_per_chunk = (bml::kTableSlots / 2) / p.num_samples;
+    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    for (int i = 0; i < 4 && e == hipSuccess; i++) e = hipEventCreate(&c->ev[i]);
+    if (e == hipSuccess && lds > 48 * 1024)
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(bml::bml_scan_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    uint8_t lut[256];
+    build_dna4_lut(lut);
+    if (e == hipSuccess) e = c->lut.need(256);
+    if (e == hipSuccess) e = hipMemcpy(c->lut.p, lut, 256, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = c->occ_count.need(1);
+    if (e != hipSuccess) {
+        bml_destroy(c);
+        return fail(BML_ERR_HIP, "bml_create: %s", hipGetErrorString(e));
+    }
+    *out = c;
+    return BML_OK;
+}
+
+void bml_destroy(bml_ctx *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->p.device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    c->genome.release(); c->lut.release(); c->pair_rc.release(); c->sort_tmp.release();
+    c->bucket_start.release(); c->occ_a.release(); c->occ_b.release();
+    c->bucket_len.release(); c->sample_hash.release(); c->seg_len.release(); c->pair_window.release();
+    c->prop_votes.release(); c->out_votes.release(); c->sample_pos.release(); c->prop_key.release();
+    c->out_offset.release(); c->chunks.release(); c->occ_count.release();
+    for (auto &e : c->ev)
+        if (e) (void)hipEventDestroy(e);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int bml_load_genome(bml_ctx *c, const uint8_t *bases, uint64_t n_bases, const uint64_t *bucket_start,
+                    const uint32_t *bucket_len, uint32_t n_buckets) {
+    if (!c || (n_bases && !bases) || (n_buckets && (!bucket_start || !bucket_len)))
+        return fail(BML_ERR_ARG, "bml_load_genome: null argument");
+    for (uint32_t b = 0; b < n_buckets; b++) {
+        if (bucket_len[b] > c->p.max_bucket_bases)
+            return fail(BML_ERR_ARG, "bucket %u has %u bases, more than max_bucket_bases = %u", b, bucket_len[b], c->p.max_bucket_bases);
+        if (bucket_start[b] > n_bases || bucket_len[b] > n_bases - bucket_start[b])
+            return fail(BML_ERR_ARG, "bucket %u lies outside the genome buffer", b);
+    }
+    HIP_TRY(hipSetDevice(c->p.device));
+    HIP_TRY(c->genome.need((size_t)n_bases));
+    HIP_TRY(c->bucket_start.need(n_buckets));
+    HIP_TRY(c->bucket_len.need(n_buckets));
+    if (n_bases) HIP_TRY(hipMemcpy(c->genome.p, bases, (size_t)n_bases, hipMemcpyHostToDevice));
+    if (n_buckets) {
+        HIP_TRY(hipMemcpy(c->bucket_start.p, bucket_start, (size_t)n_buckets * sizeof(uint64_t), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(c->bucket_len.p, bucket_len, (size_t)n_buckets * sizeof(uint32_t), hipMemcpyHostToDevice));
+    }
+    c->n_buckets = n_buckets;
+    c->h_bucket_len.assign(bucket_len, bucket_len + n_buckets);
+    c->loaded = true;
+    return BML_OK;
+}
+
+int bml_locate(bml_ctx *c, const uint32_t *sample_hash, const uint16_t *sample_pos, const uint32_t *seg_len,
+               uint32_t n_windows, const uint32_t *pair_bucket, const uint32_t *pair_window, const uint8_t *pair_rc,
+               uint32_t n_pairs, int32_t *out_offset, uint32_t *out_votes) {
+    if (!c) return fail(BML_ERR_ARG, "bml_locate: null context");
+    if (!c->loaded) return fail(BML_ERR_STATE, "no genome loaded");
+    if (n_pairs == 0) return BML_OK;
+    if (!sample_hash || !sample_pos || !seg_len || !pair_bucket || !pair_window || !pair_rc || !out_offset || !out_votes)
+        return fail(BML_ERR_ARG, "bml_locate: null argument");
+    const uint32_t p = c->p.num_samples;
+    if ((uint64_t)n_pairs * p >= 0xFFFFFFFFull) return fail(BML_ERR_UNSUPPORTED, "too many candidates in one batch");
+    // chunks: all candidates of a bucket are adjacent; split long runs so that a chunk's k-mers fit the LDS table
+    std::vector<bml::Chunk> chunks;
+    for (uint32_t i = 0; i < n_pairs;) {
+        const uint32_t b = pair_bucket[i];
+        if (b >= c->n_buckets) return fail(BML_ERR_ARG, "candidate %u names bucket %u, but only %u buckets are loaded", i, b, c->n_buckets);
+        uint32_t j = i;
+        while (j < n_pairs && pair_bucket[j] == b) j++;
+        for (uint32_t s = i; s < j; s += c->max_pairs_per_chunk)
+            chunks.push_back(bml::Chunk{b, s, (j - s < c->max_pairs_per_chunk) ? j - s : c->max_pairs_per_chunk});
+        i = j;
+    }
+    for (uint32_t i = 0; i < n_pairs; i++) {
+        if (pair_window[i] >= n_windows) return fail(BML_ERR_ARG, "candidate %u names window %u of %u", i, pair_window[i], n_windows);
+        // :242 `length - k - index` must not wrap for reverse-complement candidates
+        if (seg_len[pair_window[i]] < c->p.k) return fail(BML_ERR_ARG, "candidate %u: window shorter than k", i);
+    }
+    HIP_TRY(hipSetDevice(c->p.device));
+    const size_t n_s = (size_t)n_windows * p;
+    HIP_TRY(c->sample_hash.need(n_s));
+    HIP_TRY(c->sample_pos.need(n_s));
+    HIP_TRY(c->seg_len.need(n_windows));
+    HIP_TRY(c->pair_window.need(n_pairs));
+    HIP_TRY(c->pair_rc.need(n_pairs));
+    HIP_TRY(c->chunks.need(chunks.size()));
+    HIP_TRY(c->out_offset.need(n_pairs));
+    HIP_TRY(c->out_votes.need(n_pairs));
+    HIP_TRY(hipMemcpyAsync(c->sample_hash.p, sample_hash, n_s * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->sample_pos.p, sample_pos, n_s * sizeof(uint16_t), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->seg_len.p, seg_len, (size_t)n_windows * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->pair_window.p, pair_window, (size_t)n_pairs * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->pair_rc.p, pair_rc, (size_t)n_pairs, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->chunks.p, chunks.data(), chunks.size() * sizeof(bml::Chunk), hipMemcpyHostToDevice, c->stream));
+
+    // occurrence buffer: a true match per sample is the common case; grow and re-scan when it was too small
+    unsigned long long cap = std::max<unsigned long long>(1ull << 20, 2ull * n_pairs * p);
+    unsigned long long n_occ = 0;
+    for (int attempt = 0; attempt < 3; attempt++) {
+        HIP_TRY(c->occ_a.need((size_t)cap));
+        HIP_TRY(hipMemsetAsync(c->occ_count.p, 0, sizeof(unsigned long long), c->stream));
+        HIP_TRY(hipEventRecord(c->ev[0], c->stream));
+        hipLaunchKernelGGL(bml::bml_scan_kernel, dim3((unsigned)chunks.size()), dim3(bml::kThreads), c->scan_lds, c->stream,
+                           c->lp, c->genome.p, c->bucket_start.p, c->bucket_len.p, c->lut.p, c->chunks.p, c->sample_hash.p,
+                           c->pair_window.p, c->pair_rc.p, c->occ_a.p, c->occ_count.p, cap);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(c->ev[1], c->stream));
+        HIP_TRY(hipMemcpyAsync(&n_occ, c->occ_count.p, sizeof n_occ, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (n_occ <= cap) break;
+        cap = n_occ;
+        if (attempt == 2) return fail(BML_ERR_HIP, "occurrence buffer still too small after re-scan");
+    }
+    c->last_occ = n_occ;
+    // sort: (candidate, sample in processing order) ascending, offset descending (encoded in the key)
+    const uint64_t *sorted = c->occ_a.p;
+    if (n_occ > 1) {
+        HIP_TRY(c->occ_b.need((size_t)n_occ));
+        size_t tmp_bytes = 0;
+        HIP_TRY(hipcub::DeviceRadixSort::SortKeys(nullptr, tmp_bytes, c->occ_a.p, c->occ_b.p, (int64_t)n_occ, 0, 64, c->stream));
+        HIP_TRY(c->sort_tmp.need(tmp_bytes));
+        HIP_TRY(hipcub::DeviceRadixSort::SortKeys(c->sort_tmp.p, tmp_bytes, c->occ_a.p, c->occ_b.p, (int64_t)n_occ, 0, 64, c->stream));
+        sorted = c->occ_b.p;
+    }
+    HIP_TRY(hipEventRecord(c->ev[2], c->stream));
+    HIP_TRY(c->prop_key.need((size_t)n_occ));
+    HIP_TRY(c->prop_votes.need((size_t)n_occ));
+    hipLaunchKernelGGL(bml::bml_replay_kernel, dim3((n_pairs + bml::kThreads - 1) / bml::kThreads), dim3(bml::kThreads), 0,
+                       c->stream, c->lp, sorted, (uint64_t)n_occ, c->sample_pos.p, c->seg_len.p, c->pair_window.p,
+                       c->pair_rc.p, n_pairs, c->prop_key.p, c->prop_votes.p, c->out_offset.p, c->out_votes.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(c->ev[3], c->stream));
+    HIP_TRY(hipMemcpyAsync(out_offset, c->out_offset.p, (size_t)n_pairs * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(out_votes, c->out_votes.p, (size_t)n_pairs * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    for (int i = 0; i < 3; i++) HIP_TRY(hipEventElapsedTime(&c->ms[i], c->ev[i], c->ev[i + 1]));
+    return BML_OK;
+}
+
+int bml_last_stats(bml_ctx *c, float *ms_scan, float *ms_sort, float *ms_replay, uint64_t *n_occurrences) {
+    if (!c) return fail(BML_ERR_ARG, "bml_last_stats: null context");
+    if (ms_scan) *ms_scan = c->ms[0];
+    if (ms_sort) *ms_sort = c->ms[1];
+    if (ms_replay) *ms_replay = c->ms[2];
+    if (n_occurrences) *n_occurrences = c->last_occ;
+    return BML_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,216 @@
+// bml_kernels.hip.h -- gfx950 kernels of the locator candidate scan (include/bml.h).
+//
+//   bml_scan_kernel   : one 256-thread workgroup per (bucket, chunk of <= max_pairs candidates).  Packs the
+//                       bucket to 2 bits/base in LDS, hashes the k-mers the chunk's candidates ask for
+//                       into an LDS open-addressing table, scans every k-mer of the bucket against the
+//                       table and emits (target, offset) occurrences -- the work the reference does by
+//                       building an unordered_multimap of ALL k-mers per bucket
+//                       (bucket_locator.h:162-177) and calling equal_range per sample (:246).
+//   (sort)            : occurrences are sorted by (candidate, sample in processing order, offset
+//                       descending) -- the order libstdc++'s equal_range yields equal keys.
+//   bml_replay_kernel : one thread per candidate replays _find_offset's order-dependent vote
+//                       (bucket_locator.h:233-288) over its sorted occurrences; its std::map<int,unsigned>
+//                       lives as a sorted array in a scratch slice as long as the candidate's occurrences.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace bml {
+
+constexpr int kThreads = 256;
+constexpr uint32_t kTableSlots = 4096;        // LDS open-addressing table (targets of one chunk)
+constexpr uint32_t kLdsOcc = 2048;            // occurrences staged in LDS per workgroup
+constexpr uint32_t kEmpty = 0xFFFFFFFFu;
+
+struct Chunk {
+    uint32_t bucket;
+    uint32_t pair_begin;
+    uint32_t pair_count;
+};
+
+struct LocParams {
+    uint32_t k, p;
+    int32_t allowed_mismatch, allowed_indel;
+    uint32_t max_words;        // LDS words reserved for the packed bucket
+};
+
+__host__ __device__ inline size_t scan_lds_bytes(uint32_t max_words) {
+    return (size_t)kLdsOcc * 8 + 16 + 256 + (size_t)kTableSlots * 8 + ((size_t)max_words + 2) * 4;
+}
+
+// utils.h:291-302
+__device__ __forceinline__ uint32_t hash_reverse_complement(uint32_t h, uint32_t k) {
+    uint32_t rc = 0;
+    for (uint32_t i = 0; i < k; i++) {
+        rc = (rc << 2) | ((~h) & 3u);
+        h >>= 2;
+    }
+    return rc;
+}
+
+__device__ __forceinline__ uint32_t slot_of(uint32_t h) { return (h * 2654435761u) >> 20; }   // 12 bits
+
+// LDS layout (all dynamic, 16-byte aligned base): locc[kLdsOcc] u64 | gbase u64 | lds_cnt u32 (+pad) |
+//                       lut[256] u8 | tkey[kTableSlots] u32 | ttgt[kTableSlots] u32 | packed[max_words + 2] u32
+__global__ __launch_bounds__(kThreads) void bml_scan_kernel(
+    LocParams P, const uint8_t *__restrict__ genome, const uint64_t *__restrict__ bucket_start,
+    const uint32_t *__restrict__ bucket_len, const uint8_t *__restrict__ dna4_lut, const Chunk *__restrict__ chunks,
+    const uint32_t *__restrict__ sample_hash, const uint32_t *__restrict__ pair_window,
+    const uint8_t *__restrict__ pair_rc, uint64_t *__restrict__ occ_keys, unsigned long long *__restrict__ occ_count,
+    unsigned long long occ_cap) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint64_t *locc = reinterpret_cast<uint64_t *>(smem);
+    unsigned long long &gbase = *reinterpret_cast<unsigned long long *>(locc + kLdsOcc);
+    uint32_t &lds_cnt = *reinterpret_cast<uint32_t *>(locc + kLdsOcc + 1);
+    uint8_t *lut = reinterpret_cast<uint8_t *>(locc + kLdsOcc + 2);
+    uint32_t *tkey = reinterpret_cast<uint32_t *>(lut + 256);
+    uint32_t *ttgt = tkey + kTableSlots;
+    uint32_t *packed = ttgt + kTableSlots;
+
+    const Chunk ch = chunks[blockIdx.x];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t nb = bucket_len[ch.bucket];
+    const uint8_t *base = genome + bucket_start[ch.bucket];
+
+    lut[tid] = dna4_lut[tid];
+    if (tid == 0) lds_cnt = 0;
+    for (uint32_t s = tid; s < kTableSlots; s += kThreads) ttgt[s] = kEmpty;
+    __syncthreads();
+
+    // 2-bit packing, first base in the most significant bits of each word
+    const uint32_t n_words = (nb + 15u) / 16u;
+    for (uint32_t w = tid; w <= n_words; w += kThreads) {
+        uint32_t word = 0;
+        for (uint32_t t = 0; t < 16; t++) {
+            const uint32_t pos = w * 16u + t;
+            const uint32_t code = pos < nb ? lut[base[pos]] : 0u;
+            word |= code << (30u - 2u * t);
+        }
+        packed[w] = word;
+    }
+    // the k-mers this chunk's candidates ask for: target t = (candidate, i-th processed sample)
+    const uint32_t n_t = ch.pair_count * P.p;
+    for (uint32_t t = tid; t < n_t; t += kThreads) {
+        const uint32_t pair = ch.pair_begin + t / P.p, i = t % P.p;
+        const uint32_t w = pair_window[pair];
+        const bool rc = pair_rc[pair] != 0;
+        // bucket_locator.h:235-242: reverse-complement candidates start from the last sample
+        uint32_t h = sample_hash[(size_t)w * P.p + (rc ? P.p - 1u - i : i)];
+        if (rc) h = hash_reverse_complement(h, P.k);
+        uint32_t slot = slot_of(h);
+        while (atomicCAS(&ttgt[slot], kEmpty, t) != kEmpty) slot = (slot + 1u) & (kTableSlots - 1u);
+        tkey[slot] = h;
+    }
+    __syncthreads();
+
+    // scan every k-mer of the bucket (bucket_locator.h:172-176 enumerates the same k-mers)
+    const uint32_t nk = nb >= P.k ? nb - P.k + 1u : 0u;
+    const uint32_t kmask = P.k >= 16 ? 0xFFFFFFFFu : ((1u << (2u * P.k)) - 1u);
+    for (uint32_t j = tid; j < nk; j += kThreads) {
+        const uint64_t two = ((uint64_t)packed[j >> 4] << 32) | packed[(j >> 4) + 1];
+        const uint32_t h = (uint32_t)(two >> (64u - 2u * (j & 15u) - 2u * P.k)) & kmask;
+        uint32_t slot = slot_of(h), t;
+        while ((t = ttgt[slot]) != kEmpty) {
+            if (tkey[slot] == h) {
+                const uint32_t target = (ch.pair_begin + t / P.p) * P.p + t % P.p;
+                const uint64_t key = ((uint64_t)target << 32) | (uint32_t)(0x7FFFFFFFu - j);   // offset descending
+                const uint32_t at = atomicAdd(&lds_cnt, 1u);
+                if (at < kLdsOcc) {
+                    locc[at] = key;
+                } else {   // rare (repeats): past the LDS staging area, go to HBM directly
+                    const unsigned long long g = atomicAdd(occ_count, 1ull);
+                    if (g < occ_cap) occ_keys[g] = key;
+                }
+            }
+            slot = (slot + 1u) & (kTableSlots - 1u);
+        }
+    }
+    __syncthreads();
+    const uint32_t n_l = lds_cnt < kLdsOcc ? lds_cnt : kLdsOcc;
+    if (tid == 0 && n_l) gbase = atomicAdd(occ_count, (unsigned long long)n_l);
+    __syncthreads();
+    for (uint32_t i = tid; i < n_l; i += kThreads)
+        if (gbase + i < occ_cap) occ_keys[gbase + i] = locc[i];
+}
+
+__device__ __forceinline__ uint64_t lower_bound_key(const uint64_t *keys, uint64_t n, uint64_t v) {
+    uint64_t lo = 0, hi = n;
+    while (lo < hi) {
+        const uint64_t mid = lo + (hi - lo) / 2;
+        if (keys[mid] < v) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+// _find_offset (bucket_locator.h:209-290) for one candidate per thread.
+__global__ __launch_bounds__(kThreads) void bml_replay_kernel(
+    LocParams P, const uint64_t *__restrict__ keys, uint64_t n_occ, const uint16_t *__restrict__ sample_pos,
+    const uint32_t *__restrict__ seg_len, const uint32_t *__restrict__ pair_window, const uint8_t *__restrict__ pair_rc,
+    uint32_t n_pairs, int32_t *__restrict__ prop_key, uint32_t *__restrict__ prop_votes, int32_t *__restrict__ out_offset,
+    uint32_t *__restrict__ out_votes) {
+    const uint32_t pair = blockIdx.x * kThreads + threadIdx.x;
+    if (pair >= n_pairs) return;
+    const uint64_t first = lower_bound_key(keys, n_occ, (uint64_t)pair * P.p << 32);
+    const uint64_t end = lower_bound_key(keys, n_occ, (uint64_t)(pair + 1u) * P.p << 32);
+    int32_t *pk = prop_key + first;      // the vote_counter map: sorted keys ...
+    uint32_t *pv = prop_votes + first;   // ... and their votes; never more entries than occurrences
+    uint32_t np = 0;
+    const uint32_t w = pair_window[pair];
+    const bool rc = pair_rc[pair] != 0;
+    const uint32_t length = seg_len[w];
+    uint64_t cur = first;
+    for (uint32_t i = 0; i < P.p; i++) {
+        uint32_t idx = sample_pos[(size_t)w * P.p + (rc ? P.p - 1u - i : i)];
+        if (rc) idx = length - P.k - idx;                        // :242 where the k-mer starts on the other strand
+        const uint32_t target = pair * P.p + i;
+        const bool was_empty = np == 0;                          // :247 evaluated once per sample
+        while (cur < end && (uint32_t)(keys[cur] >> 32) == target) {
+            const uint32_t occ = 0x7FFFFFFFu - (uint32_t)keys[cur];
+            const int32_t position = (int32_t)(occ - idx);       // :250,257 (unsigned arithmetic, wraps like int)
+            // lower_bound(position - indel) .. upper_bound(position + indel)  (:259-260)
+            uint32_t lb = 0, ub = np;
+            if (!was_empty) {
+                const int32_t lo_key = position - P.allowed_indel, hi_key = position + P.allowed_indel;
+                uint32_t a = 0, b = np;
+                while (a < b) { const uint32_t m = (a + b) / 2; if (pk[m] < lo_key) a = m + 1; else b = m; }
+                lb = a;
+                b = np;
+                while (a < b) { const uint32_t m = (a + b) / 2; if (pk[m] <= hi_key) a = m + 1; else b = m; }
+                ub = a;
+            }
+            if (!was_empty && lb < ub) {
+                for (uint32_t v = lb; v < ub; v++) pv[v]++;     // :262-265 every proposal in range gets the vote
+            } else {
+                // vote_counter[position]++ (:251,269): insert, or increment when the key exists
+                uint32_t a = 0, b = np;
+                while (a < b) { const uint32_t m = (a + b) / 2; if (pk[m] < position) a = m + 1; else b = m; }
+                if (a < np && pk[a] == position) {
+                    pv[a]++;
+                } else {
+                    for (uint32_t v = np; v > a; v--) { pk[v] = pk[v - 1]; pv[v] = pv[v - 1]; }
+                    pk[a] = position;
+                    pv[a] = 1;
+                    np++;
+                }
+            }
+            cur++;
+        }
+    }
+    int32_t off = -1;
+    uint32_t votes = 0;
+    if (np) {
+        uint32_t best = 0;                                       // :281-283 most votes, ties -> smallest offset
+        for (uint32_t v = 1; v < np; v++)
+            if (pv[v] > pv[best]) best = v;
+        // :284 unsigned >= int compares as unsigned
+        if (pv[best] >= (uint32_t)((int32_t)P.p - P.allowed_mismatch) && pk[best] >= 0) {
+            off = pk[best];
+            votes = pv[best];
+        }
+    }
+    out_offset[pair] = off;
+    out_votes[pair] = votes;
+}
+
+}  // namespace bml

@@ -14,8 +14,9 @@
 #include <iostream>
 #include <memory>
 
-// Defined per build: the product links make_mapper_gpu.cpp.
+// Defined per build: the product links make_mapper_gpu.cpp (MI355X filter + MI355X locator scan).
 std::unique_ptr<bm::mapper> bm_make_mapper(const bm::cmd_arguments &args, unsigned int num_buckets, unsigned int fault);
+std::unique_ptr<bm::offset_scanner> bm_make_scanner(const bm::cmd_arguments &args, int allowed_mismatch, int allowed_indel);
 
 int main(int argc, char **argv) {
     bm::cmd_arguments args;
@@ -84,7 +85,11 @@ int main(int argc, char **argv) {
         const unsigned int fault = bm::ceil_mul_f32(args.allowed_seed_miss_rate, args.mapper_sample_size);
         std::unique_ptr<bm::mapper> map = bm_make_mapper(args, num_buckets, fault);
         // main.cpp:211-218 (the locator receives -b, not -u, as its quality threshold)
-        bm::bucket_locator loc(map.get(), args.bucket_len, args.max_read_length, args.query_seed_length,
+        const unsigned int locator_samples = static_cast<unsigned int>(args.locator_sample_size);
+        std::unique_ptr<bm::offset_scanner> scanner =
+            bm_make_scanner(args, static_cast<int>(bm::ceil_mul_f32(args.allowed_seed_miss_rate, locator_samples)),   // bucket_locator.h:419
+                            static_cast<int>(bm::ceil_mul_f32(args.locator_allowed_indel_rate, args.max_read_length))); // :420
+        bm::bucket_locator loc(map.get(), scanner.get(), args.bucket_len, args.max_read_length, args.query_seed_length,
                                args.allowed_seed_miss_rate, args.locator_allowed_indel_rate,
                                static_cast<unsigned int>(args.locator_sample_size), args.average_base_quality);
         run_indexer();

@@ -1,0 +1,76 @@
+/*
+ * bml.h -- C ABI of the MI355X locator candidate scan ("bucket-map locate", part of libbmf.so).
+ *
+ * Second hot path of BucketMap.  For every candidate
+ * (window, bucket, strand) produced by the filter it replaces
+ *
+ *   reference (bucket_map/locator/bucket_locator.h)            this ABI
+ *   --------------------------------------------------------  ---------------------------------
+ *   bucket_locator ctor: allowed_mismatch/indel   :419-420     bml_create
+ *   _initialize_kmer_index (bucket sequences)     :151-160     bml_load_genome
+ *   _create_kmer_index + _find_offset, per bucket :162-177,    bml_locate  (all candidates of one
+ *     and per candidate, inside _locate's loop    :209-290,      _locate call in one batch)
+ *                                                 :651-695
+ *
+ * What stays on the host (bucket-map_amd/host/bucket_locator.h): sampling the locator k-mers of each
+ * window (_prepare_read_query :292-347), the order in which results are appended per read (:651-693),
+ * _filter_best_locations (:350-405) and SAM output (:455-611).
+ *
+ * Instead of one hash multimap per bucket (65 k node allocations per bucket in the reference) the
+ * device scans each candidate bucket once against the few hundred k-mers actually asked of it, sorts
+ * the occurrences so that they replay in the reference's order -- per sample, occurrences in the order
+ * libstdc++'s unordered_multimap::equal_range yields them, i.e. DESCENDING bucket offset -- and lets one
+ * thread per candidate replay the order-dependent vote of _find_offset exactly.
+ *
+ * Conventions as in bmf.h: plain C types, int status, message in bml_last_error(), no CPU fallback.
+ */
+#ifndef BML_H
+#define BML_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { BML_OK = 0, BML_ERR_ARG = 1, BML_ERR_HIP = 2, BML_ERR_STATE = 3, BML_ERR_UNSUPPORTED = 5 };
+
+typedef struct bml_params {
+    uint32_t k;                /* seed length (-l), <= 16                                         */
+    uint32_t num_samples;      /* p (-p): sampled k-mers per window, <= 64                        */
+    int32_t  allowed_mismatch; /* ceil(e*p), float32 (bucket_locator.h:419)                       */
+    int32_t  allowed_indel;    /* ceil(n*read_len), float32 (bucket_locator.h:420)                */
+    uint32_t max_bucket_bases; /* longest bucket incl. overlap: bucket_len + read_len             */
+    int32_t  device;
+} bml_params;
+
+typedef struct bml_ctx bml_ctx;
+
+const char *bml_last_error(void);
+int  bml_create(const bml_params *params, bml_ctx **out);
+void bml_destroy(bml_ctx *ctx);
+
+/* The reference genome as one byte string (ASCII, any record concatenation) and the kept buckets as
+ * (start, length) views into it (iterate_through_buckets, utils.h:72-97).  Uploaded once. */
+int  bml_load_genome(bml_ctx *ctx, const uint8_t *bases, uint64_t n_bases, const uint64_t *bucket_start,
+                     const uint32_t *bucket_len, uint32_t n_buckets);
+
+/* One batch of candidates.
+ *   windows : sample_hash[w*p + s], sample_pos[w*p + s] (start of the k-mer in the window, u16 as
+ *             query_sequences_storage keeps it), seg_len[w] = length of the window
+ *   pairs   : pair_bucket[i], pair_window[i], pair_rc[i] (1 = reverse-complement candidate).  MUST be
+ *             grouped by bucket (all pairs of one bucket adjacent); order inside a group is free.
+ *   outputs : out_offset[i] = winning start offset in the bucket (as _find_offset returns it: can be 0;
+ *             the caller keeps only > 0) or -1; out_votes[i] = its votes or 0. */
+int  bml_locate(bml_ctx *ctx, const uint32_t *sample_hash, const uint16_t *sample_pos, const uint32_t *seg_len,
+                uint32_t n_windows, const uint32_t *pair_bucket, const uint32_t *pair_window, const uint8_t *pair_rc,
+                uint32_t n_pairs, int32_t *out_offset, uint32_t *out_votes);
+
+/* Kernel times of the last bml_locate in ms (scan, sort, replay) and the number of k-mer occurrences
+ * it handled. */
+int  bml_last_stats(bml_ctx *ctx, float *ms_scan, float *ms_sort, float *ms_replay, uint64_t *n_occurrences);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -24,6 +24,12 @@ class Params(C.Structure):
     ]
 
 
+class LocParams(C.Structure):
+    """bmlo_params (oracle/bm_locator_oracle.h)."""
+    _fields_ = [("k", C.c_uint32), ("num_samples", C.c_uint32), ("allowed_mismatch", C.c_int32),
+                ("allowed_indel", C.c_int32)]
+
+
 _u8p, _u32p, _u64p, _i32p = (C.POINTER(t) for t in (C.c_uint8, C.c_uint32, C.c_uint64, C.c_int32))
 _lib = None
 
@@ -54,6 +60,8 @@ def lib() -> C.CDLL:
             "bmo_query": (u32, [vp, _u32p, u32, _u32p]),
             "bmo_query_sequence": (None, [vp, _u8p, _u8p, u32, _u32p, _u32p, _u32p, _u32p, _u32p, _u32p]),
             "bmo_map_windows": (C.c_uint64, [vp, _u8p, _u8p, _u64p, _u32p, u32, _u32p, _u32p]),
+            "bmlo_locate": (C.c_int, [C.POINTER(LocParams), _u8p, _u64p, _u32p, u32, _u32p, C.POINTER(C.c_uint16), _u32p,
+                                      _u32p, _u32p, _u8p, u32, C.POINTER(C.c_int32), _u32p]),
         }
         for name, (res, args) in sig.items():
             fn = getattr(L, name)
@@ -105,6 +113,26 @@ def window_starts(record_len: int, read_len: int, n_seg: int = 5) -> np.ndarray:
     out = np.zeros(max(n_seg, 1), dtype=np.uint32)
     n = lib().bmo_window_starts(record_len, read_len, n_seg, _p(out, _u32p))
     return out[:n].copy()
+
+
+def locate(k, num_samples, allowed_mismatch, allowed_indel, genome, bucket_start, bucket_len, sample_hash, sample_pos,
+           seg_len, pair_bucket, pair_window, pair_rc):
+    """bmlo_locate: _create_kmer_index + _find_offset for every candidate (bucket_locator.h:162-177,209-290)."""
+    prm = LocParams(k, num_samples, allowed_mismatch, allowed_indel)
+    g = np.ascontiguousarray(genome, np.uint8)
+    bs, bl = np.ascontiguousarray(bucket_start, np.uint64), np.ascontiguousarray(bucket_len, np.uint32)
+    sh, sp = np.ascontiguousarray(sample_hash, np.uint32), np.ascontiguousarray(sample_pos, np.uint16)
+    sl = np.ascontiguousarray(seg_len, np.uint32)
+    pb, pw = np.ascontiguousarray(pair_bucket, np.uint32), np.ascontiguousarray(pair_window, np.uint32)
+    pr = np.ascontiguousarray(pair_rc, np.uint8)
+    off = np.full(len(pb), -1, np.int32)
+    votes = np.zeros(len(pb), np.uint32)
+    rc = lib().bmlo_locate(C.byref(prm), _p(g, _u8p), _p(bs, _u64p), _p(bl, _u32p), len(bs), _p(sh, _u32p),
+                           _p(sp, C.POINTER(C.c_uint16)), _p(sl, _u32p), _p(pb, _u32p), _p(pw, _u32p), _p(pr, _u8p),
+                           len(pb), _p(off, C.POINTER(C.c_int32)), _p(votes, _u32p))
+    if rc:
+        raise RuntimeError("oracle locator: bad bucket id")
+    return off, votes
 
 
 class Index:

@@ -1,11 +1,13 @@
-// make_mapper_oracle.cpp -- TEST INFRASTRUCTURE: the CPU oracle behind bm::mapper.
+// make_mapper_oracle.cpp -- TEST INFRASTRUCTURE: the CPU oracles behind bm::mapper and bm::offset_scanner.
 //
-// Links oracle/bm_oracle.c into the same `bucketmap` main as the product, so that (a) the host plumbing
-// (FASTQ loop, windowing, scatter, locator, SAM) can be exercised without a GPU and (b) the SAM file of
-// the GPU build can be compared with the SAM file of an oracle-backed build on the same inputs.
-// Never shipped: built only by tests/ into tests/cpp/bucketmap_oracle.
+// Links oracle/bm_oracle.c and oracle/bm_locator_oracle.c into the same `bucketmap` main as the product,
+// so that (a) the host plumbing (FASTQ loop, windowing, scatter, result ordering, SAM) can be exercised
+// without a GPU and (b) the SAM file of the GPU build can be compared with the SAM file of an
+// oracle-backed build on the same inputs.  Never shipped: built only into tests/cpp/bucketmap_oracle.
+#include "../../bucket-map_amd/host/bucket_locator.h"
 #include "../../bucket-map_amd/host/cli.h"
 #include "../../bucket-map_amd/host/gpu_q_gram_mapper.h"   // for bm::batched_mapper (host half of map())
+#include "../../oracle/bm_locator_oracle.h"
 #include "../../oracle/bm_oracle.h"
 
 #include <memory>
@@ -49,8 +51,41 @@ public:
     }
 };
 
+class oracle_scanner : public bm::offset_scanner {
+    bmlo_params p_{};
+    std::vector<uint8_t> genome_;
+    std::vector<uint64_t> bstart_;
+    std::vector<uint32_t> blen_;
+
+public:
+    oracle_scanner(uint32_t k, uint32_t num_samples, int allowed_mismatch, int allowed_indel) {
+        p_.k = k;
+        p_.num_samples = num_samples;
+        p_.allowed_mismatch = allowed_mismatch;
+        p_.allowed_indel = allowed_indel;
+    }
+    void load_genome(const uint8_t *bases, uint64_t n_bases, const uint64_t *bucket_start, const uint32_t *bucket_len,
+                     uint32_t n_buckets) override {
+        genome_.assign(bases, bases + n_bases);
+        bstart_.assign(bucket_start, bucket_start + n_buckets);
+        blen_.assign(bucket_len, bucket_len + n_buckets);
+    }
+    void scan(const uint32_t *sample_hash, const uint16_t *sample_pos, const uint32_t *seg_len, uint32_t,
+              const uint32_t *pair_bucket, const uint32_t *pair_window, const uint8_t *pair_rc, uint32_t n_pairs,
+              int32_t *out_offset, uint32_t *out_votes) override {
+        if (bmlo_locate(&p_, genome_.data(), bstart_.data(), blen_.data(), static_cast<uint32_t>(blen_.size()), sample_hash,
+                        sample_pos, seg_len, pair_bucket, pair_window, pair_rc, n_pairs, out_offset, out_votes))
+            throw std::runtime_error("oracle locator: bad bucket id");
+    }
+};
+
 }  // namespace
 
 std::unique_ptr<bm::mapper> bm_make_mapper(const bm::cmd_arguments &args, unsigned int num_buckets, unsigned int fault) {
     return std::make_unique<oracle_mapper>(args, num_buckets, fault);
+}
+
+std::unique_ptr<bm::offset_scanner> bm_make_scanner(const bm::cmd_arguments &args, int allowed_mismatch, int allowed_indel) {
+    return std::make_unique<oracle_scanner>(args.query_seed_length, static_cast<uint32_t>(args.locator_sample_size),
+                                            allowed_mismatch, allowed_indel);
 }

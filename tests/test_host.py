@@ -20,13 +20,7 @@ ORACLE_CLI = os.path.join(ROOT, "tests", "cpp", "bucketmap_oracle")
 
 
 def build_oracle_cli():
-    src = [os.path.join(ROOT, "bucket-map_amd", "host", "main.cpp"), os.path.join(ROOT, "tests", "cpp", "make_mapper_oracle.cpp"),
-           os.path.join(ROOT, "oracle", "bm_oracle.c")]
-    newest = max(os.path.getmtime(p) for p in src + [os.path.join(ROOT, "bucket-map_amd", "host", f)
-                                                      for f in os.listdir(os.path.join(ROOT, "bucket-map_amd", "host"))])
-    if not os.path.exists(ORACLE_CLI) or os.path.getmtime(ORACLE_CLI) < newest:
-        subprocess.run(["g++", "-O2", "-std=c++17", "-pthread", "-o", ORACLE_CLI, *src, "-L" + os.path.join(ROOT, "bucket-map_amd"),
-                        "-lbmf", "-Wl,-rpath," + os.path.join(ROOT, "bucket-map_amd"), "-lm"], check=True)
+    subprocess.run(["make", "-C", ROOT, "tests/cpp/bucketmap_oracle"], check=True, stdout=subprocess.DEVNULL)
     return ORACLE_CLI
 
 

@@ -1,0 +1,187 @@
+"""The locator candidate scan: CPU oracle sanity (no GPU) and GPU == oracle parity (gpu).
+
+Bar for the GPU tests: bit-exact (offset, votes) for every candidate -- the vote of _find_offset is
+order dependent (bucket_locator.h:233-274), so repeats are the interesting inputs.
+"""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import bm_oracle_np as onp
+from oracle import oracle_c as oc
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+LETTERS = np.frombuffer(b"ACGT", np.uint8)
+
+
+def revcomp(seq_codes):
+    return 3 - seq_codes[::-1]
+
+
+def make_case(rng, *, n_buckets, bucket_len, read_len, n_reads, k=12, p=10, motif=None, sub=0.01, decoys=True, qual_b=25):
+    """Genome of n_buckets buckets (optionally built from a short repeated motif), reads with their sampled
+    locator k-mers (bucket_locator.h:292-347 restated in numpy) and candidate (window, bucket, strand)
+    pairs: the true one plus decoys."""
+    size = bucket_len + read_len
+    if motif is None:
+        genome = rng.integers(0, 4, n_buckets * bucket_len + read_len).astype(np.uint8)
+    else:
+        unit = rng.integers(0, 4, motif).astype(np.uint8)
+        genome = np.tile(unit, (n_buckets * bucket_len + read_len) // motif + 1)[: n_buckets * bucket_len + read_len].copy()
+        flips = rng.random(len(genome)) < 0.02                     # a few point differences between copies
+        genome[flips] = rng.integers(0, 4, flips.sum())
+    bstart = (np.arange(n_buckets) * bucket_len).astype(np.uint64)
+    blen = np.full(n_buckets, size, np.uint32)
+    blen[-1] = len(genome) - int(bstart[-1])
+    sh, sp, sl, pb, pw, pr, truth = [], [], [], [], [], [], []
+    for r in range(n_reads):
+        b = int(rng.integers(0, n_buckets))
+        start = int(rng.integers(1, int(blen[b]) - read_len - 1))
+        seq = genome[int(bstart[b]) + start: int(bstart[b]) + start + read_len].copy()
+        for _ in range(int(rng.poisson(sub * read_len))):
+            seq[int(rng.integers(0, read_len))] = rng.integers(0, 4)
+        rc = bool(rng.integers(0, 2))
+        if rc:
+            seq = revcomp(seq)
+        text = LETTERS[seq]
+        quals = np.full(read_len, ord("E"), np.uint8)
+        if r % 4 == 1:
+            quals = rng.integers(33 + 10, 33 + 41, read_len).astype(np.uint8)
+        hs, qs = onp.kmer_hashes(text, k), onp.kmer_qualities(quals, k)
+        good = np.nonzero(qs >= qual_b * k)[0]
+        if len(good) == 0:
+            good = np.arange(len(hs))
+        pos = [int(good[i]) for i in onp.sample_positions(p, len(good) - 1)]
+        sh.append([int(hs[j]) for j in pos]); sp.append(pos); sl.append(read_len)
+        cands = [(b, rc)]
+        if decoys:
+            cands += [(b, not rc), (int(rng.integers(0, n_buckets)), rc)]
+        for cb, crc in cands:
+            pb.append(cb); pw.append(r); pr.append(int(crc))
+        truth.append((b, start, rc))
+    order = np.argsort(np.array(pb), kind="stable")                # candidates grouped by bucket
+    pb, pw, pr = np.array(pb, np.uint32)[order], np.array(pw, np.uint32)[order], np.array(pr, np.uint8)[order]
+    return dict(genome=LETTERS[genome], bstart=bstart, blen=blen, sh=np.array(sh, np.uint32), sp=np.array(sp, np.uint16),
+                sl=np.array(sl, np.uint32), pb=pb, pw=pw, pr=pr, truth=truth, k=k, p=p)
+
+
+def oracle(case, mismatch=4, indel=6):
+    return oc.locate(case["k"], case["p"], mismatch, indel, case["genome"], case["bstart"], case["blen"], case["sh"],
+                     case["sp"], case["sl"], case["pb"], case["pw"], case["pr"])
+
+
+# ------------------------------------------------------------------------------------------ CPU
+
+def test_unordered_multimap_order_assumption():
+    # the one assumption the oracle imports from libstdc++: equal keys come back in descending offset
+    exe = os.path.join(ROOT, "tests", "cpp", "umm_order")
+    subprocess.run(["make", "-C", ROOT, "tests/cpp/umm_order"], check=True, stdout=subprocess.DEVNULL)
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 0 and r.stdout.strip() == "OK"
+
+
+def test_oracle_finds_true_offsets():
+    rng = np.random.default_rng(1)
+    case = make_case(rng, n_buckets=6, bucket_len=4096, read_len=150, n_reads=120)
+    off, votes = oracle(case)
+    hit = 0
+    for i in range(len(case["pb"])):
+        b, start, rc = case["truth"][int(case["pw"][i])]
+        if int(case["pb"][i]) == b and bool(case["pr"][i]) == rc:
+            hit += int(abs(int(off[i]) - start) <= 6 and votes[i] >= 6)
+        else:
+            assert off[i] == -1 and votes[i] == 0               # decoys: wrong strand / wrong bucket
+    assert hit >= 0.95 * len(case["truth"])
+
+
+def test_oracle_hand_traced_vote():
+    # bucket = ACGT x 8 (32 bases), k=4, p=2.  Window "ACGTACGT" sampled at positions 0 and 4 (both "ACGT" = 27).
+    # Occurrences of ACGT: offsets 0,4,...,28, visited DESCENDING.  Sample 0 (idx 0): proposals 28,24,...,0 with 1
+    # vote each.  Sample 1 (idx 4): occurrence o proposes o-4; with indel 0 it votes for the existing key o-4
+    # (o = 28..4) and creates -4 for o = 0.  Keys 0..24 have 2 votes, 28 and -4 have 1: max 2, smallest key 0.
+    genome = np.frombuffer(b"ACGT" * 8, np.uint8)
+    off, votes = oc.locate(4, 2, 0, 0, genome, [0], [32], [[27, 27]], [[0, 4]], [8], [0], [0], [0])
+    assert (int(off[0]), int(votes[0])) == (0, 2)
+    # with indel 4 every sample-1 occurrence (positions P = 24, 20, ..., 0, -4) votes for ALL proposals within
+    # +-4: key K gets one vote per P with |P-K| <= 4.  K = 0 gets P in {4, 0, -4} (so P = -4 creates no key),
+    # K = 4..20 get three, K = 24 gets {24, 20}, K = 28 gets {24}.  Max 1 + 3 = 4 votes, smallest such key = 0.
+    off, votes = oc.locate(4, 2, 0, 4, genome, [0], [32], [[27, 27]], [[0, 4]], [8], [0], [0], [0])
+    assert (int(off[0]), int(votes[0])) == (0, 4)
+    # order dependence: sampled at positions 4 then 0 instead, the first sample proposes -4, 0, ..., 24; the
+    # second (P = 28, ..., 0) then creates nothing new either, but now key -4 exists and collects {0}: the
+    # winner must still be a key >= 0 with the most votes
+    off, votes = oc.locate(4, 2, 0, 4, genome, [0], [32], [[27, 27]], [[4, 0]], [8], [0], [0], [0])
+    assert int(votes[0]) == 4 and int(off[0]) >= 0
+    # reverse-complement candidate of the same window: ACGT is its own reverse complement, positions mirror
+    off, votes = oc.locate(4, 2, 0, 0, genome, [0], [32], [[27, 27]], [[0, 4]], [8], [0], [0], [1])
+    assert (int(off[0]), int(votes[0])) == (0, 2)
+    # too few votes: p - allowed_mismatch = 2 needed, a window that matches once only gets 1
+    off, votes = oc.locate(4, 2, 0, 0, genome, [0], [32], [[27, 0]], [[0, 4]], [8], [0], [0], [0])
+    assert (int(off[0]), int(votes[0])) == (-1, 0)
+
+
+# ------------------------------------------------------------------------------------------ GPU
+
+def gpu_scan(case, mismatch=4, indel=6):
+    from bucket_map_amd import locate
+    s = locate.LocatorScan(case["k"], case["p"], mismatch, indel, int(case["blen"].max()))
+    s.load_genome(case["genome"], case["bstart"], case["blen"])
+    off, votes = s.locate(case["sh"], case["sp"], case["sl"], case["pb"], case["pw"], case["pr"])
+    st = s.stats()
+    s.close()
+    return off, votes, st
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,kw", [
+    ("random genome", dict(n_buckets=40, bucket_len=8192, read_len=150, n_reads=1500)),
+    ("reference geometry", dict(n_buckets=6, bucket_len=65536, read_len=300, n_reads=600)),
+    ("tandem repeats", dict(n_buckets=4, bucket_len=8192, read_len=150, n_reads=300, motif=97)),
+    ("short motif: thousands of occurrences", dict(n_buckets=2, bucket_len=16384, read_len=100, n_reads=60, motif=23)),
+    ("one hot bucket: chunking", dict(n_buckets=1, bucket_len=32768, read_len=150, n_reads=1200, decoys=False)),
+    ("k=16 p=20", dict(n_buckets=8, bucket_len=4096, read_len=200, n_reads=300, k=16, p=20)),
+    ("k=9 p=5", dict(n_buckets=8, bucket_len=4096, read_len=120, n_reads=300, k=9, p=5)),
+])
+def test_gpu_scan_equals_oracle(name, kw):
+    rng = np.random.default_rng(abs(hash(name)) % 1000)
+    case = make_case(rng, **kw)
+    p = case["p"]
+    mismatch, indel = int(np.ceil(0.4 * p)), 6
+    o_ref, v_ref = oracle(case, mismatch, indel)
+    o_got, v_got, st = gpu_scan(case, mismatch, indel)
+    bad = np.nonzero((o_ref != o_got) | (v_ref != v_got))[0]
+    assert bad.size == 0, f"{name}: {bad.size} candidates differ, first {bad[:5]}: ref {o_ref[bad[:5]]}/{v_ref[bad[:5]]} got {o_got[bad[:5]]}/{v_got[bad[:5]]}"
+    assert st["occurrences"] >= (o_ref >= 0).sum()
+    if "motif" in kw:
+        assert st["occurrences"] > 20 * len(case["pb"])          # repeats really produce many occurrences
+
+
+@pytest.mark.gpu
+def test_gpu_scan_hand_traced():
+    from bucket_map_amd import locate
+    genome = np.frombuffer(b"ACGT" * 8, np.uint8)
+    for indel, want in ((0, (0, 2)), (4, (0, 4))):
+        s = locate.LocatorScan(4, 2, 0, indel, 32)
+        s.load_genome(genome, [0], [32])
+        off, votes = s.locate([[27, 27]], [[0, 4]], [8], [0], [0], [0])
+        assert (int(off[0]), int(votes[0])) == want
+        s.close()
+
+
+@pytest.mark.gpu
+def test_gpu_scan_errors():
+    from bucket_map_amd import locate
+    s = locate.LocatorScan(12, 10, 4, 6, 1000)
+    with pytest.raises(locate.BmlError):                           # no genome yet
+        s.locate(np.zeros((1, 10)), np.zeros((1, 10)), [100], [0], [0], [0])
+    g = np.frombuffer(b"ACGT" * 100, np.uint8)
+    with pytest.raises(locate.BmlError):                           # bucket longer than max_bucket_bases
+        s.load_genome(np.tile(g, 4), [0], [1600])
+    s.load_genome(g, [0], [400])
+    with pytest.raises(locate.BmlError):                           # unknown bucket
+        s.locate(np.zeros((1, 10)), np.zeros((1, 10)), [100], [3], [0], [0])
+    off, votes = s.locate(np.zeros((1, 10)), np.zeros((1, 10)), [100], np.zeros(0), np.zeros(0), np.zeros(0))
+    assert len(off) == 0
+    s.close()
