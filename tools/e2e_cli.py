@@ -1,0 +1,80 @@
+#!/usr/bin/env python3
+"""End-to-end run of the `bucketmap` tool on a synthetic genome (GPU box): writes FASTA + FASTQ, indexes,
+maps with the GPU mapper + GPU locator scan, reports the tool's own [BENCHMARK] lines and the accuracy
+against the simulator's ground truth.
+
+    python tools/e2e_cli.py --workload egu --reads 1000000 --out gpurun_out/e2e_egu.txt
+"""
+import argparse
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "bucket-map_amd", "python"))
+import bench  # noqa: E402
+from bucket_map_amd import host  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--workload", default="egu")
+ap.add_argument("--reads", type=int, default=1_000_000)
+ap.add_argument("--dir", default="/tmp/bm_e2e")
+ap.add_argument("--out", default="")
+ap.add_argument("--extra", default="", help="extra CLI flags, e.g. '--early-exit'")
+args = ap.parse_args()
+
+total_bp, bucket_len, read_len, _ = bench.WORKLOADS[args.workload]
+os.makedirs(args.dir, exist_ok=True)
+log = []
+
+
+def say(msg):
+    print(msg, flush=True)
+    log.append(msg)
+
+
+t = time.perf_counter()
+lens = [total_bp] if args.workload in ("ecoli", "mini") else bench.egu_like_record_lengths(total_bp)
+g = host.Genome.synth(20240001, lens)
+g.write_fasta(os.path.join(args.dir, "g.fa"))
+rd = host.Reads(g, bucket_len, read_len, read_len, args.reads, seed=20240003)
+rd.write_fastq(os.path.join(args.dir, "reads"))
+say(f"[e2e] inputs written in {time.perf_counter() - t:.1f} s ({g.total_length()} bp, {rd.n} reads)")
+exe = os.path.join(ROOT, "bucket-map_amd", "bucketmap")
+common = ["-i", "idx", "--genome", "g.fa", "--bucket-len", str(bucket_len), "-r", str(read_len), "-f", "1"]
+for f in ("idx.qgram", "idx.kmers_index", "idx.bucket_id", "out.sam"):
+    p = os.path.join(args.dir, f)
+    if os.path.exists(p):
+        os.remove(p)
+t = time.perf_counter()
+r = subprocess.run([exe, "-x", *common], cwd=args.dir, capture_output=True, text=True)
+say(f"[e2e] index: exit {r.returncode}, {time.perf_counter() - t:.1f} s")
+t = time.perf_counter()
+r = subprocess.run([exe, *common, "-q", "reads.fastq", "-o", "out.sam", *args.extra.split()], cwd=args.dir,
+                   capture_output=True, text=True)
+say(f"[e2e] map: exit {r.returncode}, {time.perf_counter() - t:.1f} s wall")
+for line in r.stderr.splitlines():
+    if "[BENCHMARK]" in line or "[ERROR]" in line:
+        say("    " + line)
+truth = [l.split() for l in open(os.path.join(args.dir, "reads.position_ground_truth"))]
+names = [g.record_id(i).split(" ")[0] for i in range(g.n_records)]
+ok = mapped = 0
+seen = set()
+for line in open(os.path.join(args.dir, "out.sam")):
+    if line[0] == "@":
+        continue
+    f = line.split("\t", 5)
+    i = int(f[0])
+    if i in seen:
+        continue
+    seen.add(i)
+    mapped += 1
+    ref, pos, rc = int(truth[i][0]), int(truth[i][1]), int(truth[i][2])
+    ok += int(f[2] == names[ref] and abs(int(f[3]) - pos) <= 10 and (int(f[1]) == 16) == bool(rc))
+say(f"[e2e] reads with a SAM record: {mapped}/{rd.n} ({100.0 * mapped / rd.n:.3f} %), first record at the true position "
+    f"(+-10): {ok} ({100.0 * ok / rd.n:.3f} %)")
+if args.out:
+    with open(args.out, "w") as f:
+        f.write("\n".join(log) + "\n")
