@@ -1,0 +1,61 @@
+"""Parameter sweep of the filter's parity: random small indexes and reads under many (q, k, S, F,
+max_candidates, kmer_frac, NB) combinations, GPU vs oracle, bit-exact.  Covers the corners of the kernel
+variant table the fixed geometries do not: PLANES 2..5 (F = 1..31), G = 1..8, S = 1..64, windows with
+fewer good k-mers than samples (repeated sample positions), thresholds that reject k-mers."""
+import numpy as np
+import pytest
+
+from conftest import assert_same_candidates
+
+pytestmark = pytest.mark.gpu
+
+
+def random_case(rng, *, nb, q, k, S, F, max_cand, kmer_frac, density, read_len, n_reads, threshold, minq):
+    import bucket_map_amd as bma
+    from oracle import oracle_c as oc
+    n_q = 4 ** q
+    kept = rng.random(n_q) < kmer_frac
+    k2i = np.full(n_q, -1, np.int32)
+    k2i[kept] = np.arange(kept.sum())
+    bits = rng.random((int(kept.sum()), nb)) < density
+    rows = np.packbits(bits, axis=1, bitorder="little")
+    letters = np.frombuffer(b"ACGTacgtN", np.uint8)
+    lens = rng.integers(0, read_len + 1, n_reads)
+    lens[: n_reads // 2] = read_len
+    off = np.concatenate(([0], np.cumsum(lens))).astype(np.uint64)
+    bases = letters[rng.integers(0, len(letters), int(off[-1]))]
+    quals = rng.integers(33, 33 + 42, int(off[-1])).astype(np.uint8)
+    kw = dict(q=q, k=k, num_samples=S, num_fault=F, threshold=threshold, min_base_quality=minq, max_candidates=max_cand,
+              read_len=read_len)
+    ix = oc.Index(oc.make_params(nb, **kw), rows, k2i)
+    flt = bma.Filter(bma.Params(num_buckets=nb, **kw))
+    flt.load_index(rows, k2i)
+    fe = bma.Filter(bma.Params(num_buckets=nb, flags=bma.BMF_FLAG_EARLY_EXIT, **kw))
+    fe.load_index(rows, k2i)
+    ws, wl = off[:-1], lens.astype(np.uint32)
+    c_ref, b_ref, rows_ref = ix.map_windows(bases, quals, ws, wl)
+    c_got, b_got = flt.map_windows(bases, quals, ws, wl)
+    c_e, b_e = fe.map_windows(bases, quals, ws, wl)
+    flt.close(); fe.close()
+    return c_ref, b_ref, c_got, b_got, c_e, b_e
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_parameters(seed):
+    rng = np.random.default_rng(1000 + seed)
+    q = int(rng.integers(2, 7))
+    k = q + int(rng.integers(0, min(8, 17 - q)))
+    S = int(rng.choice([1, 2, 3, 5, 8, 15, 20, 31, 40, 64]))
+    F = int(rng.integers(1, min(S, 31) + 1))
+    nb = int(rng.choice([1, 31, 64, 127, 128, 129, 1000, 8191, 8193, 20000]))
+    max_cand = int(rng.choice([1, 5, 30, 64]))
+    density = float(rng.choice([0.02, 0.3, 0.7, 0.97]))
+    read_len = int(rng.choice([k, k + 3, 60, 150]))
+    threshold = int(rng.choice([0, nb // 2, nb]))
+    minq = int(rng.choice([0, 15 * k, 30 * k]))
+    c_ref, b_ref, c_got, b_got, c_e, b_e = random_case(
+        rng, nb=nb, q=q, k=k, S=S, F=F, max_cand=max_cand, kmer_frac=float(rng.choice([0.3, 1.0])), density=density,
+        read_len=read_len, n_reads=160, threshold=threshold, minq=minq)
+    what = f"q={q} k={k} S={S} F={F} NB={nb} mc={max_cand} dens={density} L={read_len} thr={threshold} minq={minq}"
+    assert_same_candidates(c_ref, b_ref, c_got, b_got, what)
+    assert_same_candidates(c_ref, b_ref, c_e, b_e, what + " (early exit)")
