@@ -68,6 +68,8 @@ def main():
                     help="default = CLI defaults (k12 q9 S15 F6); bench = benchmark_map.sh (-s 20 -e 0.6 -l 14 -b 10)")
     ap.add_argument("--cpu-sample", type=int, default=200000, help="reads timed on the CPU oracle (0 = skip)")
     ap.add_argument("--host-threads", type=int, default=0)
+    ap.add_argument("--index-build", default="gpu", choices=["gpu", "host"],
+                    help="where the synthetic index is built (setup only, outside the timed region)")
     ap.add_argument("--early-exit", action="store_true",
                     help="BMF_FLAG_EARLY_EXIT: identical outputs, fewer rows actually read (off by default so "
                          "that the roofline line prices exactly the reference's row reads)")
@@ -129,11 +131,12 @@ def main():
     genome = host.Genome.synth(20240001, lens, threads)
     nb = genome.awk_bucket_num(bucket_len)
     log(f"genome: {len(lens)} records, {genome.total_length()} bp, NB={nb} ({time.perf_counter() - t0:.1f}s)")
-    t0 = time.perf_counter()
-    index = host.Index(genome, nb, bucket_len, read_len, q=cli["index_seed"], kmer_frac=1.0, threads=threads)
-    row_bytes = index.row_bytes
-    log(f"index: {index.num_rows} rows x {row_bytes} B = {index.num_rows * row_bytes / 1e6:.1f} MB "
-        f"({time.perf_counter() - t0:.1f}s)")
+    row_bytes = (nb + 7) >> 3
+    index = None
+    if args.index_build == "host":
+        t0 = time.perf_counter()
+        index = host.Index(genome, nb, bucket_len, read_len, q=cli["index_seed"], kmer_frac=1.0, threads=threads)
+        log(f"index (host indexer): {index.num_rows} rows x {row_bytes} B ({time.perf_counter() - t0:.1f}s)")
     t0 = time.perf_counter()
     reads = host.Reads(genome, bucket_len, read_len, read_len, n_reads, sub=0.002, ins=0.00025, dele=0.00025,
                        seed=20240003 + 7919 * rank, threads=threads)
@@ -143,8 +146,18 @@ def main():
     params = bma.Params.from_cli(nb, device=device, flags=bma.BMF_FLAG_EARLY_EXIT if args.early_exit else 0, **cli)
     flt = bma.Filter(params)
     t0 = time.perf_counter()
-    flt.load_index_ptr(index.rows_ptr, index.num_rows, index.k2i_ptr, index.num_kmers)
-    log(f"index in HBM ({time.perf_counter() - t0:.1f}s), kernel variant {flt.info()}")
+    k2i = host.select_qgrams(cli["index_seed"], 1.0)
+    n_rows = int((k2i >= 0).sum())
+    if index is not None:
+        flt.load_index_ptr(index.rows_ptr, index.num_rows, index.k2i_ptr, index.num_kmers)
+    else:
+        # GPU index build (bmf_build_index): byte-identical to the host indexer (tests/test_index_build_gpu.py)
+        flat, _ = genome.flat()
+        bstart, blen = genome.bucket_views(bucket_len, read_len)
+        flt.build_index(flat, bstart, blen, k2i)
+        del flat
+    log(f"index in HBM via {args.index_build} build: {n_rows} rows x {row_bytes} B = {n_rows * row_bytes / 1e6:.1f} MB "
+        f"({time.perf_counter() - t0:.1f}s), kernel variant {flt.info()}")
     # mapper::map's windowing: one window [0, min(read_len, len)) per short read
     win_start, win_len, _, _ = bma.windows_for_reads(reads.offsets, read_len)
     batch = flt.batch(reads.bases, reads.quals, win_start, win_len)
@@ -197,7 +210,7 @@ def main():
             "vs_baseline": None, "dtype": "u32", "data": "synthetic",
             "config": {
                 "workload": f"{args.workload}-like synthetic genome {genome.total_length()} bp, bucket_len {bucket_len}, "
-                            f"NB={nb}, -f 1 index ({index.num_rows} rows x {row_bytes} B), {reads.n} x {read_len} bp "
+                            f"NB={nb}, -f 1 index ({n_rows} rows x {row_bytes} B), {reads.n} x {read_len} bp "
                             f"simulated reads per GPU (sub 0.002, ins=del 0.00025), params {args.params} "
                             f"(k={params.k} q={params.q} S={params.num_samples} F={params.num_fault})",
                 "reads_per_gpu": int(reads.n), "global_reads_per_step": int(world * reads.n),
@@ -230,8 +243,8 @@ def main():
         if args.cpu_sample > 0:
             from oracle import oracle_c
             n_cpu = min(args.cpu_sample, reads.n)
-            ora = oracle_c.Index(oracle_c.params_from_cli(nb, **cli), rows_ptr=index.rows_ptr, n_rows=index.num_rows,
-                                 k2i_ptr=index.k2i_ptr, n_kmers=index.num_kmers)
+            rows_host = index.rows() if index is not None else flt.index_download()
+            ora = oracle_c.Index(oracle_c.params_from_cli(nb, **cli), rows_host, k2i)
             t0 = time.perf_counter()
             c_ref, b_ref, rows_ref = ora.map_windows(reads.bases, reads.quals, win_start[:n_cpu], win_len[:n_cpu])
             cpu_s = time.perf_counter() - t0

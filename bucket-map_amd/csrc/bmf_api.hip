@@ -4,6 +4,7 @@
 // (rows at a 128-byte pitch + one all-ones row), the fp64 sampler table (utils.h:160-178), launches
 // and HIP-event timing.  There is deliberately no CPU implementation of the filter in this library.
 #include "bmf_kernels.hip.h"
+#include "bmi_kernels.hip.h"
 
 #include "../../include/bmf.h"
 
@@ -323,6 +324,105 @@ int bmf_load_index(bmf_ctx *c, const uint8_t *rows, uint64_t n_rows, const int32
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->loaded = true;
+    return BMF_OK;
+}
+
+// GPU form of bucket_indexer::index (bucket_indexer.h:49-61,170-216): see bmi_kernels.hip.h.
+int bmf_build_index(bmf_ctx *c, const uint8_t *genome, uint64_t n_bases, const uint64_t *bucket_start,
+                    const uint32_t *bucket_len, uint32_t n_buckets, const int32_t *kmer_to_index, uint64_t n_kmers) {
+    if (!c) return fail(BMF_ERR_ARG, "bmf_build_index: null context");
+    if (c->loaded) return fail(BMF_ERR_STATE, "the q-gram index is not empty; call bmf_reset first");
+    if ((n_bases && !genome) || (n_buckets && (!bucket_start || !bucket_len)) || !kmer_to_index)
+        return fail(BMF_ERR_ARG, "bmf_build_index: null argument");
+    const uint32_t q = c->p.q;
+    if (q < 3 || q > 10) return fail(BMF_ERR_UNSUPPORTED, "the GPU index build supports 3 <= q <= 10 (got %u)", q);
+    if (n_kmers != (1ull << (2 * q))) return fail(BMF_ERR_ARG, "kmer_to_index must have 4^q entries");
+    if (n_buckets > c->p.num_buckets)
+        return fail(BMF_ERR_ARG, "%u buckets do not fit NB = %u", n_buckets, c->p.num_buckets);
+    uint32_t max_len = 0;
+    for (uint32_t b = 0; b < n_buckets; b++) {
+        if (bucket_start[b] > n_bases || bucket_len[b] > n_bases - bucket_start[b])
+            return fail(BMF_ERR_ARG, "bucket %u lies outside the genome buffer", b);
+        if (bucket_len[b] > max_len) max_len = bucket_len[b];
+    }
+    // rows are numbered 0..n_rows-1 in ascending q-gram hash (bucket_indexer.h:147-157)
+    int64_t n_rows = 0;
+    for (uint64_t i = 0; i < n_kmers; i++)
+        if (kmer_to_index[i] >= 0) {
+            if (kmer_to_index[i] != n_rows) return fail(BMF_ERR_ARG, "kmer_to_index must number the kept q-grams 0,1,2,... in order");
+            n_rows++;
+        }
+    HIP_TRY(hipSetDevice(c->p.device));
+    const uint32_t pitch = c->dp.pitch;
+    const uint64_t n_words = ((1ull << (2 * q)) + 31) / 32;
+    uint8_t *d_genome = nullptr, *d_lut = c->d_lut;
+    uint64_t *d_bstart = nullptr;
+    uint32_t *d_blen = nullptr, *d_presence = nullptr;
+    hipError_t e = hipSuccess;
+    auto ok = [&](hipError_t r) { if (e == hipSuccess) e = r; };
+    ok(dev_alloc(&c->d_rows, (size_t)(n_rows + 1) * pitch));
+    ok(dev_alloc(&c->d_k2i, (size_t)n_kmers));
+    ok(dev_alloc(&c->d_zeros, (size_t)n_rows));
+    ok(dev_alloc(&c->d_qgram_ok, (size_t)n_words));
+    ok(dev_alloc(&d_genome, (size_t)n_bases));
+    ok(dev_alloc(&d_bstart, n_buckets));
+    ok(dev_alloc(&d_blen, n_buckets));
+    ok(dev_alloc(&d_presence, (size_t)n_buckets * n_words));
+    if (e == hipSuccess) {
+        ok(hipMemsetAsync(c->d_rows, 0, (size_t)n_rows * pitch, c->stream));
+        ok(hipMemsetAsync(c->d_rows + (size_t)n_rows * pitch, 0xFF, pitch, c->stream));
+        ok(hipMemcpy(d_genome, genome, (size_t)n_bases, hipMemcpyHostToDevice));
+        ok(hipMemcpy(d_bstart, bucket_start, (size_t)n_buckets * sizeof(uint64_t), hipMemcpyHostToDevice));
+        ok(hipMemcpy(d_blen, bucket_len, (size_t)n_buckets * sizeof(uint32_t), hipMemcpyHostToDevice));
+        ok(hipMemcpy(c->d_k2i, kmer_to_index, (size_t)n_kmers * sizeof(int32_t), hipMemcpyHostToDevice));
+    }
+    const size_t lds = (size_t)n_words * 4 + 256;
+    if (e == hipSuccess && lds > 48 * 1024)
+        ok(hipFuncSetAttribute(reinterpret_cast<const void *>(bmi::bmi_presence_kernel),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if (e == hipSuccess && n_buckets) {
+        hipLaunchKernelGGL(bmi::bmi_presence_kernel, dim3(n_buckets), dim3(bmi::kThreads), lds, c->stream, d_genome, d_bstart,
+                           d_blen, d_lut, q, d_presence);
+        const uint64_t n_waves = (uint64_t)((n_buckets + 63u) / 64u) * (n_words / 2);
+        hipLaunchKernelGGL(bmi::bmi_transpose_kernel, dim3((unsigned)((n_waves * 64 + bmi::kThreads - 1) / bmi::kThreads)),
+                           dim3(bmi::kThreads), 0, c->stream, reinterpret_cast<const uint64_t *>(d_presence), n_buckets, q,
+                           c->d_k2i, c->d_rows, pitch);
+        ok(hipGetLastError());
+    }
+    c->n_rows = (uint64_t)n_rows;
+    c->dp.ones_row = (uint32_t)n_rows;
+    c->dp.n_kmers = (uint32_t)n_kmers;
+    if (e == hipSuccess) {
+        if (n_rows)
+            hipLaunchKernelGGL(bmf::bmf_zeros_kernel, dim3((unsigned)n_rows), dim3(bmf::kWave), 0, c->stream, c->d_rows,
+                               (uint64_t)n_rows, pitch, c->p.num_buckets, c->d_zeros);
+        hipLaunchKernelGGL(bmf::bmf_qgram_ok_kernel, dim3((unsigned)((n_words + 255) / 256)), dim3(256), 0, c->stream,
+                           c->d_k2i, n_kmers, c->d_zeros, c->p.threshold, c->d_qgram_ok, n_words);
+        ok(hipGetLastError());
+        ok(hipStreamSynchronize(c->stream));
+    }
+    (void)hipFree(d_genome);
+    (void)hipFree(d_bstart);
+    (void)hipFree(d_blen);
+    (void)hipFree(d_presence);
+    (void)max_len;
+    if (e != hipSuccess) {
+        free_index(c);
+        return fail(BMF_ERR_HIP, "bmf_build_index: %s", hipGetErrorString(e));
+    }
+    c->loaded = true;
+    return BMF_OK;
+}
+
+int bmf_index_download(bmf_ctx *c, uint8_t *rows_out, uint64_t *n_rows_out) {
+    if (!c) return fail(BMF_ERR_ARG, "bmf_index_download: null context");
+    if (!c->loaded) return fail(BMF_ERR_STATE, "no index loaded");
+    if (n_rows_out) *n_rows_out = c->n_rows;
+    if (!rows_out) return BMF_OK;
+    HIP_TRY(hipSetDevice(c->p.device));
+    const uint32_t row_bytes = (c->p.num_buckets + 7u) >> 3;
+    if (c->n_rows)
+        HIP_TRY(hipMemcpy2D(rows_out, row_bytes, c->d_rows, c->dp.pitch, row_bytes, (size_t)c->n_rows, hipMemcpyDeviceToHost));
     return BMF_OK;
 }
 

@@ -1,0 +1,79 @@
+// bmi_kernels.hip.h -- gfx950 kernels that build the q-gram x bucket index directly in HBM.
+//
+// GPU form of bucket_indexer::index / _insert_into_bucket (bucket_map/indexer/bucket_indexer.h:49-61,
+// :170-216): bit (row of q-gram g, bucket b) is set iff q-gram g occurs in bucket b.  Two passes:
+//   bmi_presence_kernel  : one workgroup per bucket; the bucket's q-gram PRESENCE bitmap (4^q bits, 32 KiB
+//                          for q = 9) is accumulated in LDS with LDS atomics and written out once,
+//                          coalesced -- a (bucket x q-gram) bit matrix, the transpose of the index.
+//   bmi_transpose_kernel : 64 x 64 bit tiles are transposed with 64 wave ballots each and stored into the
+//                          index rows (q-gram x bucket), skipping q-grams FracMinHash did not keep.
+// The reference does the same work as one std::bitset::set per base of every bucket on one CPU thread.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace bmi {
+
+constexpr int kThreads = 256;
+
+// LDS (dynamic): bitmap[4^q / 32] u32 | lut[256] u8
+__global__ __launch_bounds__(kThreads) void bmi_presence_kernel(const uint8_t *__restrict__ genome,
+                                                               const uint64_t *__restrict__ bucket_start,
+                                                               const uint32_t *__restrict__ bucket_len,
+                                                               const uint8_t *__restrict__ dna4_lut, uint32_t q,
+                                                               uint32_t *__restrict__ presence /* n_buckets x 4^q/32 */) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const uint32_t n_words = (1u << (2 * q)) >> 5;
+    uint32_t *bitmap = reinterpret_cast<uint32_t *>(smem);
+    uint8_t *lut = smem + (size_t)n_words * 4;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t b = blockIdx.x;
+    lut[tid] = dna4_lut[tid];
+    for (uint32_t w = tid; w < n_words; w += kThreads) bitmap[w] = 0;
+    __syncthreads();
+    const uint32_t len = bucket_len[b];
+    const uint8_t *s = genome + bucket_start[b];
+    if (len >= q) {
+        // every thread owns a contiguous run of q-gram start positions and rolls the hash along it
+        const uint32_t nq = len - q + 1;
+        const uint32_t per = (nq + kThreads - 1) / kThreads;
+        const uint32_t j0 = tid * per, j1 = (j0 + per < nq) ? j0 + per : nq;
+        if (j0 < j1) {
+            const uint32_t mask = (uint32_t)((1ull << (2 * q)) - 1ull);
+            uint32_t h = 0;
+            for (uint32_t t = 0; t + 1 < q; t++) h = (h << 2) | lut[s[j0 + t]];
+            for (uint32_t j = j0; j < j1; j++) {
+                h = ((h << 2) | lut[s[j + q - 1]]) & mask;
+                atomicOr(&bitmap[h >> 5], 1u << (h & 31u));
+            }
+        }
+    }
+    __syncthreads();
+    uint32_t *out = presence + (size_t)b * n_words;
+    for (uint32_t w = tid; w < n_words; w += kThreads) out[w] = bitmap[w];
+}
+
+// One wave per (group of 64 buckets, 64 consecutive q-grams).  presence is read as u64 words.
+__global__ __launch_bounds__(kThreads) void bmi_transpose_kernel(const uint64_t *__restrict__ presence, uint32_t n_buckets,
+                                                                uint32_t q, const int32_t *__restrict__ k2i,
+                                                                uint8_t *__restrict__ rows, uint32_t pitch) {
+    const uint32_t n_w64 = (1u << (2 * q)) >> 6;           // 64-bit words per bucket
+    const uint32_t wave = (blockIdx.x * kThreads + threadIdx.x) >> 6;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t n_groups = (n_buckets + 63u) / 64u;
+    if (wave >= n_groups * n_w64) return;
+    const uint32_t group = wave / n_w64, w64 = wave % n_w64;  // consecutive waves walk the q-gram words of one group
+    const uint32_t b = group * 64u + lane;
+    const uint64_t v = b < n_buckets ? presence[(size_t)b * n_w64 + w64] : 0ull;
+    uint64_t mine = 0;
+#pragma unroll 8
+    for (uint32_t t = 0; t < 64; t++) {
+        const uint64_t m = __ballot((v >> t) & 1ull);      // bit i = bucket group*64+i holds q-gram w64*64+t
+        if (lane == t) mine = m;
+    }
+    const int32_t row = k2i[w64 * 64u + lane];             // FracMinHash: -1 = q-gram not kept
+    if (row >= 0) *reinterpret_cast<uint64_t *>(rows + (size_t)row * pitch + (size_t)group * 8u) = mine;
+}
+
+}  // namespace bmi

@@ -54,6 +54,27 @@ uint64_t bmh_genome_record_len(const bmh_genome *g, uint32_t i) { return g->g.se
 const char *bmh_genome_record_id(const bmh_genome *g, uint32_t i) { return g->g.ids[i].c_str(); }
 const char *bmh_genome_record_seq(const bmh_genome *g, uint32_t i) { return g->g.seqs[i].data(); }
 
+// All records back to back in one caller buffer of bmh_genome_total(g) bytes; rec_off receives
+// records+1 offsets.  (What the GPU index build and the GPU locator scan take as "the genome".)
+uint64_t bmh_genome_total(const bmh_genome *g) { return g->g.total_length(); }
+void bmh_genome_flatten(const bmh_genome *g, uint8_t *out, uint64_t *rec_off) {
+    uint64_t o = 0;
+    for (size_t r = 0; r < g->g.seqs.size(); r++) {
+        rec_off[r] = o;
+        std::memcpy(out + o, g->g.seqs[r].data(), g->g.seqs[r].size());
+        o += g->g.seqs[r].size();
+    }
+    rec_off[g->g.seqs.size()] = o;
+}
+
+// FracMinHash row selection alone (bucket_indexer.h:147-157): fills 4^q entries, returns the row count.
+uint64_t bmh_select_qgrams(uint32_t q, float kmer_frac, uint64_t hash_seed, int32_t *out_k2i) {
+    bm::QgramIndex ix;
+    bm::select_qgrams(ix, q, bm::FracMinHash::from_seed(hash_seed), kmer_frac);
+    std::memcpy(out_k2i, ix.kmer_to_index.data(), ix.kmer_to_index.size() * sizeof(int32_t));
+    return ix.num_rows;
+}
+
 // BM_BUCKET_NUM as bucket_map/CMakeLists.txt:13-46 computes it
 uint32_t bmh_awk_bucket_num(const bmh_genome *g, uint32_t bucket_len) { return bm::awk_bucket_num(g->g, bucket_len); }
 

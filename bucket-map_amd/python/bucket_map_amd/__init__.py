@@ -51,6 +51,8 @@ SYMBOLS = {
     "bmf_create": (C.c_int, [C.POINTER(_Params), C.POINTER(C.c_void_p)]),
     "bmf_destroy": (None, [C.c_void_p]),
     "bmf_load_index": (C.c_int, [C.c_void_p, _u8p, C.c_uint64, _i32p, C.c_uint64]),
+    "bmf_build_index": (C.c_int, [C.c_void_p, _u8p, C.c_uint64, _u64p, _u32p, C.c_uint32, _i32p, C.c_uint64]),
+    "bmf_index_download": (C.c_int, [C.c_void_p, _u8p, _u64p]),
     "bmf_load_index_files": (C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p]),
     "bmf_reset": (C.c_int, [C.c_void_p]),
     "bmf_index_zeros": (C.c_int, [C.c_void_p, _u32p]),
@@ -229,6 +231,24 @@ class Filter:
         """Same, from raw pointers (e.g. straight out of libbmhost, no numpy copy)."""
         _check(lib().bmf_load_index(self._h, C.cast(rows_ptr, _u8p), n_rows, C.cast(k2i_ptr, _i32p), n_kmers))
         self._n_rows = n_rows
+
+    def build_index(self, genome_bytes, bucket_start, bucket_len, kmer_to_index) -> None:
+        """GPU form of the host indexer: rows are built in HBM from the genome and the bucket views."""
+        g = np.ascontiguousarray(genome_bytes, dtype=np.uint8)
+        bs = np.ascontiguousarray(bucket_start, dtype=np.uint64)
+        bl = np.ascontiguousarray(bucket_len, dtype=np.uint32)
+        k2i = np.ascontiguousarray(kmer_to_index, dtype=np.int32)
+        _check(lib().bmf_build_index(self._h, _ptr(g, _u8p), len(g), _ptr(bs, _u64p), _ptr(bl, _u32p), len(bs),
+                                     _ptr(k2i, _i32p), len(k2i)))
+        self._n_rows = int((k2i >= 0).sum())
+
+    def index_download(self) -> np.ndarray:
+        """The loaded index in the .qgram layout: n_rows x ceil(NB/8) bytes."""
+        n = C.c_uint64()
+        _check(lib().bmf_index_download(self._h, None, C.byref(n)))
+        rows = np.zeros((n.value, (self.params.num_buckets + 7) >> 3), dtype=np.uint8)
+        _check(lib().bmf_index_download(self._h, _ptr(rows, _u8p), C.byref(n)))
+        return rows
 
     # mapper::load, from <dir>/<indicator>.{kmers_index,qgram}
     def load_index_files(self, index_dir: str, indicator: str) -> None:

@@ -31,6 +31,9 @@ def lib() -> C.CDLL:
             "bmh_genome_record_len": (u64, [vp, u32]),
             "bmh_genome_record_id": (C.c_char_p, [vp, u32]),
             "bmh_genome_record_seq": (vp, [vp, u32]),
+            "bmh_genome_total": (u64, [vp]),
+            "bmh_genome_flatten": (None, [vp, vp, vp]),
+            "bmh_select_qgrams": (u64, [u32, C.c_float, u64, vp]),
             "bmh_awk_bucket_num": (u32, [vp, u32]),
             "bmh_cut_buckets": (u32, [vp, u32, u32, C.POINTER(u32)]),
             "bmh_index_build": (vp, [vp, u32, u32, u32, u32, C.c_float, u64, u32]),
@@ -71,6 +74,13 @@ def _view(ptr, n, dtype) -> np.ndarray:
     return np.frombuffer(buf, dtype=dtype)
 
 
+def select_qgrams(q: int, kmer_frac: float = 1.0, hash_seed: int = 20240004) -> np.ndarray:
+    """FracMinHash row selection (bucket_indexer.h:147-157): kmer_to_index with 4^q entries."""
+    out = np.zeros(4 ** q, dtype=np.int32)
+    lib().bmh_select_qgrams(q, kmer_frac, hash_seed, out.ctypes.data)
+    return out
+
+
 class Genome:
     def __init__(self, handle):
         if not handle:
@@ -105,6 +115,20 @@ class Genome:
 
     def total_length(self) -> int:
         return sum(self.record_len(i) for i in range(self.n_records))
+
+    def flat(self):
+        """(all records back to back as one uint8 array, record offsets[n_records+1])."""
+        out = np.empty(lib().bmh_genome_total(self._h), dtype=np.uint8)
+        off = np.zeros(self.n_records + 1, dtype=np.uint64)
+        lib().bmh_genome_flatten(self._h, out.ctypes.data, off.ctypes.data)
+        return out, off
+
+    def bucket_views(self, bucket_len: int, read_len: int):
+        """Kept buckets as (start, length) views into flat(): what bmf_build_index / bml_load_genome take."""
+        b = self.cut_buckets(bucket_len, read_len)
+        off = np.concatenate(([0], np.cumsum([self.record_len(i) for i in range(self.n_records)]))).astype(np.uint64)
+        start = off[b[:, 0]] + b[:, 2].astype(np.uint64)
+        return start.astype(np.uint64), (b[:, 3] - b[:, 2]).astype(np.uint32)
 
     def awk_bucket_num(self, bucket_len: int) -> int:
         return lib().bmh_awk_bucket_num(self._h, bucket_len)

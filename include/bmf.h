@@ -91,6 +91,19 @@ void bmf_destroy(bmf_ctx *ctx);
  * (q_gram_mapper.h:171-196).  BMF_ERR_STATE if an index is already loaded (:325-328). */
 int  bmf_load_index(bmf_ctx *ctx, const uint8_t *rows, uint64_t n_rows, const int32_t *kmer_to_index,
                     uint64_t n_kmers);
+/* GPU form of the host indexer (bucket_indexer::index / _insert_into_bucket,
+ * bucket_map/indexer/bucket_indexer.h:49-61,170-216): builds the index rows straight in HBM from the
+ * genome (one byte string, ASCII) and the kept buckets given as (start, length) views
+ * (iterate_through_buckets, utils.h:72-97), for the q-grams kmer_to_index keeps (numbered 0,1,2,... in
+ * ascending hash, bucket_indexer.h:147-157).  Leaves the context loaded, exactly as bmf_load_index would
+ * with the rows the host indexer writes.  Optional: indexing stays a host job in the reference, this is
+ * the fast path for benchmarks and for `bucketmap -x`.  3 <= q <= 10. */
+int  bmf_build_index(bmf_ctx *ctx, const uint8_t *genome, uint64_t n_bases, const uint64_t *bucket_start,
+                     const uint32_t *bucket_len, uint32_t n_buckets, const int32_t *kmer_to_index,
+                     uint64_t n_kmers);
+/* Copies the loaded index back in the .qgram layout (n_rows x ceil(NB/8) bytes); rows_out may be NULL to
+ * query n_rows only. */
+int  bmf_index_download(bmf_ctx *ctx, uint8_t *rows_out, uint64_t *n_rows_out);
 /* Same, reading <index_dir>/<indicator>.kmers_index and .qgram (q_gram_mapper.h:331-358). */
 int  bmf_load_index_files(bmf_ctx *ctx, const char *index_dir, const char *indicator);
 /* mapper::reset (q_gram_mapper.h:638-645): frees the index in HBM; the context stays usable. */

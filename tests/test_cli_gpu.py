@@ -71,6 +71,14 @@ def test_full_size_properties():
     cli = dict(read_len=300)
     flt = bma.Filter(bma.Params.from_cli(nb, **cli))
     flt.load_index_ptr(index.rows_ptr, index.num_rows, index.k2i_ptr, index.num_kmers)
+    # (0) the GPU index build gives the host indexer's rows byte for byte at full size too
+    fb = bma.Filter(bma.Params.from_cli(nb, **cli))
+    flat, _ = genome.flat()
+    bstart, blen = genome.bucket_views(65536, 300)
+    fb.build_index(flat, bstart, blen, index.kmer_to_index())
+    del flat
+    assert np.array_equal(fb.index_download(), index.rows())
+    fb.close()
     ws, wl, _, _ = bma.windows_for_reads(reads.offsets, 300)
     c, b = flt.map_windows(reads.bases, reads.quals, ws, wl)
     # (a) parity with the oracle on a sample
