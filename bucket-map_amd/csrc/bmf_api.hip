@@ -6,6 +6,8 @@
 #include "bmf_kernels.hip.h"
 #include "bmi_kernels.hip.h"
 
+#include <hipcub/hipcub.hpp>
+
 #include "../../include/bmf.h"
 
 #include <math.h>
@@ -83,14 +85,33 @@ vote_fn pick_vote(int cpl, int planes) {
 
 }  // namespace
 
+// Grow-only device buffer (a batch that is reused keeps its allocations).
+template <typename T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t cap = 0;
+    hipError_t need(size_t n) {
+        if (n <= cap && p) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        hipError_t e = hipMalloc(reinterpret_cast<void **>(&p), (n ? n : 1) * sizeof(T));
+        if (e == hipSuccess) cap = n ? n : 1;
+        return e;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
 struct bmf_batch {
     uint32_t n_windows = 0;
     uint64_t n_bytes = 0;
-    uint8_t *d_bases = nullptr, *d_quals = nullptr;
-    uint64_t *d_win_start = nullptr;
-    uint32_t *d_win_len = nullptr;
-    uint32_t *d_lists = nullptr, *d_list_n = nullptr, *d_rows_anded = nullptr;
-    uint32_t *d_counts = nullptr, *d_buckets = nullptr;
+    DevBuf<uint8_t> bases, quals, scan_tmp;
+    DevBuf<uint64_t> win_start;
+    DevBuf<uint32_t> win_len, lists, list_n, rows_anded, counts, buckets, offsets, compact;
 };
 
 struct bmf_ctx {
@@ -115,6 +136,8 @@ struct bmf_ctx {
     bool profiling = false;
     uint32_t prof_max = 0, prof_n = 0;
     std::vector<hipEvent_t> ev;      // 3 per run: before sample, between, after vote
+    // buffers reused by bmf_map_windows from call to call
+    bmf_batch *scratch = nullptr;
 };
 
 extern "C" {
@@ -274,6 +297,7 @@ void bmf_destroy(bmf_ctx *c) {
     (void)hipSetDevice(c->p.device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
+    if (c->scratch) bmf_batch_destroy(nullptr, c->scratch);
     free_index(c);
     (void)hipFree(c->d_lut);
     (void)hipFree(c->d_pos_table);
@@ -486,22 +510,15 @@ void bmf_batch_destroy(bmf_ctx *c, bmf_batch *b) {
         (void)hipSetDevice(c->p.device);
         (void)hipStreamSynchronize(c->stream);
     }
-    (void)hipFree(b->d_bases);
-    (void)hipFree(b->d_quals);
-    (void)hipFree(b->d_win_start);
-    (void)hipFree(b->d_win_len);
-    (void)hipFree(b->d_lists);
-    (void)hipFree(b->d_list_n);
-    (void)hipFree(b->d_rows_anded);
-    (void)hipFree(b->d_counts);
-    (void)hipFree(b->d_buckets);
+    b->bases.release(); b->quals.release(); b->scan_tmp.release(); b->win_start.release(); b->win_len.release();
+    b->lists.release(); b->list_n.release(); b->rows_anded.release(); b->counts.release(); b->buckets.release();
+    b->offsets.release(); b->compact.release();
     delete b;
 }
 
-int bmf_batch_create(bmf_ctx *c, const uint8_t *bases, const uint8_t *quals, uint64_t n_bytes,
-                     const uint64_t *win_start, const uint32_t *win_len, uint32_t n_windows, bmf_batch **out) {
-    if (!c || !out) return fail(BMF_ERR_ARG, "bmf_batch_create: null argument");
-    *out = nullptr;
+// Validates the windows, (re)sizes the batch's device buffers and uploads reads + window views.
+static int batch_fill(bmf_ctx *c, bmf_batch *b, const uint8_t *bases, const uint8_t *quals, uint64_t n_bytes,
+                      const uint64_t *win_start, const uint32_t *win_len, uint32_t n_windows) {
     if (n_windows && (!win_start || !win_len)) return fail(BMF_ERR_ARG, "win_start/win_len is null");
     if (n_windows > 0x3FFFFFFFu) return fail(BMF_ERR_ARG, "too many windows");
     if (n_bytes && (!bases || !quals)) return fail(BMF_ERR_ARG, "bases/quals is null");
@@ -513,32 +530,42 @@ int bmf_batch_create(bmf_ctx *c, const uint8_t *bases, const uint8_t *quals, uin
                         (unsigned long long)win_start[w], win_len[w], (unsigned long long)n_bytes);
     }
     HIP_TRY(hipSetDevice(c->p.device));
-    bmf_batch *b = new bmf_batch();
+    HIP_TRY(hipStreamSynchronize(c->stream));   // the buffers may still be in use by an earlier run
     b->n_windows = n_windows;
     b->n_bytes = n_bytes;
     const size_t n = n_windows;
     hipError_t e = hipSuccess;
     auto ok = [&](hipError_t r) { if (e == hipSuccess) e = r; };
-    ok(dev_alloc(&b->d_bases, (size_t)n_bytes));
-    ok(dev_alloc(&b->d_quals, (size_t)n_bytes));
-    ok(dev_alloc(&b->d_win_start, n));
-    ok(dev_alloc(&b->d_win_len, n));
-    ok(dev_alloc(&b->d_lists, 2 * n * c->dp.list_len));
-    ok(dev_alloc(&b->d_list_n, n));
-    ok(dev_alloc(&b->d_rows_anded, n));
-    ok(dev_alloc(&b->d_counts, 2 * n));
-    ok(dev_alloc(&b->d_buckets, 2 * n * c->p.max_candidates));
+    ok(b->bases.need((size_t)n_bytes));
+    ok(b->quals.need((size_t)n_bytes));
+    ok(b->win_start.need(n));
+    ok(b->win_len.need(n));
+    ok(b->lists.need(2 * n * c->dp.list_len));
+    ok(b->list_n.need(n));
+    ok(b->rows_anded.need(n));
+    ok(b->counts.need(2 * n));
+    ok(b->buckets.need(2 * n * c->p.max_candidates));
     if (e == hipSuccess && n_bytes) {
-        ok(hipMemcpy(b->d_bases, bases, (size_t)n_bytes, hipMemcpyHostToDevice));
-        ok(hipMemcpy(b->d_quals, quals, (size_t)n_bytes, hipMemcpyHostToDevice));
+        ok(hipMemcpy(b->bases.p, bases, (size_t)n_bytes, hipMemcpyHostToDevice));
+        ok(hipMemcpy(b->quals.p, quals, (size_t)n_bytes, hipMemcpyHostToDevice));
     }
     if (e == hipSuccess && n) {
-        ok(hipMemcpy(b->d_win_start, win_start, n * sizeof(uint64_t), hipMemcpyHostToDevice));
-        ok(hipMemcpy(b->d_win_len, win_len, n * sizeof(uint32_t), hipMemcpyHostToDevice));
+        ok(hipMemcpy(b->win_start.p, win_start, n * sizeof(uint64_t), hipMemcpyHostToDevice));
+        ok(hipMemcpy(b->win_len.p, win_len, n * sizeof(uint32_t), hipMemcpyHostToDevice));
     }
-    if (e != hipSuccess) {
+    if (e != hipSuccess) return fail(BMF_ERR_HIP, "uploading the batch failed: %s", hipGetErrorString(e));
+    return BMF_OK;
+}
+
+int bmf_batch_create(bmf_ctx *c, const uint8_t *bases, const uint8_t *quals, uint64_t n_bytes,
+                     const uint64_t *win_start, const uint32_t *win_len, uint32_t n_windows, bmf_batch **out) {
+    if (!c || !out) return fail(BMF_ERR_ARG, "bmf_batch_create: null argument");
+    *out = nullptr;
+    bmf_batch *b = new bmf_batch();
+    const int rc = batch_fill(c, b, bases, quals, n_bytes, win_start, win_len, n_windows);
+    if (rc != BMF_OK) {
         bmf_batch_destroy(c, b);
-        return fail(BMF_ERR_HIP, "bmf_batch_create: %s", hipGetErrorString(e));
+        return rc;
     }
     *out = b;
     return BMF_OK;
@@ -554,11 +581,11 @@ int bmf_batch_run(bmf_ctx *c, bmf_batch *b) {
     hipEvent_t *ev = prof ? &c->ev[(size_t)3 * c->prof_n] : nullptr;
     if (prof) HIP_TRY(hipEventRecord(ev[0], c->stream));
     hipLaunchKernelGGL(bmf::bmf_sample_kernel, dim3(b->n_windows), dim3(bmf::kWave), c->sample_lds, c->stream, c->dp,
-                       b->d_bases, b->d_quals, b->d_win_start, b->d_win_len, c->d_lut, c->d_qgram_ok, c->d_k2i, c->d_pos_table,
-                       b->d_lists, b->d_list_n, b->d_rows_anded);
+                       b->bases.p, b->quals.p, b->win_start.p, b->win_len.p, c->d_lut, c->d_qgram_ok, c->d_k2i, c->d_pos_table,
+                       b->lists.p, b->list_n.p, b->rows_anded.p);
     if (prof) HIP_TRY(hipEventRecord(ev[1], c->stream));
-    hipLaunchKernelGGL(c->vote, dim3(2 * b->n_windows), dim3(bmf::kWave), 0, c->stream, c->dp, c->d_rows, b->d_lists,
-                       b->d_list_n, b->d_counts, b->d_buckets);
+    hipLaunchKernelGGL(c->vote, dim3(2 * b->n_windows), dim3(bmf::kWave), 0, c->stream, c->dp, c->d_rows, b->lists.p,
+                       b->list_n.p, b->counts.p, b->buckets.p);
     if (prof) {
         HIP_TRY(hipEventRecord(ev[2], c->stream));
         c->prof_n++;
@@ -580,15 +607,35 @@ int bmf_batch_download(bmf_ctx *c, bmf_batch *b, uint32_t *out_counts, uint32_t 
     HIP_TRY(hipStreamSynchronize(c->stream));
     const size_t n = b->n_windows;
     if (n == 0) return BMF_OK;
-    HIP_TRY(hipMemcpy(out_counts, b->d_counts, 2 * n * sizeof(uint32_t), hipMemcpyDeviceToHost));
-    // The device buffer is dense (max_candidates slots per list); only `count` slots are defined, so
-    // copy through a staging buffer and hand over exactly the defined entries.
-    std::vector<uint32_t> tmp(2 * n * c->p.max_candidates);
-    HIP_TRY(hipMemcpy(tmp.data(), b->d_buckets, tmp.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    // The device buffer is dense (max_candidates slots per list) but holds < 1 id per list on average:
+    // exclusive-scan the counts on the device, gather the defined ids into one compact array and copy
+    // only that (2 x 4 B per window + the ids instead of 2 x max_candidates x 4 B per window).
+    const size_t n_items = 2 * n;
     const uint32_t mc = c->p.max_candidates;
-    for (size_t i = 0; i < 2 * n; i++) {
+    HIP_TRY(b->offsets.need(n_items));
+    size_t tmp_bytes = 0;
+    HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, b->counts.p, b->offsets.p, (int)n_items, c->stream));
+    HIP_TRY(b->scan_tmp.need(tmp_bytes));
+    HIP_TRY(hipcub::DeviceScan::ExclusiveSum(b->scan_tmp.p, tmp_bytes, b->counts.p, b->offsets.p, (int)n_items, c->stream));
+    HIP_TRY(hipMemcpyAsync(out_counts, b->counts.p, n_items * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    uint64_t total = 0;
+    for (size_t i = 0; i < n_items; i++) {
         if (out_counts[i] > mc) return fail(BMF_ERR_HIP, "device returned count %u > max_candidates", out_counts[i]);
-        memcpy(out_buckets + i * mc, tmp.data() + i * mc, out_counts[i] * sizeof(uint32_t));
+        total += out_counts[i];
+    }
+    if (total == 0) return BMF_OK;
+    HIP_TRY(b->compact.need((size_t)total));
+    hipLaunchKernelGGL(bmf::bmf_compact_kernel, dim3((unsigned)((n_items + 255) / 256)), dim3(256), 0, c->stream, b->counts.p,
+                       b->offsets.p, b->buckets.p, mc, (uint32_t)n_items, b->compact.p);
+    HIP_TRY(hipGetLastError());
+    std::vector<uint32_t> ids((size_t)total);
+    HIP_TRY(hipMemcpyAsync(ids.data(), b->compact.p, (size_t)total * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    size_t at = 0;
+    for (size_t i = 0; i < n_items; i++) {
+        memcpy(out_buckets + i * mc, ids.data() + at, out_counts[i] * sizeof(uint32_t));
+        at += out_counts[i];
     }
     return BMF_OK;
 }
@@ -599,7 +646,7 @@ int bmf_batch_rows_anded(bmf_ctx *c, bmf_batch *b, uint64_t *out) {
     HIP_TRY(hipStreamSynchronize(c->stream));
     std::vector<uint32_t> tmp(b->n_windows);
     if (b->n_windows)
-        HIP_TRY(hipMemcpy(tmp.data(), b->d_rows_anded, tmp.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(tmp.data(), b->rows_anded.p, tmp.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
     uint64_t s = 0;
     for (uint32_t v : tmp) s += v;
     *out = s;
@@ -613,12 +660,10 @@ int bmf_map_windows(bmf_ctx *c, const uint8_t *bases, const uint8_t *quals, uint
     if (!c->loaded) return fail(BMF_ERR_STATE, "the q-gram index is empty; cannot accept query");
     if (n_windows == 0) return BMF_OK;
     if (!out_counts || !out_buckets) return fail(BMF_ERR_ARG, "bmf_map_windows: null output");
-    bmf_batch *b = nullptr;
-    int rc = bmf_batch_create(c, bases, quals, n_bytes, win_start, win_len, n_windows, &b);
-    if (rc != BMF_OK) return rc;
-    rc = bmf_batch_run(c, b);
-    if (rc == BMF_OK) rc = bmf_batch_download(c, b, out_counts, out_buckets);
-    bmf_batch_destroy(c, b);
+    if (!c->scratch) c->scratch = new bmf_batch();   // device buffers are kept from call to call
+    int rc = batch_fill(c, c->scratch, bases, quals, n_bytes, win_start, win_len, n_windows);
+    if (rc == BMF_OK) rc = bmf_batch_run(c, c->scratch);
+    if (rc == BMF_OK) rc = bmf_batch_download(c, c->scratch, out_counts, out_buckets);
     return rc;
 }
 

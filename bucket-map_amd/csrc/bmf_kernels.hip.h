@@ -198,6 +198,16 @@ __global__ __launch_bounds__(kWave) void bmf_sample_kernel(
     }
 }
 
+// Gathers the defined candidate ids of the dense per-list slots into one compact array (download path).
+__global__ void bmf_compact_kernel(const uint32_t *__restrict__ counts, const uint32_t *__restrict__ offsets,
+                                   const uint32_t *__restrict__ buckets, uint32_t max_cand, uint32_t n_items,
+                                   uint32_t *__restrict__ compact) {
+    const uint32_t item = blockIdx.x * blockDim.x + threadIdx.x;
+    if (item >= n_items) return;
+    const uint32_t n = counts[item], o = offsets[item];
+    for (uint32_t i = 0; i < n; i++) compact[o + i] = buckets[(size_t)item * max_cand + i];
+}
+
 // --------------------------------------------------------------------------------------------------
 // vote kernel
 // --------------------------------------------------------------------------------------------------

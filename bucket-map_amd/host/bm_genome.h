@@ -6,6 +6,7 @@
 
 #include "bm_common.h"
 
+#include <array>
 #include <cstdio>
 #include <fstream>
 #include <functional>
@@ -49,9 +50,22 @@ inline Genome read_fasta(const std::string &path) {
             g.seqs.emplace_back();
         } else {
             if (g.seqs.empty()) throw std::runtime_error("FASTA file " + path + " does not start with '>'");
+            // append the line, then fold it in place through a 256-entry table (white space inside a
+            // sequence line is rare: only then fall back to filtering character by character)
+            static const auto fold = [] {
+                std::array<char, 256> t{};
+                for (int c = 0; c < 256; c++) t[static_cast<size_t>(c)] = fold_genome_char(static_cast<char>(c));
+                return t;
+            }();
             std::string &s = g.seqs.back();
-            for (char c : line)
-                if (c != ' ' && c != '\t') s.push_back(fold_genome_char(c));
+            const size_t at = s.size();
+            if (line.find_first_of(" \t") == std::string::npos) {
+                s.append(line);
+            } else {
+                for (char c : line)
+                    if (c != ' ' && c != '\t') s.push_back(c);
+            }
+            for (size_t i = at; i < s.size(); i++) s[i] = fold[static_cast<unsigned char>(s[i])];
         }
     }
     return g;
