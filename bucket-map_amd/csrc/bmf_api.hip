@@ -55,7 +55,8 @@ hipError_t dev_alloc(T **p, size_t n) {
 using vote_fn = void (*)(bmf::DevParams, const uint8_t *, const uint32_t *, const uint32_t *, uint32_t *,
                          uint32_t *);
 
-constexpr int depth_for(int cpl) { return cpl <= 2 ? 8 : (cpl <= 4 ? 4 : 2); }
+// rows in flight per wave: about 12-16 KB of row data per wave whatever the row length
+constexpr int depth_for(int cpl) { return cpl <= 2 ? 8 : (cpl <= 4 ? 4 : (cpl <= 6 ? 3 : 2)); }
 
 template <int CPL>
 vote_fn pick_planes(int planes) {

@@ -41,6 +41,25 @@ def test_sam_identical_to_oracle_backed_run(tmp_path, gpus, long_reads):
     assert gpu_sam.count(b"\n") > 0.9 * rd.n
 
 
+def test_long_read_profile_sam_identical(tmp_path):
+    # the reference's long-read command line (benchmark/long_read/benchmark_map.sh:25):
+    # -s 30 -e 0.9 -n 0.1 -l 12 -p 20 -u 5 on ONT-like reads (sub 0.03, ins = del 0.025), bucket_len 262144
+    from bucket_map_amd import host
+    g = host.Genome.synth(23, [2_400_000, 700_000])
+    g.write_fasta(str(tmp_path / "g.fa"))
+    rd = host.Reads(g, 262144, 300, 6000, 150, sub=0.03, ins=0.025, dele=0.025, seed=8)
+    rd.write_fastq(str(tmp_path / "reads"))
+    flags = ["-i", "idx", "--genome", "g.fa", "--bucket-len", "262144", "-f", "1", "-s", "30", "-e", "0.9", "-n", "0.1",
+             "-l", "12", "-p", "20", "-u", "5", "-q", "reads.fastq"]
+    _run(GPU_CLI, [*flags, "-o", "gpu.sam", "--gpus", "0,0"], tmp_path)
+    _run(ORACLE_CLI, [*flags, "-o", "cpu.sam"], tmp_path)
+    gpu_sam = (tmp_path / "gpu.sam").read_bytes()
+    assert gpu_sam == (tmp_path / "cpu.sam").read_bytes()
+    # most long reads get at least one location despite 8 % errors
+    names = {line.split(b"\t", 1)[0] for line in gpu_sam.split(b"\n") if line and not line.startswith(b"@")}
+    assert len(names) > 0.5 * rd.n
+
+
 def test_cli_without_index_files_builds_them(tmp_path):
     # locator::initialize indexes first when the files are missing (locator.h:33-34)
     from bucket_map_amd import host
