@@ -53,7 +53,7 @@ hipError_t dev_alloc(T **p, size_t n) {
 }
 
 using vote_fn = void (*)(bmf::DevParams, const uint8_t *, const uint32_t *, const uint32_t *, uint32_t *,
-                         uint32_t *);
+                         uint32_t *, uint32_t *);
 
 // rows in flight per wave: about 12-16 KB of row data per wave whatever the row length
 constexpr int depth_for(int cpl) { return cpl <= 2 ? 8 : (cpl <= 4 ? 4 : (cpl <= 6 ? 3 : 2)); }
@@ -62,10 +62,21 @@ template <int CPL>
 vote_fn pick_planes(int planes) {
     constexpr int D = depth_for(CPL);
     switch (planes) {
-    case 2: return bmf::bmf_vote_kernel<CPL, 2, D>;
-    case 3: return bmf::bmf_vote_kernel<CPL, 3, D>;
-    case 4: return bmf::bmf_vote_kernel<CPL, 4, D>;
-    case 5: return bmf::bmf_vote_kernel<CPL, 5, D>;
+    case 2: return bmf::bmf_vote_kernel<CPL, 2, D, false>;
+    case 3: return bmf::bmf_vote_kernel<CPL, 3, D, false>;
+    case 4: return bmf::bmf_vote_kernel<CPL, 4, D, false>;
+    case 5: return bmf::bmf_vote_kernel<CPL, 5, D, false>;
+    }
+    return nullptr;
+}
+
+// NB > 65 536: every wave takes one slice of 8 chunks per lane
+vote_fn pick_sliced(int planes) {
+    switch (planes) {
+    case 2: return bmf::bmf_vote_kernel<8, 2, 2, true>;
+    case 3: return bmf::bmf_vote_kernel<8, 3, 2, true>;
+    case 4: return bmf::bmf_vote_kernel<8, 4, 2, true>;
+    case 5: return bmf::bmf_vote_kernel<8, 5, 2, true>;
     }
     return nullptr;
 }
@@ -113,6 +124,7 @@ struct bmf_batch {
     DevBuf<uint8_t> bases, quals, scan_tmp;
     DevBuf<uint64_t> win_start;
     DevBuf<uint32_t> win_len, lists, list_n, rows_anded, counts, buckets, offsets, compact;
+    DevBuf<uint32_t> slice_min, slice_cnt, slice_ids;   // NB > 65 536 only
 };
 
 struct bmf_ctx {
@@ -131,6 +143,7 @@ struct bmf_ctx {
     uint16_t *d_pos_table = nullptr;
     // kernel variant
     int cpl = 0, planes = 0, depth = 0;
+    uint32_t n_slices = 1;           // > 1 when NB > 65 536: one wave per (item, 65 536-bucket slice)
     vote_fn vote = nullptr;
     size_t sample_lds = 0;
     // profiling
@@ -194,8 +207,10 @@ int bmf_create(const bmf_params *params, bmf_ctx **out) {
 
     const uint32_t row_bytes = (p.num_buckets + 7u) >> 3;
     const uint32_t n_chunks = (row_bytes + 15u) / 16u;
-    const int cpl = (int)((n_chunks + 63u) / 64u);
-    if (cpl > 8) return fail(BMF_ERR_UNSUPPORTED, "num_buckets > 65536 is not supported yet (got %u)", p.num_buckets);
+    int cpl = (int)((n_chunks + 63u) / 64u);
+    const uint32_t n_slices = cpl > 8 ? (n_chunks + 511u) / 512u : 1u;   // NB > 65 536: 65 536-bucket slices
+    if (n_slices > 256) return fail(BMF_ERR_UNSUPPORTED, "num_buckets must be <= 16777216 (got %u)", p.num_buckets);
+    if (n_slices > 1) cpl = 8;
     int planes = 0;
     while (((1u << planes) - 1u) < p.num_fault) planes++;
     if (planes < 2) planes = 2;
@@ -210,8 +225,9 @@ int bmf_create(const bmf_params *params, bmf_ctx **out) {
     c->p = p;
     c->cpl = cpl;
     c->planes = planes;
-    c->depth = depth_for(cpl);
-    c->vote = pick_vote(cpl, planes);
+    c->n_slices = n_slices;
+    c->depth = n_slices > 1 ? 2 : depth_for(cpl);
+    c->vote = n_slices > 1 ? pick_sliced(planes) : pick_vote(cpl, planes);
     if (!c->vote) {
         delete c;
         return fail(BMF_ERR_UNSUPPORTED, "no vote kernel for cpl=%d planes=%d", cpl, planes);
@@ -514,6 +530,7 @@ void bmf_batch_destroy(bmf_ctx *c, bmf_batch *b) {
     b->bases.release(); b->quals.release(); b->scan_tmp.release(); b->win_start.release(); b->win_len.release();
     b->lists.release(); b->list_n.release(); b->rows_anded.release(); b->counts.release(); b->buckets.release();
     b->offsets.release(); b->compact.release();
+    b->slice_min.release(); b->slice_cnt.release(); b->slice_ids.release();
     delete b;
 }
 
@@ -546,6 +563,11 @@ static int batch_fill(bmf_ctx *c, bmf_batch *b, const uint8_t *bases, const uint
     ok(b->rows_anded.need(n));
     ok(b->counts.need(2 * n));
     ok(b->buckets.need(2 * n * c->p.max_candidates));
+    if (c->n_slices > 1) {
+        ok(b->slice_min.need(2 * n * c->n_slices));
+        ok(b->slice_cnt.need(2 * n * c->n_slices));
+        ok(b->slice_ids.need(2 * n * c->n_slices * c->p.max_candidates));
+    }
     if (e == hipSuccess && n_bytes) {
         ok(hipMemcpy(b->bases.p, bases, (size_t)n_bytes, hipMemcpyHostToDevice));
         ok(hipMemcpy(b->quals.p, quals, (size_t)n_bytes, hipMemcpyHostToDevice));
@@ -585,8 +607,16 @@ int bmf_batch_run(bmf_ctx *c, bmf_batch *b) {
                        b->bases.p, b->quals.p, b->win_start.p, b->win_len.p, c->d_lut, c->d_qgram_ok, c->d_k2i, c->d_pos_table,
                        b->lists.p, b->list_n.p, b->rows_anded.p);
     if (prof) HIP_TRY(hipEventRecord(ev[1], c->stream));
-    hipLaunchKernelGGL(c->vote, dim3(2 * b->n_windows), dim3(bmf::kWave), 0, c->stream, c->dp, c->d_rows, b->lists.p,
-                       b->list_n.p, b->counts.p, b->buckets.p);
+    if (c->n_slices == 1) {
+        hipLaunchKernelGGL(c->vote, dim3(2 * b->n_windows), dim3(bmf::kWave), 0, c->stream, c->dp, c->d_rows, b->lists.p,
+                           b->list_n.p, b->counts.p, b->buckets.p, (uint32_t *)nullptr);
+    } else {
+        hipLaunchKernelGGL(c->vote, dim3(2 * b->n_windows, c->n_slices), dim3(bmf::kWave), 0, c->stream, c->dp, c->d_rows,
+                           b->lists.p, b->list_n.p, b->slice_cnt.p, b->slice_ids.p, b->slice_min.p);
+        hipLaunchKernelGGL(bmf::bmf_merge_slices_kernel, dim3((2 * b->n_windows + 255) / 256), dim3(256), 0, c->stream, c->dp,
+                           2 * b->n_windows, c->n_slices, b->slice_min.p, b->slice_cnt.p, b->slice_ids.p, b->counts.p,
+                           b->buckets.p);
+    }
     if (prof) {
         HIP_TRY(hipEventRecord(ev[2], c->stream));
         c->prof_n++;

@@ -274,10 +274,14 @@ __device__ __forceinline__ uint32_t count_ge(const u128 (&cnt)[PLANES][CPL], int
 // minimum miss count if that minimum is < F, emitted as ascending ids.  Non-bucket bits carry a
 // saturated counter from the start (see the kernel), so they can never be in the minimum set unless
 // the minimum itself is saturated (>= F), in which case the result is empty anyway.
-template <int CPL, int PLANES>
+//
+// SLICED (NB > 65 536): the wave only holds one 65 536-bucket slice of the row.  It then reports its LOCAL
+// minimum, and the ids at that minimum (or "more than max_candidates"), to per-(item, slice) slots;
+// bmf_merge_slices_kernel takes the minimum over the slices and concatenates the slices that reach it.
+template <int CPL, int PLANES, bool SLICED>
 __device__ __forceinline__ void emit_best(const DevParams &P, const u128 (&cnt)[PLANES][CPL], uint32_t item,
-                                          uint32_t lane, uint32_t *__restrict__ out_counts,
-                                          uint32_t *__restrict__ out_buckets) {
+                                          uint32_t lane, uint32_t chunk0, uint32_t *__restrict__ out_counts,
+                                          uint32_t *__restrict__ out_buckets, uint32_t *__restrict__ out_min) {
     u128 cand[CPL];
 #pragma unroll
     for (int j = 0; j < CPL; j++)
@@ -308,8 +312,14 @@ __device__ __forceinline__ void emit_best(const DevParams &P, const u128 (&cnt)[
         mine += pc[j];
     }
     const uint32_t total = wave_sum(mine);
-    // m_min >= F: every level of the reference's filter is empty.  total > max_cand: cleared.
-    if (m_min >= P.F || total > P.max_cand) {
+    if (SLICED) {
+        if (lane == 0) {
+            out_min[item] = m_min;
+            out_counts[item] = m_min >= P.F ? 0u : (total > P.max_cand ? P.max_cand + 1u : total);
+        }
+        if (m_min >= P.F || total > P.max_cand) return;
+    } else if (m_min >= P.F || total > P.max_cand) {
+        // m_min >= F: every level of the reference's filter is empty.  total > max_cand: cleared.
         if (lane == 0) out_counts[item] = 0;
         return;
     }
@@ -330,12 +340,12 @@ __device__ __forceinline__ void emit_best(const DevParams &P, const u128 (&cnt)[
         for (int x = 0; x < 4; x++) {
             uint32_t bits = cand[j].v[x];
             while (bits) {
-                out[pos++] = (lane + kWave * j) * 128u + x * 32u + (uint32_t)__builtin_ctz(bits);
+                out[pos++] = (chunk0 + lane + kWave * j) * 128u + x * 32u + (uint32_t)__builtin_ctz(bits);
                 bits &= bits - 1u;
             }
         }
     }
-    if (lane == 0) out_counts[item] = total;
+    if (!SLICED && lane == 0) out_counts[item] = total;
 }
 
 // CPL   : 16-byte chunks per lane (lane l owns chunks l, l+64, ...: every load is 1 KiB contiguous)
@@ -346,25 +356,31 @@ __device__ __forceinline__ void emit_best(const DevParams &P, const u128 (&cnt)[
 // plus DEPTH (a row of ones ANDs as the identity and, landing on a sample boundary, adds no miss), and
 // lanes past the end of the row re-read the row's last chunk, so every load is unconditional and the
 // compiler can wait for exactly the oldest row in flight (counted vmcnt) instead of draining the ring.
-template <int CPL, int PLANES, int DEPTH>
+template <int CPL, int PLANES, int DEPTH, bool SLICED>
 __global__ __launch_bounds__(kWave) void bmf_vote_kernel(DevParams P, const uint8_t *__restrict__ rows,
                                                         const uint32_t *__restrict__ row_lists,
                                                         const uint32_t *__restrict__ list_n,
                                                         uint32_t *__restrict__ out_counts,
-                                                        uint32_t *__restrict__ out_buckets) {
-    const uint32_t item = blockIdx.x;          // 2*window + orientation
+                                                        uint32_t *__restrict__ out_buckets,
+                                                        uint32_t *__restrict__ out_min) {
     const uint32_t lane = threadIdx.x;
-    if (list_n[item >> 1] == 0) {              // window rejected by the sample kernel
-        if (lane == 0) out_counts[item] = 0;
+    // SLICED: blockIdx.y selects the 65 536-bucket slice; outputs go to the (item, slice) slot
+    const uint32_t chunk0 = SLICED ? blockIdx.y * (uint32_t)(CPL * kWave) : 0u;
+    const uint32_t item = SLICED ? blockIdx.x * gridDim.y + blockIdx.y : blockIdx.x;   // output slot
+    const uint32_t *__restrict__ list = row_lists + (size_t)blockIdx.x * P.list_len;   // blockIdx.x = 2*window + orientation
+    if (list_n[blockIdx.x >> 1] == 0) {        // window rejected by the sample kernel
+        if (lane == 0) {
+            out_counts[item] = 0;
+            if (SLICED) out_min[item] = 0xFFFFFFFFu;
+        }
         return;
     }
-    const uint32_t *__restrict__ list = row_lists + (size_t)item * P.list_len;
     const uint32_t n_iter = P.list_len - DEPTH;     // rows to consume, a multiple of DEPTH
 
     uint32_t coff[CPL];
 #pragma unroll
     for (int j = 0; j < CPL; j++) {
-        const uint32_t c = lane + kWave * j;
+        const uint32_t c = chunk0 + lane + kWave * j;
         coff[j] = (c < P.n_chunks ? c : P.n_chunks - 1u) * 16u;
     }
 
@@ -384,7 +400,7 @@ __global__ __launch_bounds__(kWave) void bmf_vote_kernel(DevParams P, const uint
         for (int x = 0; x < 4; x++) {
             bf[j].v[x] = 0xFFFFFFFFu;
             // bits that are not buckets start with a saturated (>= F) counter: never candidates
-            const uint32_t dead = ~bucket_mask(P, lane + kWave * j, x);
+            const uint32_t dead = ~bucket_mask(P, chunk0 + lane + kWave * j, x);
 #pragma unroll
             for (int p = 0; p < PLANES; p++) cnt[p][j].v[x] = dead;
         }
@@ -414,14 +430,44 @@ __global__ __launch_bounds__(kWave) void bmf_vote_kernel(DevParams P, const uint
 #pragma unroll
                         for (int x = 0; x < 4; x++) alive |= ~count_ge<CPL, PLANES>(cnt, j2, x, P.F);
                     if (__ballot(alive != 0) == 0) {
-                        if (lane == 0) out_counts[item] = 0;
+                        if (lane == 0) {
+                            out_counts[item] = 0;
+                            if (SLICED) out_min[item] = 0xFFFFFFFFu;
+                        }
                         return;
                     }
                 }
             }
         }
     }
-    emit_best<CPL, PLANES>(P, cnt, item, lane, out_counts, out_buckets);
+    emit_best<CPL, PLANES, SLICED>(P, cnt, item, lane, chunk0, out_counts, out_buckets, out_min);
+}
+
+// NB > 65 536: best_results over the slices of one (window, orientation).  One thread per item.
+__global__ void bmf_merge_slices_kernel(DevParams P, uint32_t n_items, uint32_t n_slices,
+                                        const uint32_t *__restrict__ slice_min, const uint32_t *__restrict__ slice_cnt,
+                                        const uint32_t *__restrict__ slice_ids, uint32_t *__restrict__ out_counts,
+                                        uint32_t *__restrict__ out_buckets) {
+    const uint32_t item = blockIdx.x * blockDim.x + threadIdx.x;
+    if (item >= n_items) return;
+    const uint32_t *mn = slice_min + (size_t)item * n_slices, *ct = slice_cnt + (size_t)item * n_slices;
+    uint32_t best = 0xFFFFFFFFu;
+    for (uint32_t s = 0; s < n_slices; s++) best = mn[s] < best ? mn[s] : best;
+    uint32_t total = 0;
+    if (best < P.F)
+        for (uint32_t s = 0; s < n_slices; s++)
+            if (mn[s] == best) total += ct[s];          // max_cand + 1 marks an overflowing slice
+    if (best >= P.F || total > P.max_cand) {
+        out_counts[item] = 0;
+        return;
+    }
+    uint32_t *out = out_buckets + (size_t)item * P.max_cand, at = 0;
+    for (uint32_t s = 0; s < n_slices; s++)
+        if (mn[s] == best) {
+            const uint32_t *ids = slice_ids + ((size_t)item * n_slices + s) * P.max_cand;
+            for (uint32_t i = 0; i < ct[s]; i++) out[at++] = ids[i];
+        }
+    out_counts[item] = total;
 }
 
 }  // namespace bmf

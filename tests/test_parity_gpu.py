@@ -69,7 +69,10 @@ def test_ecoli_like(ecoli_like):
     (26507, 15, 0.4, 10, 7),      # Egu geometry (CPL 4), P-default
     (26507, 20, 0.6, 12, 7),      # Egu geometry, P-bench (S=20, F=12, G=6)
     (46789, 15, 0.4, 10, 7),      # GRCh38 geometry (CPL 6)
-    (65536, 15, 0.4, 9, 7),       # largest supported NB (CPL 8)
+    (65536, 15, 0.4, 9, 7),       # largest single-wave NB (CPL 8)
+    (65537, 15, 0.4, 9, 7),       # 2 slices, the second holds one bucket
+    (140000, 15, 0.4, 10, 7),     # 3 slices (NB > 65 536: one wave per 65 536-bucket slice + merge)
+    (140000, 20, 0.6, 12, 7),     # 3 slices, P-bench
 ])
 def test_geometries(nb_target, samples, err, k, q):
     bucket_len = 256
@@ -126,6 +129,35 @@ def test_repeats_overflow_max_candidates():
                     distinguishability=0.0, average_base_quality=25)
     _, counts = _compare(case, what="repeats")
     assert counts.max() == 0
+
+
+@pytest.mark.parametrize("copies,expect_cleared", [(3, False), (40, True)])
+def test_ties_across_slices(copies, expect_cleared):
+    # NB > 65 536: identical records far apart put equally good buckets into DIFFERENT 65 536-bucket slices;
+    # the merge must concatenate them in ascending order, and clear the list when the slices together
+    # exceed max_candidates although no single slice does (q_gram_mapper.h:471-476).
+    from bucket_map_amd import host
+    per_copy = 140_000 // copies
+    g1 = host.Genome.synth(6, [per_copy * 256])          # keep alive: record_seq is a view into it
+    unit = bytes(g1.record_seq(0)).decode()
+    path = f"/tmp/bm_slices_{copies}.fa"
+    with open(path, "w") as f:
+        for i in range(copies):
+            f.write(f">copy{i}\n{unit}\n")
+    case = Case.__new__(Case)
+    case.genome = host.Genome.read_fasta(path)
+    case.bucket_len, case.read_len = 256, 100
+    case.num_buckets = case.genome.awk_bucket_num(256)
+    assert case.num_buckets > 2 * 65536
+    case.index = host.Index(case.genome, case.num_buckets, 256, 100, q=7)
+    case.reads = host.Reads(case.genome, 256, 100, 100, 200, sub=0.0, ins=0.0, dele=0.0, seed=10)
+    case.cli = dict(index_seed=7, query_seed=10, read_len=100, mapper_samples=15, max_error_rate=0.4,
+                    distinguishability=0.0, average_base_quality=25)
+    _, counts = _compare(case, what=f"{copies} copies")
+    if expect_cleared:
+        assert counts.max() == 0
+    else:
+        assert (counts.max(axis=1) >= copies).mean() > 0.8    # one candidate per copy (plus overlap neighbours)
 
 
 def test_ragged_and_degenerate_windows(ecoli_like):
@@ -252,7 +284,7 @@ def test_error_behaviour():
     assert c.sum() == 0                              # all-zero index: every bucket misses every sample
     flt.close()
     with pytest.raises(bma.BmfError):
-        bma.Filter(bma.Params.from_cli(70000))       # NB > 65536 unsupported in this round
+        bma.Filter(bma.Params.from_cli(17_000_000))  # NB > 16 777 216 unsupported
 
 
 def test_zeros_match_oracle(ecoli_like):
