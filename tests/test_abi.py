@@ -26,6 +26,17 @@ def test_library_exports_every_declared_symbol():
     assert L.bmf_abi_version() == 1
 
 
+def test_locator_abi_symbols():
+    from bucket_map_amd import locate
+    text = open(os.path.join(ROOT, "include", "bml.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    names = sorted(set(re.findall(r"\b(bml_[a-z0-9_]+)\s*\(", text)))
+    assert names == sorted(locate.SYMBOLS), "python binding and include/bml.h disagree"
+    L = locate.lib()
+    for n in names:
+        assert hasattr(L, n), f"libbmf.so does not export {n}"
+
+
 def test_float32_helpers_are_the_reference_derivations():
     L = bma.lib()
     assert L.bmf_fault_from_rate(15, 0.4) == 6
