@@ -17,6 +17,8 @@
 // Defined per build: the product links make_mapper_gpu.cpp (MI355X filter + MI355X locator scan).
 std::unique_ptr<bm::mapper> bm_make_mapper(const bm::cmd_arguments &args, unsigned int num_buckets, unsigned int fault);
 std::unique_ptr<bm::offset_scanner> bm_make_scanner(const bm::cmd_arguments &args, int allowed_mismatch, int allowed_indel);
+// --gpu-index: fills ix with the rows built on the device; false = not available in this build.
+bool bm_gpu_index(const bm::cmd_arguments &args, const bm::Genome &genome, unsigned int num_buckets, bm::QgramIndex &ix);
 
 int main(int argc, char **argv) {
     bm::cmd_arguments args;
@@ -50,10 +52,13 @@ int main(int argc, char **argv) {
             }
             std::cerr << "[INFO]\t\tSet index seed length to be: " << static_cast<int>(args.index_seed_length) << ".\n";
             auto t0 = std::chrono::steady_clock::now();
-            bm::QgramIndex ix = bm::build_index(genome, num_buckets, static_cast<int>(args.bucket_len),
-                                                static_cast<int>(args.max_read_length), args.index_seed_length,
-                                                bm::FracMinHash::from_seed(args.hash_seed), args.frac_min_hash,
-                                                args.host_threads);
+            // indexing is a host job in the reference and by default here; --gpu-index builds the same rows
+            // in HBM (bmf_build_index, byte-identical) and copies them back for the files
+            bm::QgramIndex ix;
+            if (!(args.gpu_index && bm_gpu_index(args, genome, num_buckets, ix)))
+                ix = bm::build_index(genome, num_buckets, static_cast<int>(args.bucket_len),
+                                     static_cast<int>(args.max_read_length), args.index_seed_length,
+                                     bm::FracMinHash::from_seed(args.hash_seed), args.frac_min_hash, args.host_threads);
             std::cerr << "[INFO]\t\tNumber of remaining k-mers after FracMinHash is " << ix.num_rows << " out of "
                       << ix.kmer_to_index.size() << " (" << static_cast<float>(ix.num_rows) / ix.kmer_to_index.size() * 100
                       << "%).\n";

@@ -1,6 +1,7 @@
 // make_mapper_gpu.cpp -- the product's factories: the MI355X filter behind bm::mapper and the MI355X
 // locator scan behind bm::offset_scanner.
 // (main.cpp:202-209: q_gram_mapper<BM_BUCKET_NUM> map(BM_BUCKET_LEN, read_len, k, q, S, fault, d, b))
+#include "bm_indexer.h"
 #include "cli.h"
 #include "gpu_offset_scanner.h"
 #include "gpu_q_gram_mapper.h"
@@ -13,6 +14,49 @@ std::unique_ptr<bm::mapper> bm_make_mapper(const bm::cmd_arguments &args, unsign
                                                    args.mapper_sample_size, fault,
                                                    args.mapper_distinguishability_threshold, args.average_base_quality,
                                                    30, 5, args.gpus, args.early_exit ? BMF_FLAG_EARLY_EXIT : 0u);
+}
+
+// --gpu-index: bucket_indexer::index on the device (bmf_build_index), rows copied back for the files.
+bool bm_gpu_index(const bm::cmd_arguments &args, const bm::Genome &genome, unsigned int num_buckets, bm::QgramIndex &ix) {
+    ix = bm::QgramIndex();
+    ix.num_buckets = num_buckets;
+    ix.row_bytes = (num_buckets + 7u) >> 3;
+    bm::select_qgrams(ix, args.index_seed_length, bm::FracMinHash::from_seed(args.hash_seed), args.frac_min_hash);
+    const std::vector<bm::Bucket> buckets = bm::cut_buckets(genome, static_cast<int>(args.bucket_len), static_cast<int>(args.max_read_length));
+    std::vector<uint64_t> rec_off(genome.seqs.size() + 1, 0);
+    for (size_t r = 0; r < genome.seqs.size(); r++) rec_off[r + 1] = rec_off[r] + genome.seqs[r].size();
+    std::vector<uint8_t> flat(rec_off.back());
+    for (size_t r = 0; r < genome.seqs.size(); r++)
+        std::copy(genome.seqs[r].begin(), genome.seqs[r].end(), flat.begin() + static_cast<std::ptrdiff_t>(rec_off[r]));
+    std::vector<uint64_t> bstart(buckets.size());
+    std::vector<uint32_t> blen(buckets.size());
+    for (size_t b = 0; b < buckets.size(); b++) {
+        bstart[b] = rec_off[buckets[b].record] + buckets[b].start;
+        blen[b] = buckets[b].end - buckets[b].start;
+        ix.bucket_id.push_back(genome.ids[buckets[b].record]);
+    }
+    bmf_params p{};
+    p.num_buckets = num_buckets;
+    p.q = args.index_seed_length;
+    p.k = std::max<uint32_t>(args.query_seed_length, args.index_seed_length);
+    p.num_samples = 1;
+    p.num_fault = 1;
+    p.max_candidates = 1;
+    p.read_len = std::max<uint32_t>(args.max_read_length, p.k);
+    p.num_segment_samples = 5;
+    p.device = args.gpus.front();
+    bmf_ctx *c = nullptr;
+    if (bmf_create(&p, &c) != BMF_OK) throw std::runtime_error(std::string("--gpu-index: ") + bmf_last_error());
+    int rc = bmf_build_index(c, flat.data(), flat.size(), bstart.data(), blen.data(), static_cast<uint32_t>(buckets.size()),
+                             ix.kmer_to_index.data(), ix.kmer_to_index.size());
+    if (rc == BMF_OK) {
+        ix.rows.assign(static_cast<size_t>(ix.num_rows) * ix.row_bytes, 0);
+        rc = bmf_index_download(c, ix.rows.data(), nullptr);
+    }
+    const std::string why = rc == BMF_OK ? "" : bmf_last_error();
+    bmf_destroy(c);
+    if (rc != BMF_OK) throw std::runtime_error("--gpu-index: " + why);
+    return true;
 }
 
 std::unique_ptr<bm::offset_scanner> bm_make_scanner(const bm::cmd_arguments &args, int allowed_mismatch, int allowed_indel) {

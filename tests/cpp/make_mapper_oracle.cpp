@@ -4,6 +4,7 @@
 // so that (a) the host plumbing (FASTQ loop, windowing, scatter, result ordering, SAM) can be exercised
 // without a GPU and (b) the SAM file of the GPU build can be compared with the SAM file of an
 // oracle-backed build on the same inputs.  Never shipped: built only into tests/cpp/bucketmap_oracle.
+#include "../../bucket-map_amd/host/bm_indexer.h"
 #include "../../bucket-map_amd/host/bucket_locator.h"
 #include "../../bucket-map_amd/host/cli.h"
 #include "../../bucket-map_amd/host/gpu_q_gram_mapper.h"   // for bm::batched_mapper (host half of map())
@@ -84,6 +85,9 @@ public:
 std::unique_ptr<bm::mapper> bm_make_mapper(const bm::cmd_arguments &args, unsigned int num_buckets, unsigned int fault) {
     return std::make_unique<oracle_mapper>(args, num_buckets, fault);
 }
+
+// the oracle-backed tool always uses the host indexer
+bool bm_gpu_index(const bm::cmd_arguments &, const bm::Genome &, unsigned int, bm::QgramIndex &) { return false; }
 
 std::unique_ptr<bm::offset_scanner> bm_make_scanner(const bm::cmd_arguments &args, int allowed_mismatch, int allowed_indel) {
     return std::make_unique<oracle_scanner>(args.query_seed_length, static_cast<uint32_t>(args.locator_sample_size),

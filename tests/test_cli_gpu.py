@@ -60,6 +60,20 @@ def test_long_read_profile_sam_identical(tmp_path):
     assert len(names) > 0.5 * rd.n
 
 
+@pytest.mark.parametrize("frac", ["1", "0.25"])
+def test_gpu_index_writes_identical_files(tmp_path, frac):
+    # bucketmap -x --gpu-index must write byte-identical .qgram / .kmers_index / .bucket_id
+    from bucket_map_amd import host
+    g = host.Genome.synth(24, [500_000, 90_000])
+    g.write_fasta(str(tmp_path / "g.fa"))
+    common = ["--genome", "g.fa", "--bucket-len", "4096", "-r", "150", "-f", frac]
+    _run(GPU_CLI, ["-x", "-i", "host", *common], tmp_path)
+    err = _run(GPU_CLI, ["-x", "-i", "gpu", "--gpu-index", *common], tmp_path)
+    assert "stored in" in err
+    for ext in ("qgram", "kmers_index", "bucket_id"):
+        assert (tmp_path / f"gpu.{ext}").read_bytes() == (tmp_path / f"host.{ext}").read_bytes(), ext
+
+
 def test_cli_without_index_files_builds_them(tmp_path):
     # locator::initialize indexes first when the files are missing (locator.h:33-34)
     from bucket_map_amd import host
