@@ -728,6 +728,17 @@ int bmf_profile_end(bmf_ctx *c, uint32_t *n_runs, float *ms_sample, float *ms_vo
     return BMF_OK;
 }
 
+int bmf_pinned_alloc(size_t bytes, void **out) {
+    if (!out) return fail(BMF_ERR_ARG, "bmf_pinned_alloc: null argument");
+    *out = nullptr;
+    HIP_TRY(hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault));
+    return BMF_OK;
+}
+
+void bmf_pinned_free(void *p) {
+    if (p) (void)hipHostFree(p);
+}
+
 int bmf_info(bmf_ctx *c, uint32_t *row_pitch_bytes, uint32_t *chunks_per_lane, uint32_t *planes,
              uint32_t *rows_in_flight) {
     if (!c) return fail(BMF_ERR_ARG, "bmf_info: null context");

@@ -8,6 +8,9 @@
 
 #include <array>
 #include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string_view>
 #include <fstream>
 #include <functional>
 #include <stdexcept>
@@ -15,6 +18,16 @@
 #include <vector>
 
 namespace bm {
+
+// Size of the blocks the FASTA / FASTQ readers pull from the file (BM_IO_BLOCK overrides it: tests use
+// tiny blocks to put record boundaries everywhere).
+inline size_t io_block_bytes() {
+    if (const char *e = std::getenv("BM_IO_BLOCK")) {
+        const size_t v = std::strtoull(e, nullptr, 10);
+        if (v >= 16) return v;
+    }
+    return 32u << 20;
+}
 
 struct Genome {
     std::vector<std::string> ids;      // full FASTA header lines without '>'
@@ -38,36 +51,63 @@ inline char fold_genome_char(char c) {
 }
 
 inline Genome read_fasta(const std::string &path) {
-    std::ifstream in(path, std::ios::binary);
-    if (!in) throw std::runtime_error("cannot open FASTA file " + path);
+    // Block reader: 32 MiB pieces, lines found with memchr, each sequence line appended and folded in
+    // place through a 256-entry table (a 1.7 Gbp genome has 28 M lines: getline per line is the slow way).
+    FILE *f = std::fopen(path.c_str(), "rb");
+    if (!f) throw std::runtime_error("cannot open FASTA file " + path);
+    static const auto fold = [] {
+        std::array<char, 256> t{};
+        for (int c = 0; c < 256; c++) t[static_cast<size_t>(c)] = fold_genome_char(static_cast<char>(c));
+        return t;
+    }();
     Genome g;
-    std::string line;
-    while (std::getline(in, line)) {
-        if (!line.empty() && line.back() == '\r') line.pop_back();
-        if (line.empty()) continue;
+    std::vector<char> buf(io_block_bytes());
+    size_t have = 0;
+    bool eof = false;
+    auto take_line = [&](const char *line, size_t len) {
+        if (len && line[len - 1] == '\r') len--;
+        if (len == 0) return;
         if (line[0] == '>') {
-            g.ids.push_back(line.substr(1));
+            g.ids.emplace_back(line + 1, len - 1);
             g.seqs.emplace_back();
-        } else {
-            if (g.seqs.empty()) throw std::runtime_error("FASTA file " + path + " does not start with '>'");
-            // append the line, then fold it in place through a 256-entry table (white space inside a
-            // sequence line is rare: only then fall back to filtering character by character)
-            static const auto fold = [] {
-                std::array<char, 256> t{};
-                for (int c = 0; c < 256; c++) t[static_cast<size_t>(c)] = fold_genome_char(static_cast<char>(c));
-                return t;
-            }();
-            std::string &s = g.seqs.back();
-            const size_t at = s.size();
-            if (line.find_first_of(" \t") == std::string::npos) {
-                s.append(line);
-            } else {
-                for (char c : line)
-                    if (c != ' ' && c != '\t') s.push_back(c);
-            }
-            for (size_t i = at; i < s.size(); i++) s[i] = fold[static_cast<unsigned char>(s[i])];
+            return;
         }
+        if (g.seqs.empty()) {
+            std::fclose(f);
+            throw std::runtime_error("FASTA file " + path + " does not start with '>'");
+        }
+        std::string &s = g.seqs.back();
+        const size_t at = s.size();
+        if (!std::memchr(line, ' ', len) && !std::memchr(line, '\t', len)) {
+            s.append(line, len);
+        } else {   // white space inside a sequence line: rare, filter character by character
+            for (size_t i = 0; i < len; i++)
+                if (line[i] != ' ' && line[i] != '\t') s.push_back(line[i]);
+        }
+        for (size_t i = at; i < s.size(); i++) s[i] = fold[static_cast<unsigned char>(s[i])];
+    };
+    while (!eof) {
+        const size_t got = std::fread(buf.data() + have, 1, buf.size() - have, f);
+        have += got;
+        if (got == 0) eof = true;
+        size_t pos = 0;
+        while (pos < have) {
+            const char *nl = static_cast<const char *>(std::memchr(buf.data() + pos, '\n', have - pos));
+            if (!nl) {
+                if (eof) {
+                    take_line(buf.data() + pos, have - pos);
+                    pos = have;
+                }
+                break;
+            }
+            take_line(buf.data() + pos, static_cast<size_t>(nl - (buf.data() + pos)));
+            pos = static_cast<size_t>(nl - buf.data()) + 1;
+        }
+        std::memmove(buf.data(), buf.data() + pos, have - pos);
+        have -= pos;
+        if (have == buf.size()) buf.resize(buf.size() * 2);
     }
+    std::fclose(f);
     return g;
 }
 
@@ -84,32 +124,74 @@ inline void write_fasta(const Genome &g, const std::string &path, size_t width =
     }
 }
 
+// Views into the reader's block buffer: valid only during the callback.
 struct FastqRecord {
-    std::string id;      // header line without '@', untruncated
-    std::string seq;     // as in the file (ASCII); dna4 folding happens where it is hashed
-    std::string qual;    // phred+33
+    std::string_view id;      // header line without '@', untruncated
+    std::string_view seq;     // as in the file (ASCII); dna4 folding happens where it is hashed
+    std::string_view qual;    // phred+33
 };
 
-// Calls op for every record of a 4-line FASTQ file.
+// Calls op for every record of a 4-line FASTQ file.  Block reader: the file is read in 32 MiB pieces
+// and lines are found with memchr (the mapper, the locator's sampling pass and the SAM pass each walk
+// the whole FASTQ, as the reference does, so this loop is the host-side bottleneck of the tool).
 inline void for_each_fastq(const std::string &path, const std::function<void(const FastqRecord &)> &op) {
-    std::ifstream in(path, std::ios::binary);
-    if (!in) throw std::runtime_error("cannot open FASTQ file " + path);
-    FastqRecord rec;
-    std::string plus;
-    auto chomp = [](std::string &s) { if (!s.empty() && s.back() == '\r') s.pop_back(); };
-    while (std::getline(in, rec.id)) {
-        chomp(rec.id);
-        if (rec.id.empty()) continue;
-        if (rec.id[0] != '@') throw std::runtime_error("FASTQ record does not start with '@' in " + path);
-        rec.id.erase(0, 1);
-        if (!std::getline(in, rec.seq) || !std::getline(in, plus) || !std::getline(in, rec.qual))
-            throw std::runtime_error("truncated FASTQ record in " + path);
-        chomp(rec.seq);
-        chomp(rec.qual);
-        if (rec.seq.size() != rec.qual.size())
-            throw std::runtime_error("sequence and quality lengths differ in " + path);
-        op(rec);
+    FILE *f = std::fopen(path.c_str(), "rb");
+    if (!f) throw std::runtime_error("cannot open FASTQ file " + path);
+    std::vector<char> buf(io_block_bytes());
+    size_t have = 0;
+    bool eof = false;
+    auto fail = [&](const std::string &what) {
+        std::fclose(f);
+        throw std::runtime_error(what + " in " + path);
+    };
+    for (;;) {
+        if (!eof) {
+            const size_t got = std::fread(buf.data() + have, 1, buf.size() - have, f);
+            have += got;
+            if (got == 0) eof = true;
+        }
+        size_t pos = 0;
+        for (;;) {
+            // four lines; at end of file the last line may lack its '\n'
+            const char *line[4];
+            size_t len[4];
+            size_t p = pos;
+            int got_lines = 0;
+            while (got_lines < 4) {
+                if (p > have) break;
+                const char *nl = p < have ? static_cast<const char *>(std::memchr(buf.data() + p, '\n', have - p)) : nullptr;
+                size_t end;
+                if (nl) end = static_cast<size_t>(nl - buf.data());
+                else if (eof && p < have) end = have;
+                else break;
+                line[got_lines] = buf.data() + p;
+                len[got_lines] = end - p;
+                if (len[got_lines] && line[got_lines][len[got_lines] - 1] == '\r') len[got_lines]--;
+                got_lines++;
+                p = end + 1;
+                if (got_lines == 1 && len[0] == 0) {   // blank line between records: skip it
+                    pos = p;
+                    got_lines = 0;
+                }
+            }
+            if (got_lines < 4) {
+                if (eof && got_lines > 0) fail("truncated FASTQ record");
+                break;
+            }
+            if (line[0][0] != '@') fail("FASTQ record does not start with '@'");
+            if (len[1] != len[3]) fail("sequence and quality lengths differ");
+            FastqRecord rec{std::string_view(line[0] + 1, len[0] - 1), std::string_view(line[1], len[1]),
+                            std::string_view(line[3], len[3])};
+            op(rec);
+            pos = p > have ? have : p;
+        }
+        if (eof) break;
+        // keep the unfinished tail, grow the buffer if one record does not fit
+        std::memmove(buf.data(), buf.data() + pos, have - pos);
+        have -= pos;
+        if (have == buf.size()) buf.resize(buf.size() * 2);
     }
+    std::fclose(f);
 }
 
 // One kept bucket of iterate_through_buckets (utils.h:72-97).

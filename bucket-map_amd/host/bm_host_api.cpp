@@ -75,6 +75,25 @@ uint64_t bmh_select_qgrams(uint32_t q, float kmer_frac, uint64_t hash_seed, int3
     return ix.num_rows;
 }
 
+// Walks a FASTQ file with the tool's own reader: number of records, total bases and a checksum over
+// ids, sequences and qualities (for tests of the block reader).
+int bmh_fastq_stats(const char *path, uint64_t *n_records, uint64_t *n_bases, uint64_t *checksum) {
+    BMH_GUARD(1, {
+        uint64_t n = 0, b = 0, h = 1469598103934665603ull;
+        auto mix = [&](std::string_view v) {
+            for (unsigned char c : v) h = (h ^ c) * 1099511628211ull;
+            h = (h ^ 0xFFu) * 1099511628211ull;
+        };
+        bm::for_each_fastq(path, [&](const bm::FastqRecord &r) {
+            n++;
+            b += r.seq.size();
+            mix(r.id); mix(r.seq); mix(r.qual);
+        });
+        *n_records = n; *n_bases = b; *checksum = h;
+        return 0;
+    })
+}
+
 // BM_BUCKET_NUM as bucket_map/CMakeLists.txt:13-46 computes it
 uint32_t bmh_awk_bucket_num(const bmh_genome *g, uint32_t bucket_len) { return bm::awk_bucket_num(g->g, bucket_len); }
 

@@ -13,16 +13,23 @@
 #include "mapper.h"
 
 #include <chrono>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
 #include <iostream>
 #include <thread>
 
 namespace bm {
 
 // The host half of q_gram_mapper::map, independent of where query_sequence runs.
+//
+// Two batch slots: while the devices work on one batch, the next one is parsed from the FASTQ file into
+// the other (staging buffers come from host_alloc, pinned memory in the GPU mapper).  Results are
+// scattered strictly in batch order, so the per-bucket lists keep the reference's (read, window) order.
 class batched_mapper : public mapper {
 protected:
     unsigned int num_buckets_, read_length_, num_segment_samples_, max_candidates_;
-    size_t batch_reads_ = 1u << 20;
+    size_t batch_reads_ = 1u << 18;   // reads per batch: small enough to overlap parsing with the devices
 
     // query_sequence for n windows (views into bases/quals); counts: 2 per window, buckets:
     // 2 x max_candidates per window.  Returns false on failure (message already printed).
@@ -30,81 +37,146 @@ protected:
                                const uint64_t *win_start, const uint32_t *win_len, uint32_t n, uint32_t *counts,
                                uint32_t *buckets) = 0;
     virtual bool index_loaded() const = 0;
+    // staging memory for reads (overridden with pinned memory where a device copies from it)
+    virtual uint8_t *host_alloc(size_t bytes) { return static_cast<uint8_t *>(std::malloc(bytes ? bytes : 1)); }
+    virtual void host_free(uint8_t *p) { std::free(p); }
+
+private:
+    struct Slot {
+        uint8_t *bases = nullptr, *quals = nullptr;
+        size_t cap = 0, n_bytes = 0, n_reads = 0;
+        unsigned int first_read = 0;
+        std::vector<uint64_t> win_start;
+        std::vector<uint32_t> win_len, win_read, counts, buckets;
+        std::vector<int> win_pos;
+        bool ok = true;
+    };
+
+    void slot_reserve(Slot &s, size_t need) {
+        if (need <= s.cap) return;
+        // first allocation: room for a whole batch of reads of the nominal length (one page-locking call)
+        size_t cap = s.cap ? s.cap : std::max<size_t>(1u << 20, batch_reads_ * static_cast<size_t>(read_length_ + 8));
+        while (cap < need) cap *= 2;
+        uint8_t *b = host_alloc(cap), *q = host_alloc(cap);
+        if (!b || !q) throw std::runtime_error("out of host memory for the read staging buffers");
+        if (s.n_bytes) {
+            std::memcpy(b, s.bases, s.n_bytes);
+            std::memcpy(q, s.quals, s.n_bytes);
+        }
+        if (s.bases) host_free(s.bases);
+        if (s.quals) host_free(s.quals);
+        s.bases = b;
+        s.quals = q;
+        s.cap = cap;
+    }
 
 public:
     batched_mapper(unsigned int num_buckets, unsigned int read_len, unsigned int num_candidate_buckets,
                    unsigned int num_segment_samples)
         : num_buckets_(num_buckets), read_length_(read_len), num_segment_samples_(num_segment_samples),
-          max_candidates_(num_candidate_buckets) {}
+          max_candidates_(num_candidate_buckets) {
+        if (const char *e = std::getenv("BM_BATCH_READS")) batch_reads_ = std::max<size_t>(1, std::strtoull(e, nullptr, 10));
+    }
 
     // q_gram_mapper::map (q_gram_mapper.h:483-557)
     std::pair<segments_t, segments_t> map(std::filesystem::path const &sequence_file) override {
         unsigned int mapped_reads = 0, num_buckets_orig = 0, num_buckets_rev_comp = 0;
         segments_t res_orig(num_buckets_), res_rev_comp(num_buckets_);
-        const unsigned int first_record = num_records;
         auto t0 = std::chrono::steady_clock::now();
-
-        std::vector<uint8_t> bases, quals;
-        std::vector<uint64_t> win_start;
-        std::vector<uint32_t> win_len, win_read;
-        std::vector<int> win_pos;
-        std::vector<uint32_t> counts, buckets, starts(num_segment_samples_ ? num_segment_samples_ : 1);
+        Slot slots[2];
+        std::thread worker;
+        int cur = 0, in_flight = -1;
+        std::vector<uint32_t> starts(num_segment_samples_ ? num_segment_samples_ : 1);
         std::vector<uint8_t> read_mapped;
-        size_t reads_in_batch = 0;
 
-        auto flush = [&]() {
-            const uint32_t n = static_cast<uint32_t>(win_start.size());
+        // runs on the worker thread: query_sequence for every window of the slot
+        auto run = [&](Slot &s) {
+            const uint32_t n = static_cast<uint32_t>(s.win_start.size());
+            s.counts.assign(2 * static_cast<size_t>(n), 0);
+            s.buckets.assign(2 * static_cast<size_t>(n) * max_candidates_, 0);
+            s.ok = true;
             if (n == 0) return;
-            counts.assign(2 * static_cast<size_t>(n), 0);
-            buckets.assign(2 * static_cast<size_t>(n) * max_candidates_, 0);
             if (!index_loaded()) {
                 // q_gram_mapper.h:389-393 (printed once per query in the reference; once per batch here)
                 std::cerr << "[ERROR]\t\tThe q-gram index is empty. Cannot accept query.\n";
-            } else if (!query_windows(bases.data(), quals.data(), bases.size(), win_start.data(), win_len.data(), n,
-                                      counts.data(), buckets.data())) {
-                throw std::runtime_error("the candidate-bucket filter failed (see the [ERROR] line above)");
+            } else {
+                s.ok = query_windows(s.bases, s.quals, s.n_bytes, s.win_start.data(), s.win_len.data(), n, s.counts.data(),
+                                     s.buckets.data());
             }
-            read_mapped.assign(reads_in_batch, 0);
-            const unsigned int base_read = win_read.empty() ? 0 : win_read.front();
+        };
+        // q_gram_mapper.h:526-538: scatter (read, window start) into the per-bucket lists, in batch order
+        auto scatter = [&](Slot &s) {
+            if (!s.ok) throw std::runtime_error("the candidate-bucket filter failed (see the [ERROR] line above)");
+            const uint32_t n = static_cast<uint32_t>(s.win_start.size());
+            read_mapped.assign(s.n_reads, 0);
             for (uint32_t w = 0; w < n; w++) {
-                const segment_info_t seg{win_read[w], win_pos[w]};
-                const uint32_t cf = counts[2 * w], cr = counts[2 * w + 1];
-                const uint32_t *bf = buckets.data() + static_cast<size_t>(2 * w) * max_candidates_;
+                const segment_info_t seg{s.win_read[w], s.win_pos[w]};
+                const uint32_t cf = s.counts[2 * w], cr = s.counts[2 * w + 1];
+                const uint32_t *bf = s.buckets.data() + static_cast<size_t>(2 * w) * max_candidates_;
                 const uint32_t *br = bf + max_candidates_;
                 for (uint32_t i = 0; i < cf; i++) res_orig[bf[i]].push_back(seg);
                 for (uint32_t i = 0; i < cr; i++) res_rev_comp[br[i]].push_back(seg);
                 if (cf || cr) {
-                    read_mapped[win_read[w] - base_read] = 1;
+                    read_mapped[s.win_read[w] - s.first_read] = 1;
                     num_buckets_orig += cf;
                     num_buckets_rev_comp += cr;
                 }
             }
             for (uint8_t m : read_mapped) mapped_reads += m;
-            bases.clear(); quals.clear(); win_start.clear(); win_len.clear(); win_read.clear(); win_pos.clear();
-            reads_in_batch = 0;
+            s.win_start.clear(); s.win_len.clear(); s.win_read.clear(); s.win_pos.clear();
+            s.n_bytes = 0;
+            s.n_reads = 0;
+        };
+        auto finish_in_flight = [&]() {
+            if (in_flight < 0) return;
+            worker.join();
+            scatter(slots[in_flight]);
+            in_flight = -1;
+        };
+        auto submit = [&]() {   // hand the filled slot to the devices, continue parsing into the other one
+            finish_in_flight();
+            in_flight = cur;
+            worker = std::thread(run, std::ref(slots[cur]));
+            cur ^= 1;
         };
 
-        for_each_fastq(sequence_file.string(), [&](const FastqRecord &rec) {
-            const uint64_t off = bases.size();
-            const uint32_t len = static_cast<uint32_t>(rec.seq.size());
-            bases.insert(bases.end(), rec.seq.begin(), rec.seq.end());
-            quals.insert(quals.end(), rec.qual.begin(), rec.qual.end());
-            // q_gram_mapper.h:510-523: window starts {0}, or Sampler(5) for reads longer than 2*read_len
-            const uint32_t nw = bmf_window_starts(len, read_length_, num_segment_samples_, starts.data());
-            for (uint32_t i = 0; i < nw; i++) {
-                const uint32_t s = starts[i];
-                win_start.push_back(off + s);
-                win_len.push_back(std::min(s + read_length_, len) - s);
-                win_read.push_back(num_records);
-                win_pos.push_back(static_cast<int>(s));
+        try {
+            for_each_fastq(sequence_file.string(), [&](const FastqRecord &rec) {
+                Slot &s = slots[cur];
+                if (s.n_reads == 0) s.first_read = num_records;
+                const uint32_t len = static_cast<uint32_t>(rec.seq.size());
+                slot_reserve(s, s.n_bytes + len);
+                std::memcpy(s.bases + s.n_bytes, rec.seq.data(), len);
+                std::memcpy(s.quals + s.n_bytes, rec.qual.data(), len);
+                // q_gram_mapper.h:510-523: window starts {0}, or Sampler(5) for reads longer than 2*read_len
+                const uint32_t nw = bmf_window_starts(len, read_length_, num_segment_samples_, starts.data());
+                for (uint32_t i = 0; i < nw; i++) {
+                    const uint32_t st = starts[i];
+                    s.win_start.push_back(s.n_bytes + st);
+                    s.win_len.push_back(std::min(st + read_length_, len) - st);
+                    s.win_read.push_back(num_records);
+                    s.win_pos.push_back(static_cast<int>(st));
+                }
+                s.n_bytes += len;
+                ++num_records;
+                if (++s.n_reads >= batch_reads_) submit();
+            });
+            if (slots[cur].n_reads) submit();
+            finish_in_flight();
+        } catch (...) {
+            if (worker.joinable()) worker.join();
+            for (Slot &s : slots) {
+                if (s.bases) host_free(s.bases);
+                if (s.quals) host_free(s.quals);
             }
-            ++num_records;
-            if (++reads_in_batch >= batch_reads_) flush();
-        });
-        flush();
+            throw;
+        }
+        for (Slot &s : slots) {
+            if (s.bases) host_free(s.bases);
+            if (s.quals) host_free(s.quals);
+        }
 
         const float time = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count() / 1000.0f;
-        const unsigned int n_rec = num_records - first_record;
         // q_gram_mapper.h:548-555 (the reference divides by the running num_records)
         std::cerr << "[BENCHMARK]\tElapsed time for bucket mapping: " << time << " s (" << time * 1000 * 1000 / num_records
                   << " μs/seq).\n";
@@ -114,7 +186,6 @@ public:
                   << static_cast<float>(num_buckets_orig) / mapped_reads << ".\n";
         std::cerr << "[BENCHMARK]\tAverage number of buckets a reverse complement of the read is mapped to: "
                   << static_cast<float>(num_buckets_rev_comp) / mapped_reads << ".\n";
-        (void)n_rec;
         return std::make_pair(std::move(res_orig), std::move(res_rev_comp));
     }
 };
@@ -125,6 +196,12 @@ class gpu_q_gram_mapper : public batched_mapper {
 
 protected:
     bool index_loaded() const override { return loaded_; }
+    // pinned staging: the H2D copies of bmf_map_windows then run at link speed
+    uint8_t *host_alloc(size_t bytes) override {
+        void *p = nullptr;
+        return bmf_pinned_alloc(bytes, &p) == BMF_OK ? static_cast<uint8_t *>(p) : nullptr;
+    }
+    void host_free(uint8_t *p) override { bmf_pinned_free(p); }
 
     bool query_windows(const uint8_t *bases, const uint8_t *quals, uint64_t n_bytes, const uint64_t *win_start,
                        const uint32_t *win_len, uint32_t n, uint32_t *counts, uint32_t *buckets) override {

@@ -67,6 +67,8 @@ SYMBOLS = {
     "bmf_sync": (C.c_int, [C.c_void_p]),
     "bmf_profile_begin": (C.c_int, [C.c_void_p, C.c_uint32]),
     "bmf_profile_end": (C.c_int, [C.c_void_p, _u32p, _f32p, _f32p]),
+    "bmf_pinned_alloc": (C.c_int, [C.c_size_t, C.POINTER(C.c_void_p)]),
+    "bmf_pinned_free": (None, [C.c_void_p]),
     "bmf_info": (C.c_int, [C.c_void_p, _u32p, _u32p, _u32p, _u32p]),
 }
 

@@ -34,6 +34,7 @@ def lib() -> C.CDLL:
             "bmh_genome_total": (u64, [vp]),
             "bmh_genome_flatten": (None, [vp, vp, vp]),
             "bmh_select_qgrams": (u64, [u32, C.c_float, u64, vp]),
+            "bmh_fastq_stats": (C.c_int, [C.c_char_p, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64)]),
             "bmh_awk_bucket_num": (u32, [vp, u32]),
             "bmh_cut_buckets": (u32, [vp, u32, u32, C.POINTER(u32)]),
             "bmh_index_build": (vp, [vp, u32, u32, u32, u32, C.c_float, u64, u32]),
@@ -79,6 +80,14 @@ def select_qgrams(q: int, kmer_frac: float = 1.0, hash_seed: int = 20240004) -> 
     out = np.zeros(4 ** q, dtype=np.int32)
     lib().bmh_select_qgrams(q, kmer_frac, hash_seed, out.ctypes.data)
     return out
+
+
+def fastq_stats(path: str):
+    """(records, bases, checksum over ids/sequences/qualities) as the tool's FASTQ reader sees the file."""
+    n, b, h = C.c_uint64(), C.c_uint64(), C.c_uint64()
+    if lib().bmh_fastq_stats(os.fsencode(path), C.byref(n), C.byref(b), C.byref(h)):
+        raise RuntimeError(_err())
+    return n.value, b.value, h.value
 
 
 class Genome:

@@ -146,6 +146,11 @@ int  bmf_sync(bmf_ctx *ctx);
 int  bmf_profile_begin(bmf_ctx *ctx, uint32_t max_runs);
 int  bmf_profile_end(bmf_ctx *ctx, uint32_t *n_runs, float *ms_sample, float *ms_vote);
 
+/* Page-locked host memory for read staging buffers (hipHostMalloc): copies from it to the device run at
+ * link speed.  Optional: every entry point accepts ordinary memory too. */
+int  bmf_pinned_alloc(size_t bytes, void **out);
+void bmf_pinned_free(void *p);
+
 /* Introspection for DESIGN.md / bench: bytes per padded row in HBM, kernel variant chosen. */
 int  bmf_info(bmf_ctx *ctx, uint32_t *row_pitch_bytes, uint32_t *chunks_per_lane, uint32_t *planes,
               uint32_t *rows_in_flight);

@@ -18,8 +18,9 @@ GPU_CLI = os.path.join(ROOT, "bucket-map_amd", "bucketmap")
 ORACLE_CLI = os.path.join(ROOT, "tests", "cpp", "bucketmap_oracle")
 
 
-def _run(exe, args, cwd):
-    r = subprocess.run([exe, *args], cwd=str(cwd), capture_output=True, text=True)
+def _run(exe, args, cwd, env=None):
+    r = subprocess.run([exe, *args], cwd=str(cwd), capture_output=True, text=True,
+                       env=None if env is None else {**os.environ, **env})
     assert r.returncode == 0, r.stderr
     return r.stderr
 
@@ -39,6 +40,21 @@ def test_sam_identical_to_oracle_backed_run(tmp_path, gpus, long_reads):
     gpu_sam, cpu_sam = (tmp_path / "gpu.sam").read_bytes(), (tmp_path / "cpu.sam").read_bytes()
     assert gpu_sam == cpu_sam
     assert gpu_sam.count(b"\n") > 0.9 * rd.n
+
+
+def test_many_small_batches_keep_the_order(tmp_path):
+    # 3000 reads in batches of 257: the two-slot pipeline (parse batch i+1 while the devices work on batch i)
+    # must scatter results in batch order -- the SAM file is order sensitive through the locator
+    from bucket_map_amd import host
+    g = host.Genome.synth(25, [350_000])
+    g.write_fasta(str(tmp_path / "g.fa"))
+    host.Reads(g, 8192, 150, 150, 3000, sub=0.01, seed=11).write_fastq(str(tmp_path / "reads"))
+    common = ["-i", "idx", "--genome", "g.fa", "--bucket-len", "8192", "-r", "150", "-f", "1", "-q", "reads.fastq"]
+    _run(GPU_CLI, [*common, "-o", "small.sam", "--gpus", "0,0"], tmp_path, env={"BM_BATCH_READS": "257"})
+    _run(GPU_CLI, [*common, "-o", "one.sam"], tmp_path)
+    _run(ORACLE_CLI, [*common, "-o", "cpu.sam"], tmp_path, env={"BM_BATCH_READS": "1000"})
+    ref = (tmp_path / "cpu.sam").read_bytes()
+    assert (tmp_path / "small.sam").read_bytes() == ref and (tmp_path / "one.sam").read_bytes() == ref
 
 
 def test_long_read_profile_sam_identical(tmp_path):

@@ -193,3 +193,30 @@ def test_cli_error_behaviour(cli_case):
     assert r.returncode == 255 and "BM_BUCKET_NUM" in r.stderr                            # no genome configured
     r = run_cli(exe, ["-i", "idx", "--genome", "g.fa", "--bogus", "1"], d)
     assert r.returncode == 255
+
+
+# ------------------------------------------------------------------ block readers
+
+def test_block_readers_survive_any_block_size(tmp_path, monkeypatch):
+    # the FASTA / FASTQ readers pull fixed-size blocks; with tiny blocks every record straddles a boundary
+    g = host.Genome.synth(12, [3000, 1, 777])
+    g.write_fasta(str(tmp_path / "g.fa"))
+    rd = host.Reads(g, 512, 60, 60, 40, seed=3)
+    rd.write_fastq(str(tmp_path / "r"))
+    ref = host.fastq_stats(str(tmp_path / "r.fastq"))
+    assert ref[0] == 40 and ref[1] == int(rd.offsets[-1])
+    for block in (16, 61, 64, 257, 4096):
+        monkeypatch.setenv("BM_IO_BLOCK", str(block))
+        assert host.fastq_stats(str(tmp_path / "r.fastq")) == ref
+        h = host.Genome.read_fasta(str(tmp_path / "g.fa"))
+        assert [bytes(h.record_seq(i)) for i in range(3)] == [bytes(g.record_seq(i)) for i in range(3)]
+    monkeypatch.delenv("BM_IO_BLOCK")
+    # CRLF line ends, blank lines between records, no newline at the end of the file
+    text = open(tmp_path / "r.fastq").read().rstrip("\n")
+    recs = text.split("\n")
+    crlf = "\r\n".join(recs[:8]) + "\r\n\r\n" + "\n".join(recs[8:])
+    (tmp_path / "weird.fastq").write_text(crlf)
+    assert host.fastq_stats(str(tmp_path / "weird.fastq")) == ref
+    (tmp_path / "cut.fastq").write_text("\n".join(recs[:-1]))
+    with pytest.raises(RuntimeError):
+        host.fastq_stats(str(tmp_path / "cut.fastq"))
