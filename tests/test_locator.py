@@ -159,6 +159,25 @@ def test_gpu_scan_equals_oracle(name, kw):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(int(os.environ.get("BM_SWEEP_SEEDS", "12"))))   # soak: BM_SWEEP_SEEDS=500
+def test_gpu_scan_random_sweep(seed):
+    rng = np.random.default_rng(7000 + seed)
+    k = int(rng.integers(6, 17))
+    p = int(rng.choice([1, 2, 5, 10, 20, 33, 64]))
+    read_len = int(rng.choice([max(k + 3, 40), 100, 150]))
+    kw = dict(n_buckets=int(rng.integers(1, 9)), bucket_len=int(rng.choice([512, 2048, 8192])), read_len=read_len,
+              n_reads=int(rng.integers(20, 200)), k=k, p=p, sub=float(rng.choice([0.0, 0.01, 0.05])),
+              motif=(None if rng.random() < 0.5 else int(rng.integers(5, 200))), qual_b=int(rng.choice([0, 25, 40])))
+    case = make_case(rng, **kw)
+    mismatch = int(rng.integers(0, p + 2))
+    indel = int(rng.choice([0, 1, 6, 30]))
+    o_ref, v_ref = oracle(case, mismatch, indel)
+    o_got, v_got, _ = gpu_scan(case, mismatch, indel)
+    bad = np.nonzero((o_ref != o_got) | (v_ref != v_got))[0]
+    assert bad.size == 0, f"{kw} mismatch={mismatch} indel={indel}: {bad.size} differ, first {bad[:5]}"
+
+
+@pytest.mark.gpu
 def test_gpu_scan_hand_traced():
     from bucket_map_amd import locate
     genome = np.frombuffer(b"ACGT" * 8, np.uint8)

@@ -2,6 +2,8 @@
 max_candidates, kmer_frac, NB) combinations, GPU vs oracle, bit-exact.  Covers the corners of the kernel
 variant table the fixed geometries do not: PLANES 2..5 (F = 1..31), G = 1..8, S = 1..64, windows with
 fewer good k-mers than samples (repeated sample positions), thresholds that reject k-mers."""
+import os
+
 import numpy as np
 import pytest
 
@@ -40,7 +42,7 @@ def random_case(rng, *, nb, q, k, S, F, max_cand, kmer_frac, density, read_len, 
     return c_ref, b_ref, c_got, b_got, c_e, b_e
 
 
-@pytest.mark.parametrize("seed", range(24))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("BM_SWEEP_SEEDS", "24"))))   # soak: BM_SWEEP_SEEDS=2000
 def test_random_parameters(seed):
     rng = np.random.default_rng(1000 + seed)
     q = int(rng.integers(2, 7))
