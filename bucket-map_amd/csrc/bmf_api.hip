@@ -59,38 +59,38 @@ using vote_fn = void (*)(bmf::DevParams, const uint8_t *, const uint32_t *, cons
 constexpr int depth_for(int cpl) { return cpl <= 2 ? 8 : (cpl <= 4 ? 4 : (cpl <= 6 ? 3 : 2)); }
 
 template <int CPL>
-vote_fn pick_planes(int planes) {
+vote_fn pick_planes(int planes, bool prune) {
     constexpr int D = depth_for(CPL);
     switch (planes) {
-    case 2: return bmf::bmf_vote_kernel<CPL, 2, D, false>;
-    case 3: return bmf::bmf_vote_kernel<CPL, 3, D, false>;
-    case 4: return bmf::bmf_vote_kernel<CPL, 4, D, false>;
-    case 5: return bmf::bmf_vote_kernel<CPL, 5, D, false>;
+    case 2: return prune ? bmf::bmf_vote_kernel<CPL, 2, D, false, true> : bmf::bmf_vote_kernel<CPL, 2, D, false, false>;
+    case 3: return prune ? bmf::bmf_vote_kernel<CPL, 3, D, false, true> : bmf::bmf_vote_kernel<CPL, 3, D, false, false>;
+    case 4: return prune ? bmf::bmf_vote_kernel<CPL, 4, D, false, true> : bmf::bmf_vote_kernel<CPL, 4, D, false, false>;
+    case 5: return prune ? bmf::bmf_vote_kernel<CPL, 5, D, false, true> : bmf::bmf_vote_kernel<CPL, 5, D, false, false>;
     }
     return nullptr;
 }
 
 // NB > 65 536: every wave takes one slice of 8 chunks per lane
-vote_fn pick_sliced(int planes) {
+vote_fn pick_sliced(int planes, bool prune) {
     switch (planes) {
-    case 2: return bmf::bmf_vote_kernel<8, 2, 2, true>;
-    case 3: return bmf::bmf_vote_kernel<8, 3, 2, true>;
-    case 4: return bmf::bmf_vote_kernel<8, 4, 2, true>;
-    case 5: return bmf::bmf_vote_kernel<8, 5, 2, true>;
+    case 2: return prune ? bmf::bmf_vote_kernel<8, 2, 2, true, true> : bmf::bmf_vote_kernel<8, 2, 2, true, false>;
+    case 3: return prune ? bmf::bmf_vote_kernel<8, 3, 2, true, true> : bmf::bmf_vote_kernel<8, 3, 2, true, false>;
+    case 4: return prune ? bmf::bmf_vote_kernel<8, 4, 2, true, true> : bmf::bmf_vote_kernel<8, 4, 2, true, false>;
+    case 5: return prune ? bmf::bmf_vote_kernel<8, 5, 2, true, true> : bmf::bmf_vote_kernel<8, 5, 2, true, false>;
     }
     return nullptr;
 }
 
-vote_fn pick_vote(int cpl, int planes) {
+vote_fn pick_vote(int cpl, int planes, bool prune) {
     switch (cpl) {
-    case 1: return pick_planes<1>(planes);
-    case 2: return pick_planes<2>(planes);
-    case 3: return pick_planes<3>(planes);
-    case 4: return pick_planes<4>(planes);
-    case 5: return pick_planes<5>(planes);
-    case 6: return pick_planes<6>(planes);
-    case 7: return pick_planes<7>(planes);
-    case 8: return pick_planes<8>(planes);
+    case 1: return pick_planes<1>(planes, prune);
+    case 2: return pick_planes<2>(planes, prune);
+    case 3: return pick_planes<3>(planes, prune);
+    case 4: return pick_planes<4>(planes, prune);
+    case 5: return pick_planes<5>(planes, prune);
+    case 6: return pick_planes<6>(planes, prune);
+    case 7: return pick_planes<7>(planes, prune);
+    case 8: return pick_planes<8>(planes, prune);
     }
     return nullptr;
 }
@@ -227,7 +227,8 @@ int bmf_create(const bmf_params *params, bmf_ctx **out) {
     c->planes = planes;
     c->n_slices = n_slices;
     c->depth = n_slices > 1 ? 2 : depth_for(cpl);
-    c->vote = n_slices > 1 ? pick_sliced(planes) : pick_vote(cpl, planes);
+    const bool prune = (p.flags & BMF_FLAG_EARLY_EXIT) != 0;
+    c->vote = n_slices > 1 ? pick_sliced(planes, prune) : pick_vote(cpl, planes, prune);
     if (!c->vote) {
         delete c;
         return fail(BMF_ERR_UNSUPPORTED, "no vote kernel for cpl=%d planes=%d", cpl, planes);

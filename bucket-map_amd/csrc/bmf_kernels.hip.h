@@ -39,7 +39,7 @@ struct DevParams {
     uint32_t pitch;      // bytes between rows in HBM (multiple of 128)
     uint32_t ones_row;   // id of the all-ones row appended after the index (for un-indexed q-grams)
     uint32_t n_kmers;    // entries of kmer_to_index (4^q, or 0 when no .kmers_index was loaded)
-    uint32_t early_exit; // 1 = stop streaming rows once no bucket can have < F misses (BMF_FLAG_EARLY_EXIT)
+    uint32_t early_exit; // BMF_FLAG_EARLY_EXIT: the PRUNE kernel variant is in use (informational)
 };
 
 __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
@@ -356,7 +356,13 @@ __device__ __forceinline__ void emit_best(const DevParams &P, const u128 (&cnt)[
 // plus DEPTH (a row of ones ANDs as the identity and, landing on a sample boundary, adds no miss), and
 // lanes past the end of the row re-read the row's last chunk, so every load is unconditional and the
 // compiler can wait for exactly the oldest row in flight (counted vmcnt) instead of draining the ring.
-template <int CPL, int PLANES, int DEPTH, bool SLICED>
+//
+// PRUNE (BMF_FLAG_EARLY_EXIT): identical outputs from fewer row bytes.  After F samples, a bucket with
+// >= F misses can no longer be in the result (its counter only grows), so (a) when every bucket is dead
+// the wave stops, and (b) a lane whose 128-bit chunk holds no live bucket stops loading that chunk --
+// typically one lane keeps loading for the true strand, none for the other.  Loads become predicated
+// per lane; dead lanes AND stale data into counters that are already >= F, which changes nothing.
+template <int CPL, int PLANES, int DEPTH, bool SLICED, bool PRUNE>
 __global__ __launch_bounds__(kWave) void bmf_vote_kernel(DevParams P, const uint8_t *__restrict__ rows,
                                                         const uint32_t *__restrict__ row_lists,
                                                         const uint32_t *__restrict__ list_n,
@@ -384,12 +390,25 @@ __global__ __launch_bounds__(kWave) void bmf_vote_kernel(DevParams P, const uint
         coff[j] = (c < P.n_chunks ? c : P.n_chunks - 1u) * 16u;
     }
 
+    bool act[CPL];            // PRUNE: this lane still loads chunk j
+#pragma unroll
+    for (int j = 0; j < CPL; j++) act[j] = chunk0 + lane + kWave * j < P.n_chunks;
+
     u128 ring[DEPTH][CPL];
+    if (PRUNE) {
+#pragma unroll
+        for (int d = 0; d < DEPTH; d++)
+#pragma unroll
+            for (int j = 0; j < CPL; j++)
+#pragma unroll
+                for (int x = 0; x < 4; x++) ring[d][j].v[x] = 0;
+    }
 #pragma unroll
     for (int d = 0; d < DEPTH; d++) {
         const uint8_t *rp = rows + (size_t)list[d] * P.pitch;
 #pragma unroll
-        for (int j = 0; j < CPL; j++) ring[d][j] = load_chunk(rp + coff[j]);
+        for (int j = 0; j < CPL; j++)
+            if (!PRUNE || act[j]) ring[d][j] = load_chunk(rp + coff[j]);
     }
 
     u128 bf[CPL];             // AND of the current sample's rows (q_gram_mapper.h:400-406)
@@ -416,19 +435,24 @@ __global__ __launch_bounds__(kWave) void bmf_vote_kernel(DevParams P, const uint
             // refill this ring slot with the row DEPTH positions ahead (list is padded: always valid)
             const uint8_t *rp = rows + (size_t)list[i + d + DEPTH] * P.pitch;
 #pragma unroll
-            for (int j = 0; j < CPL; j++) ring[d][j] = load_chunk(rp + coff[j]);
+            for (int j = 0; j < CPL; j++)
+                if (!PRUNE || act[j]) ring[d][j] = load_chunk(rp + coff[j]);
             if (++g == P.G) {
                 g = 0;
                 count_misses<CPL, PLANES>(bf, cnt);
                 ++samples_done;
-                // Optional early exit (same result, fewer row reads): once every bucket has >= F misses
-                // the reference's filter is empty at every level whatever the remaining samples are.
-                if (P.early_exit && samples_done >= P.F && samples_done < P.S) {
+                // Once every bucket has >= F misses the reference's filter is empty at every level whatever
+                // the remaining samples are; chunks without a live bucket need not be read any more.
+                if (PRUNE && samples_done >= P.F && samples_done < P.S) {
                     uint32_t alive = 0;
 #pragma unroll
-                    for (int j2 = 0; j2 < CPL; j2++)
+                    for (int j2 = 0; j2 < CPL; j2++) {
+                        uint32_t a = 0;
 #pragma unroll
-                        for (int x = 0; x < 4; x++) alive |= ~count_ge<CPL, PLANES>(cnt, j2, x, P.F);
+                        for (int x = 0; x < 4; x++) a |= ~count_ge<CPL, PLANES>(cnt, j2, x, P.F);
+                        act[j2] = a != 0;
+                        alive |= a;
+                    }
                     if (__ballot(alive != 0) == 0) {
                         if (lane == 0) {
                             out_counts[item] = 0;
