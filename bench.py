@@ -241,7 +241,8 @@ def main():
         maskp = np.arange(bkp.shape[-1])[None, None, :] < counts[:, :, None]
         same = same and bool(np.array_equal(bkp[maskp], buckets[maskp]))
         pruned = {"value": world * reads.n * args.steps / pruned_s, "unit": "reads/s", "ms_per_step": pruned_s / args.steps * 1e3,
-                  "outputs_identical_to_headline_run": same, "flag": "BMF_FLAG_EARLY_EXIT"}
+                  "outputs_identical_to_headline_run": same, "flag": "BMF_FLAG_EARLY_EXIT",
+                  "pass1_rows": fp.info()["pass1_rows"]}
         bp.close()
         fp.close()
 

@@ -4,6 +4,7 @@
 // (rows at a 128-byte pitch + one all-ones row), the fp64 sampler table (utils.h:160-178), launches
 // and HIP-event timing.  There is deliberately no CPU implementation of the filter in this library.
 #include "bmf_kernels.hip.h"
+#include "bmf_vote2.hip.h"
 #include "bmi_kernels.hip.h"
 
 #include <hipcub/hipcub.hpp>
@@ -93,6 +94,46 @@ vote_fn pick_vote(int cpl, int planes, bool prune) {
     case 8: return pick_planes<8>(planes, prune);
     }
     return nullptr;
+}
+
+// two-pass exact pruning (bmf_vote2.hip.h), unsliced geometries only
+template <int CPL>
+vote_fn pick_planes2(int planes) {
+    constexpr int D = depth_for(CPL);
+    switch (planes) {
+    case 2: return bmf::bmf_vote2_kernel<CPL, 2, D>;
+    case 3: return bmf::bmf_vote2_kernel<CPL, 3, D>;
+    case 4: return bmf::bmf_vote2_kernel<CPL, 4, D>;
+    case 5: return bmf::bmf_vote2_kernel<CPL, 5, D>;
+    }
+    return nullptr;
+}
+
+vote_fn pick_vote2(int cpl, int planes) {
+    switch (cpl) {
+    case 1: return pick_planes2<1>(planes);
+    case 2: return pick_planes2<2>(planes);
+    case 3: return pick_planes2<3>(planes);
+    case 4: return pick_planes2<4>(planes);
+    case 5: return pick_planes2<5>(planes);
+    case 6: return pick_planes2<6>(planes);
+    case 7: return pick_planes2<7>(planes);
+    case 8: return pick_planes2<8>(planes);
+    }
+    return nullptr;
+}
+
+// P[Bin(n, p) >= m]
+double binom_tail(uint32_t n, double p, uint32_t m) {
+    if (m == 0) return 1.0;
+    if (m > n) return 0.0;
+    double tail = 0.0;
+    for (uint32_t i = m; i <= n; i++) {
+        double c = 1.0;
+        for (uint32_t j = 0; j < i; j++) c = c * (double)(n - j) / (double)(j + 1);
+        tail += c * pow(p, (double)i) * pow(1.0 - p, (double)(n - i));
+    }
+    return tail;
 }
 
 }  // namespace
@@ -310,6 +351,51 @@ static void free_index(bmf_ctx *c) {
     c->loaded = false;
 }
 
+// BMF_FLAG_EARLY_EXIT: which exact-pruning kernel serves this index.  The two-pass kernel streams r rows
+// per sample at full width, then recounts the chunks that survive; a bucket unrelated to the read survives
+// a sample with probability about d^r (d = density of the rows a read meets, weighted by density because a
+// q-gram is met in proportion to how often it occurs), so the expected number of survivors is
+// NB * P[Bin(S, d^r) >= S-F+1].  Costs are in row bytes; the single-pass PRUNE kernel reads F*G whole rows
+// before it can narrow.  BMF_PASS1_ROWS=r forces r (0: never two-pass) for experiments.
+static int select_pruned_variant(bmf_ctx *c) {
+    const bmf::DevParams &d = c->dp;
+    c->dp.pass1_rows = 0;
+    if (!(c->p.flags & BMF_FLAG_EARLY_EXIT) || c->n_slices > 1) return BMF_OK;
+    c->vote = pick_vote(c->cpl, c->planes, true);
+    if (d.G < 2 || c->n_rows == 0) return BMF_OK;
+    std::vector<uint32_t> zeros((size_t)c->n_rows);
+    HIP_TRY(hipMemcpy(zeros.data(), c->d_zeros, zeros.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    double s1 = 0.0, s2 = 0.0;
+    for (uint32_t z : zeros) {
+        const double di = 1.0 - (double)z / (double)d.nb;
+        s1 += di;
+        s2 += di * di;
+    }
+    const double dens = s1 > 0.0 ? s2 / s1 : 0.0;
+    const double row_bytes = (double)d.n_chunks * 16.0, sector = 64.0;
+    const double prune_cost = (double)d.F * d.G * row_bytes;
+    uint32_t best_r = 0;
+    double best = 0.95 * prune_cost;
+    for (uint32_t r = 1; r < d.G; r++) {
+        const double live = (double)d.nb * binom_tail(d.S, pow(dens, (double)r), d.S - d.F + 1u);
+        if (live > 24.0) continue;   // beyond one lane per live chunk the recount falls back to whole rows
+        const double cost = (double)d.S * r * row_bytes + live * d.S * (r + 1.0) * sector + (double)d.S * d.G * sector;
+        if (cost < best) {
+            best = cost;
+            best_r = r;
+        }
+    }
+    if (const char *env = getenv("BMF_PASS1_ROWS")) {
+        const long v = strtol(env, nullptr, 10);
+        best_r = v > 0 && (uint32_t)v < d.G ? (uint32_t)v : 0u;
+    }
+    if (best_r) {
+        c->dp.pass1_rows = best_r;
+        c->vote = pick_vote2(c->cpl, c->planes);
+    }
+    return BMF_OK;
+}
+
 void bmf_destroy(bmf_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->p.device);
@@ -366,7 +452,7 @@ int bmf_load_index(bmf_ctx *c, const uint8_t *rows, uint64_t n_rows, const int32
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->loaded = true;
-    return BMF_OK;
+    return select_pruned_variant(c);
 }
 
 // GPU form of bucket_indexer::index (bucket_indexer.h:49-61,170-216): see bmi_kernels.hip.h.
@@ -453,7 +539,7 @@ int bmf_build_index(bmf_ctx *c, const uint8_t *genome, uint64_t n_bases, const u
         return fail(BMF_ERR_HIP, "bmf_build_index: %s", hipGetErrorString(e));
     }
     c->loaded = true;
-    return BMF_OK;
+    return select_pruned_variant(c);
 }
 
 int bmf_index_download(bmf_ctx *c, uint8_t *rows_out, uint64_t *n_rows_out) {
@@ -747,6 +833,12 @@ int bmf_info(bmf_ctx *c, uint32_t *row_pitch_bytes, uint32_t *chunks_per_lane, u
     if (chunks_per_lane) *chunks_per_lane = (uint32_t)c->cpl;
     if (planes) *planes = (uint32_t)c->planes;
     if (rows_in_flight) *rows_in_flight = (uint32_t)c->depth;
+    return BMF_OK;
+}
+
+int bmf_pass1_rows(bmf_ctx *c, uint32_t *out) {
+    if (!c || !out) return fail(BMF_ERR_ARG, "bmf_pass1_rows: null argument");
+    *out = c->dp.pass1_rows;
     return BMF_OK;
 }
 

@@ -39,7 +39,8 @@ struct DevParams {
     uint32_t pitch;      // bytes between rows in HBM (multiple of 128)
     uint32_t ones_row;   // id of the all-ones row appended after the index (for un-indexed q-grams)
     uint32_t n_kmers;    // entries of kmer_to_index (4^q, or 0 when no .kmers_index was loaded)
-    uint32_t early_exit; // BMF_FLAG_EARLY_EXIT: the PRUNE kernel variant is in use (informational)
+    uint32_t early_exit; // BMF_FLAG_EARLY_EXIT: a pruning kernel variant is in use (informational)
+    uint32_t pass1_rows; // two-pass variant: q-gram rows of each sample read at full width in pass 1 (1..G)
 };
 
 __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
@@ -278,9 +279,12 @@ __device__ __forceinline__ uint32_t count_ge(const u128 (&cnt)[PLANES][CPL], int
 // SLICED (NB > 65 536): the wave only holds one 65 536-bucket slice of the row.  It then reports its LOCAL
 // minimum, and the ids at that minimum (or "more than max_candidates"), to per-(item, slice) slots;
 // bmf_merge_slices_kernel takes the minimum over the slices and concatenates the slices that reach it.
+//
+// cidx[j] = index of the 128-bucket chunk this lane holds in slot j; lanes (and slots) must be in
+// ascending chunk order for the emitted ids to come out ascending.
 template <int CPL, int PLANES, bool SLICED>
 __device__ __forceinline__ void emit_best(const DevParams &P, const u128 (&cnt)[PLANES][CPL], uint32_t item,
-                                          uint32_t lane, uint32_t chunk0, uint32_t *__restrict__ out_counts,
+                                          uint32_t lane, const uint32_t (&cidx)[CPL], uint32_t *__restrict__ out_counts,
                                           uint32_t *__restrict__ out_buckets, uint32_t *__restrict__ out_min) {
     u128 cand[CPL];
 #pragma unroll
@@ -340,7 +344,7 @@ __device__ __forceinline__ void emit_best(const DevParams &P, const u128 (&cnt)[
         for (int x = 0; x < 4; x++) {
             uint32_t bits = cand[j].v[x];
             while (bits) {
-                out[pos++] = (chunk0 + lane + kWave * j) * 128u + x * 32u + (uint32_t)__builtin_ctz(bits);
+                out[pos++] = cidx[j] * 128u + x * 32u + (uint32_t)__builtin_ctz(bits);
                 bits &= bits - 1u;
             }
         }
@@ -464,7 +468,10 @@ __global__ __launch_bounds__(kWave) void bmf_vote_kernel(DevParams P, const uint
             }
         }
     }
-    emit_best<CPL, PLANES, SLICED>(P, cnt, item, lane, chunk0, out_counts, out_buckets, out_min);
+    uint32_t cidx[CPL];
+#pragma unroll
+    for (int j = 0; j < CPL; j++) cidx[j] = chunk0 + lane + kWave * j;
+    emit_best<CPL, PLANES, SLICED>(P, cnt, item, lane, cidx, out_counts, out_buckets, out_min);
 }
 
 // NB > 65 536: best_results over the slices of one (window, orientation).  One thread per item.

@@ -70,6 +70,7 @@ SYMBOLS = {
     "bmf_pinned_alloc": (C.c_int, [C.c_size_t, C.POINTER(C.c_void_p)]),
     "bmf_pinned_free": (None, [C.c_void_p]),
     "bmf_info": (C.c_int, [C.c_void_p, _u32p, _u32p, _u32p, _u32p]),
+    "bmf_pass1_rows": (C.c_int, [C.c_void_p, _u32p]),
 }
 
 _lib = None
@@ -303,8 +304,10 @@ class Filter:
     def info(self) -> dict:
         v = [C.c_uint32() for _ in range(4)]
         _check(lib().bmf_info(self._h, *[C.byref(x) for x in v]))
+        r = C.c_uint32()
+        _check(lib().bmf_pass1_rows(self._h, C.byref(r)))
         return {"row_pitch_bytes": v[0].value, "chunks_per_lane": v[1].value, "planes": v[2].value,
-                "rows_in_flight": v[3].value}
+                "rows_in_flight": v[3].value, "pass1_rows": r.value}
 
     def close(self) -> None:
         if self._h:

@@ -62,9 +62,11 @@ typedef struct bmf_params {
     uint32_t flags;               /* BMF_FLAG_* (0 = behave byte for byte like round 1's default)  */
 } bmf_params;
 
-/* Stop reading index rows for a (window, orientation) as soon as every bucket has >= F misses: the
- * reference's filter is then empty at every level whatever the remaining samples are, so the outputs
- * are identical; only the number of rows actually read (not the algorithmic row count) drops. */
+/* Exact pruning: skip index bytes that cannot change the outputs.  A bucket with >= F misses is in no level
+ * of the reference's filter whatever the remaining samples are, so a wave stops when every bucket is dead
+ * and stops loading the 128-bucket chunks that hold no live bucket; where the index is sparse enough a first
+ * pass over a few rows per sample finds the live chunks and only those are counted exactly.  The outputs
+ * are identical; only the number of row bytes actually read (not the algorithmic row count) drops. */
 #define BMF_FLAG_EARLY_EXIT 1u
 
 typedef struct bmf_ctx bmf_ctx;
@@ -154,6 +156,9 @@ void bmf_pinned_free(void *p);
 /* Introspection for DESIGN.md / bench: bytes per padded row in HBM, kernel variant chosen. */
 int  bmf_info(bmf_ctx *ctx, uint32_t *row_pitch_bytes, uint32_t *chunks_per_lane, uint32_t *planes,
               uint32_t *rows_in_flight);
+/* BMF_FLAG_EARLY_EXIT only: index rows per sample the first pass of the two-pass pruning kernel streams
+ * for the loaded index; 0 = the single-pass pruning kernel (or no pruning) serves it. */
+int  bmf_pass1_rows(bmf_ctx *ctx, uint32_t *out);
 
 #ifdef __cplusplus
 }

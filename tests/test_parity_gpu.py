@@ -38,6 +38,17 @@ def _compare(case, n=None, what=""):
     c_e, b_e = fe.map_windows(rd.bases, rd.quals, ws, wl)
     assert_same_candidates(c_ref, b_ref, c_e, b_e, what + " (early exit)")
     fe.close()
+    # ... nor may the two-pass form of it, forced here (the library picks it by index density)
+    if case.cli["query_seed"] > case.cli["index_seed"] and case.num_buckets <= 65536:
+        os.environ["BMF_PASS1_ROWS"] = "1"
+        try:
+            f2 = case.gpu_filter(flags=bma.BMF_FLAG_EARLY_EXIT)
+        finally:
+            del os.environ["BMF_PASS1_ROWS"]
+        assert f2.info()["pass1_rows"] == 1
+        c_e, b_e = f2.map_windows(rd.bases, rd.quals, ws, wl)
+        assert_same_candidates(c_ref, b_ref, c_e, b_e, what + " (two-pass)")
+        f2.close()
     # the device's row count is the unit of the algorithmic-bytes figure: must equal the oracle's
     batch = flt.batch(rd.bases, rd.quals, ws, wl)
     batch.run()

@@ -39,7 +39,19 @@ def random_case(rng, *, nb, q, k, S, F, max_cand, kmer_frac, density, read_len, 
     c_got, b_got = flt.map_windows(bases, quals, ws, wl)
     c_e, b_e = fe.map_windows(bases, quals, ws, wl)
     flt.close(); fe.close()
-    return c_ref, b_ref, c_got, b_got, c_e, b_e
+    out = [c_ref, b_ref, c_got, b_got, c_e, b_e]
+    if k > q:
+        # the two-pass pruning kernel, forced (the library only picks it for sparse indexes), r rows in pass 1
+        os.environ["BMF_PASS1_ROWS"] = str(int(rng.integers(1, k - q + 1)))
+        try:
+            f2 = bma.Filter(bma.Params(num_buckets=nb, flags=bma.BMF_FLAG_EARLY_EXIT, **kw))
+            f2.load_index(rows, k2i)
+        finally:
+            del os.environ["BMF_PASS1_ROWS"]
+        assert f2.info()["pass1_rows"] >= 1
+        out += list(f2.map_windows(bases, quals, ws, wl))
+        f2.close()
+    return out
 
 
 @pytest.mark.parametrize("seed", range(int(os.environ.get("BM_SWEEP_SEEDS", "24"))))   # soak: BM_SWEEP_SEEDS=2000
@@ -55,9 +67,11 @@ def test_random_parameters(seed):
     read_len = int(rng.choice([k, k + 3, 60, 150]))
     threshold = int(rng.choice([0, nb // 2, nb]))
     minq = int(rng.choice([0, 15 * k, 30 * k]))
-    c_ref, b_ref, c_got, b_got, c_e, b_e = random_case(
+    c_ref, b_ref, c_got, b_got, c_e, b_e, *two_pass = random_case(
         rng, nb=nb, q=q, k=k, S=S, F=F, max_cand=max_cand, kmer_frac=float(rng.choice([0.3, 1.0])), density=density,
         read_len=read_len, n_reads=160, threshold=threshold, minq=minq)
     what = f"q={q} k={k} S={S} F={F} NB={nb} mc={max_cand} dens={density} L={read_len} thr={threshold} minq={minq}"
     assert_same_candidates(c_ref, b_ref, c_got, b_got, what)
     assert_same_candidates(c_ref, b_ref, c_e, b_e, what + " (early exit)")
+    if two_pass:
+        assert_same_candidates(c_ref, b_ref, two_pass[0], two_pass[1], what + " (two-pass)")
