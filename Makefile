@@ -3,7 +3,7 @@
 # drives the same targets.  The reference itself cannot be built here (SeqAn3/Sharg absent): no _ref.
 HIPCC   ?= /opt/rocm/bin/hipcc
 ARCH    ?= gfx950
-HIPFLAGS = --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -shared -Wall -Wno-unused-function
+HIPFLAGS = --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Wall -Wno-unused-function
 CXX     ?= g++
 CXXFLAGS = -O3 -std=c++17 -fPIC -Wall -Wextra -pthread
 CC      ?= gcc
@@ -11,16 +11,20 @@ CFLAGS   = -O3 -std=c11 -fPIC -shared -Wall -Wextra
 
 PKG  = bucket-map_amd
 HOST = $(PKG)/host
-HOST_HDRS = $(wildcard $(HOST)/*.h) include/bmf.h include/bml.h
+HOST_HDRS = $(wildcard $(HOST)/*.h) include/bmf.h include/bml.h include/bmv.h
 
-PRODUCT = $(PKG)/libbmf.so $(PKG)/libbmhost.so $(PKG)/bucketmap
-TESTINFRA = oracle/libbm_oracle.so tests/cpp/bucketmap_oracle tests/cpp/umm_order
+PRODUCT = $(PKG)/libbmf.so $(PKG)/libbmhost.so $(PKG)/bucketmap $(PKG)/bucketmap_align
+TESTINFRA = oracle/libbm_oracle.so tests/cpp/bucketmap_oracle tests/cpp/bucketmap_align_oracle tests/cpp/umm_order
 
 all: $(PRODUCT) $(TESTINFRA)
 
-# one product library: the candidate-bucket filter (bmf_*) and the locator scan (bml_*)
-$(PKG)/libbmf.so: $(PKG)/csrc/bmf_api.hip $(PKG)/csrc/bmf_kernels.hip.h $(PKG)/csrc/bml_api.hip $(PKG)/csrc/bml_kernels.hip.h include/bmf.h include/bml.h
-	$(HIPCC) $(HIPFLAGS) -Wno-unused-result -o $@ $(PKG)/csrc/bmf_api.hip $(PKG)/csrc/bml_api.hip
+# one product library: the candidate-bucket filter (bmf_*), the locator scan (bml_*), the verifier (bmv_*)
+CSRC = $(PKG)/csrc
+$(CSRC)/%.o: $(CSRC)/%.hip $(wildcard $(CSRC)/*.hip.h) include/bmf.h include/bml.h include/bmv.h
+	$(HIPCC) $(HIPFLAGS) -Wno-unused-result -c -o $@ $<
+
+$(PKG)/libbmf.so: $(CSRC)/bmf_api.o $(CSRC)/bml_api.o $(CSRC)/bmv_api.o
+	$(HIPCC) --offload-arch=$(ARCH) -shared -o $@ $^
 
 $(PKG)/libbmhost.so: $(HOST)/bm_host_api.cpp $(HOST_HDRS)
 	$(CXX) $(CXXFLAGS) -shared -o $@ $(HOST)/bm_host_api.cpp
@@ -29,21 +33,32 @@ $(PKG)/libbmhost.so: $(HOST)/bm_host_api.cpp $(HOST_HDRS)
 $(PKG)/bucketmap: $(HOST)/main.cpp $(HOST)/make_mapper_gpu.cpp $(HOST_HDRS) $(PKG)/libbmf.so
 	$(CXX) $(CXXFLAGS) -o $@ $(HOST)/main.cpp $(HOST)/make_mapper_gpu.cpp -L$(PKG) -lbmf -Wl,-rpath,'$$ORIGIN'
 
-oracle/libbm_oracle.so: oracle/bm_oracle.c oracle/bm_oracle.h oracle/bm_locator_oracle.c oracle/bm_locator_oracle.h
-	$(CC) $(CFLAGS) -o $@ oracle/bm_oracle.c oracle/bm_locator_oracle.c -lm
+# same sources with -DBM_ALIGN: every located candidate goes through the alignment verifier
+# (the reference builds `bucketmap_align` the same way, bucket_map/CMakeLists.txt:138)
+$(PKG)/bucketmap_align: $(HOST)/main.cpp $(HOST)/make_mapper_gpu.cpp $(HOST_HDRS) $(PKG)/libbmf.so
+	$(CXX) $(CXXFLAGS) -DBM_ALIGN -o $@ $(HOST)/main.cpp $(HOST)/make_mapper_gpu.cpp -L$(PKG) -lbmf -Wl,-rpath,'$$ORIGIN'
+
+ORACLE_SRC = oracle/bm_oracle.c oracle/bm_locator_oracle.c oracle/bm_align_oracle.c
+ORACLE_HDR = oracle/bm_oracle.h oracle/bm_locator_oracle.h oracle/bm_align_oracle.h
+oracle/libbm_oracle.so: $(ORACLE_SRC) $(ORACLE_HDR)
+	$(CC) $(CFLAGS) -o $@ $(ORACLE_SRC) -lm
 
 # TEST ONLY: same main.cpp / locator / SAM code with the CPU oracle plugged in behind bm::mapper
-tests/cpp/%.o: oracle/%.c oracle/bm_oracle.h oracle/bm_locator_oracle.h
+tests/cpp/%.o: oracle/%.c $(ORACLE_HDR)
 	$(CC) -O3 -std=c11 -fPIC -Wall -Wextra -c -o $@ $<
 
-tests/cpp/bucketmap_oracle: $(HOST)/main.cpp tests/cpp/make_mapper_oracle.cpp tests/cpp/bm_oracle.o tests/cpp/bm_locator_oracle.o $(HOST_HDRS) $(PKG)/libbmf.so
-	$(CXX) $(CXXFLAGS) -o $@ $(HOST)/main.cpp tests/cpp/make_mapper_oracle.cpp tests/cpp/bm_oracle.o tests/cpp/bm_locator_oracle.o -L$(PKG) -lbmf -Wl,-rpath,'$$ORIGIN/../../$(PKG)' -lm
+ORACLE_OBJ = tests/cpp/bm_oracle.o tests/cpp/bm_locator_oracle.o tests/cpp/bm_align_oracle.o
+tests/cpp/bucketmap_oracle: $(HOST)/main.cpp tests/cpp/make_mapper_oracle.cpp $(ORACLE_OBJ) $(HOST_HDRS) $(PKG)/libbmf.so
+	$(CXX) $(CXXFLAGS) -o $@ $(HOST)/main.cpp tests/cpp/make_mapper_oracle.cpp $(ORACLE_OBJ) -L$(PKG) -lbmf -Wl,-rpath,'$$ORIGIN/../../$(PKG)' -lm
+
+tests/cpp/bucketmap_align_oracle: $(HOST)/main.cpp tests/cpp/make_mapper_oracle.cpp $(ORACLE_OBJ) $(HOST_HDRS) $(PKG)/libbmf.so
+	$(CXX) $(CXXFLAGS) -DBM_ALIGN -o $@ $(HOST)/main.cpp tests/cpp/make_mapper_oracle.cpp $(ORACLE_OBJ) -L$(PKG) -lbmf -Wl,-rpath,'$$ORIGIN/../../$(PKG)' -lm
 
 # TEST ONLY: checks the one assumption the locator oracle imports from libstdc++ (equal_range order)
 tests/cpp/umm_order: tests/cpp/umm_order.cpp
 	$(CXX) -O2 -std=c++17 -o $@ $<
 
 clean:
-	rm -f $(PRODUCT) $(TESTINFRA)
+	rm -f $(PRODUCT) $(TESTINFRA) $(CSRC)/*.o tests/cpp/*.o
 
 .PHONY: all clean

@@ -1,0 +1,311 @@
+// bmv_api.hip -- C ABI (include/bmv.h) over the alignment-verification kernels in bmv_kernels.hip.h.
+// Host side only: validation, choice of the kernel shape for the longest query of the batch, chunking so
+// that the traceback bits of one chunk fit the scratch budget, offsets of the packed CIGAR output
+// (hipCUB exclusive sum, a library primitive).
+#include "bmv_kernels.hip.h"
+
+#include "../../include/bmv.h"
+
+#include <hipcub/hipcub.hpp>
+
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <vector>
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                                  \
+    do {                                                                                               \
+        hipError_t e_ = (expr);                                                                        \
+        if (e_ != hipSuccess)                                                                          \
+            return fail(BMV_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+void build_dna4_lut(uint8_t *lut) {
+    memset(lut, 0, 256);
+    const char *m[4] = {"AaRrWwMmDdHhVv", "CcYySsBb", "GgKk", "TtUu"};
+    for (int r = 0; r < 4; r++)
+        for (const char *c = m[r]; *c; c++) lut[(uint8_t)*c] = (uint8_t)r;
+}
+
+template <typename T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t cap = 0;
+    hipError_t need(size_t n) {
+        if (n <= cap && p) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        hipError_t e = hipMalloc(reinterpret_cast<void **>(&p), (n ? n : 1) * sizeof(T));
+        if (e == hipSuccess) cap = n ? n : 1;
+        return e;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+using align_fn = void (*)(bmv::Job);
+
+struct Shape {
+    int group, cw;
+    align_fn fn;
+};
+
+// smallest shape whose GROUP * CW words hold a query of `words` 64-row words
+Shape pick_shape(uint32_t words) {
+    if (words <= 4) return {4, 1, bmv::bmv_align_kernel<4, 1>};
+    if (words <= 8) return {8, 1, bmv::bmv_align_kernel<8, 1>};
+    if (words <= 16) return {16, 1, bmv::bmv_align_kernel<16, 1>};
+    if (words <= 64) return {64, 1, bmv::bmv_align_kernel<64, 1>};
+    if (words <= 128) return {64, 2, bmv::bmv_align_kernel<64, 2>};
+    return {64, 4, bmv::bmv_align_kernel<64, 4>};
+}
+
+}  // namespace
+
+struct bmv_ctx {
+    bmv_params p{};
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool loaded = false;
+    uint64_t n_genome = 0;
+    size_t scratch_bytes = 0;
+    DevBuf<uint8_t> genome, lut, reads, text_rc, scan_tmp;
+    DevBuf<uint64_t> text_start, query_start, trace;
+    DevBuf<uint32_t> text_len, query_len, ops_rev, nops, offsets, packed, out_begin;
+    DevBuf<int32_t> out_score;
+    // results of the last bmv_align, host side
+    uint32_t n_last = 0;
+    std::vector<int32_t> h_score;
+    std::vector<uint32_t> h_begin, h_cigar;
+    std::vector<uint64_t> h_offset;
+    float ms_kernels = 0.f;
+    uint64_t n_cells = 0;
+};
+
+extern "C" {
+
+const char *bmv_last_error(void) { return g_err; }
+
+int bmv_create(const bmv_params *params, bmv_ctx **out) {
+    if (!params || !out) return fail(BMV_ERR_ARG, "bmv_create: null argument");
+    *out = nullptr;
+    if (params->max_query_len == 0 || params->max_query_len > 16384)
+        return fail(BMV_ERR_UNSUPPORTED, "max_query_len must be in 1..16384 (got %u)", params->max_query_len);
+    if (params->max_text_len == 0 || params->max_text_len > 24576)
+        return fail(BMV_ERR_UNSUPPORTED, "max_text_len must be in 1..24576 (got %u)", params->max_text_len);
+    int n_dev = 0;
+    HIP_TRY(hipGetDeviceCount(&n_dev));
+    if (params->device < 0 || params->device >= n_dev)
+        return fail(BMV_ERR_HIP, "device %d not available (%d HIP devices)", params->device, n_dev);
+    HIP_TRY(hipSetDevice(params->device));
+    bmv_ctx *c = new bmv_ctx();
+    c->p = *params;
+    // traceback bits of the alignments in flight; BMV_SCRATCH_MB overrides (tests use it to force chunking)
+    c->scratch_bytes = (size_t)8 << 30;
+    if (const char *env = getenv("BMV_SCRATCH_MB")) {
+        const long v = strtol(env, nullptr, 10);
+        if (v > 0) c->scratch_bytes = (size_t)v << 20;
+    }
+    uint8_t lut[256];
+    build_dna4_lut(lut);
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
+        c->lut.need(256) != hipSuccess || hipMemcpy(c->lut.p, lut, 256, hipMemcpyHostToDevice) != hipSuccess) {
+        bmv_destroy(c);
+        return fail(BMV_ERR_HIP, "bmv_create: %s", hipGetErrorString(hipGetLastError()));
+    }
+    *out = c;
+    return BMV_OK;
+}
+
+void bmv_destroy(bmv_ctx *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->p.device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    c->genome.release(); c->lut.release(); c->reads.release(); c->text_rc.release(); c->scan_tmp.release();
+    c->text_start.release(); c->query_start.release(); c->trace.release();
+    c->text_len.release(); c->query_len.release(); c->ops_rev.release(); c->nops.release(); c->offsets.release();
+    c->packed.release(); c->out_begin.release(); c->out_score.release();
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int bmv_load_genome(bmv_ctx *c, const uint8_t *bases, uint64_t n_bases) {
+    if (!c || (n_bases && !bases)) return fail(BMV_ERR_ARG, "bmv_load_genome: null argument");
+    HIP_TRY(hipSetDevice(c->p.device));
+    HIP_TRY(c->genome.need((size_t)n_bases));
+    if (n_bases) HIP_TRY(hipMemcpy(c->genome.p, bases, (size_t)n_bases, hipMemcpyHostToDevice));
+    c->n_genome = n_bases;
+    c->loaded = true;
+    return BMV_OK;
+}
+
+int bmv_align(bmv_ctx *c, const uint8_t *reads, uint64_t n_read_bytes, const uint64_t *text_start,
+              const uint32_t *text_len, const uint8_t *text_rc, const uint64_t *query_start, const uint32_t *query_len,
+              uint32_t n, uint64_t *total_cigar) {
+    if (!c || !total_cigar) return fail(BMV_ERR_ARG, "bmv_align: null argument");
+    if (!c->loaded) return fail(BMV_ERR_STATE, "bmv_align before bmv_load_genome");
+    if (n && (!text_start || !text_len || !text_rc || !query_start || !query_len || (n_read_bytes && !reads)))
+        return fail(BMV_ERR_ARG, "bmv_align: null argument");
+    uint32_t max_m = 0, max_n = 0;
+    uint64_t cells = 0;
+    for (uint32_t a = 0; a < n; a++) {
+        if (query_len[a] > c->p.max_query_len)
+            return fail(BMV_ERR_ARG, "alignment %u: query of %u bases, max_query_len is %u", a, query_len[a], c->p.max_query_len);
+        if (text_len[a] > c->p.max_text_len)
+            return fail(BMV_ERR_ARG, "alignment %u: text of %u bases, max_text_len is %u", a, text_len[a], c->p.max_text_len);
+        if (query_start[a] > n_read_bytes || query_len[a] > n_read_bytes - query_start[a])
+            return fail(BMV_ERR_ARG, "alignment %u: query lies outside the read buffer", a);
+        if (text_start[a] > c->n_genome || text_len[a] > c->n_genome - text_start[a])
+            return fail(BMV_ERR_ARG, "alignment %u: text lies outside the genome", a);
+        max_m = std::max(max_m, query_len[a]);
+        max_n = std::max(max_n, text_len[a]);
+        cells += (uint64_t)query_len[a] * text_len[a];
+    }
+    c->n_last = n;
+    c->n_cells = cells;
+    c->ms_kernels = 0.f;
+    c->h_score.assign(n, 0);
+    c->h_begin.assign(n, 0);
+    c->h_offset.assign((size_t)n + 1, 0);
+    c->h_cigar.clear();
+    *total_cigar = 0;
+    if (n == 0) return BMV_OK;
+
+    HIP_TRY(hipSetDevice(c->p.device));
+    HIP_TRY(c->reads.need((size_t)n_read_bytes));
+    HIP_TRY(c->text_start.need(n));
+    HIP_TRY(c->text_len.need(n));
+    HIP_TRY(c->text_rc.need(n));
+    HIP_TRY(c->query_start.need(n));
+    HIP_TRY(c->query_len.need(n));
+    HIP_TRY(c->out_score.need(n));
+    HIP_TRY(c->out_begin.need(n));
+    if (n_read_bytes) HIP_TRY(hipMemcpyAsync(c->reads.p, reads, (size_t)n_read_bytes, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->text_start.p, text_start, (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->text_len.p, text_len, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->text_rc.p, text_rc, (size_t)n, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->query_start.p, query_start, (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->query_len.p, query_len, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+
+    // kernel shape for the longest query; scratch per alignment slot
+    const uint32_t words = (max_m + 63u) / 64u;
+    const Shape sh = pick_shape(words ? words : 1u);
+    const uint32_t l_max = std::max(1u, (words + (uint32_t)sh.cw - 1u) / (uint32_t)sh.cw);
+    const uint64_t trace_stride = (uint64_t)(max_n + l_max + 1u) * l_max * (uint32_t)sh.cw * 2u;   // 64-bit words
+    const uint32_t ops_stride = max_m + max_n + 1u;
+    const uint32_t lds_stride = (max_n + 15u) & ~15u;
+    const uint32_t gpw = 64u / (uint32_t)sh.group;
+    const size_t lds = (size_t)gpw * lds_stride;
+    if (lds > 64 * 1024) return fail(BMV_ERR_UNSUPPORTED, "text windows of %u bases need %zu B of LDS", max_n, lds);
+    if (lds > 48 * 1024)
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(sh.fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const uint64_t per_slot = trace_stride * 8u + (uint64_t)ops_stride * 4u;
+    uint64_t chunk = std::max<uint64_t>(gpw, c->scratch_bytes / per_slot);
+    chunk = std::min<uint64_t>(chunk / gpw * gpw, (uint64_t)n);
+    if (chunk == 0) chunk = n;
+    HIP_TRY(c->trace.need((size_t)(chunk * trace_stride)));
+    HIP_TRY(c->ops_rev.need((size_t)(chunk * ops_stride)));
+    HIP_TRY(c->nops.need((size_t)chunk));
+    HIP_TRY(c->offsets.need((size_t)chunk));
+    size_t tmp_bytes = 0;
+    HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, c->nops.p, c->offsets.p, (int)chunk, c->stream));
+    HIP_TRY(c->scan_tmp.need(tmp_bytes));
+
+    std::vector<uint32_t> h_nops, h_packed;
+    for (uint64_t first = 0; first < n; first += chunk) {
+        const uint32_t count = (uint32_t)std::min<uint64_t>(chunk, n - first);
+        bmv::Job j{};
+        j.genome = c->genome.p;
+        j.reads = c->reads.p;
+        j.lut = c->lut.p;
+        j.text_start = c->text_start.p;
+        j.text_len = c->text_len.p;
+        j.text_rc = c->text_rc.p;
+        j.query_start = c->query_start.p;
+        j.query_len = c->query_len.p;
+        j.first = (uint32_t)first;
+        j.count = count;
+        j.trace = c->trace.p;
+        j.trace_stride = trace_stride;
+        j.ops_rev = c->ops_rev.p;
+        j.ops_stride = ops_stride;
+        j.text_lds_stride = lds_stride;
+        j.out_score = c->out_score.p;
+        j.out_begin = c->out_begin.p;
+        j.out_nops = c->nops.p;
+        HIP_TRY(hipEventRecord(c->ev0, c->stream));
+        hipLaunchKernelGGL(sh.fn, dim3((count + gpw - 1u) / gpw), dim3(bmv::kWave), lds, c->stream, j);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(c->ev1, c->stream));
+        HIP_TRY(hipcub::DeviceScan::ExclusiveSum(c->scan_tmp.p, tmp_bytes, c->nops.p, c->offsets.p, (int)count, c->stream));
+        // total of the chunk = last offset + last count
+        uint32_t last_off = 0, last_n = 0;
+        HIP_TRY(hipMemcpyAsync(&last_off, c->offsets.p + (count - 1u), 4, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemcpyAsync(&last_n, c->nops.p + (count - 1u), 4, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        const uint32_t total = last_off + last_n;
+        HIP_TRY(c->packed.need(total));
+        hipLaunchKernelGGL(bmv::bmv_gather_kernel, dim3((count + 31u) / 32u), dim3(256), 0, c->stream, c->ops_rev.p, ops_stride,
+                           c->nops.p, c->offsets.p, count, c->packed.p);
+        HIP_TRY(hipGetLastError());
+        h_nops.resize(count);
+        h_packed.resize(total);
+        HIP_TRY(hipMemcpyAsync(h_nops.data(), c->nops.p, (size_t)count * 4, hipMemcpyDeviceToHost, c->stream));
+        if (total) HIP_TRY(hipMemcpyAsync(h_packed.data(), c->packed.p, (size_t)total * 4, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+        c->ms_kernels += ms;
+        uint64_t at = c->h_cigar.size();
+        for (uint32_t s = 0; s < count; s++) {
+            c->h_offset[first + s] = at;
+            at += h_nops[s];
+        }
+        c->h_cigar.insert(c->h_cigar.end(), h_packed.begin(), h_packed.end());
+    }
+    c->h_offset[n] = c->h_cigar.size();
+    HIP_TRY(hipMemcpy(c->h_score.data(), c->out_score.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(c->h_begin.data(), c->out_begin.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+    *total_cigar = c->h_cigar.size();
+    return BMV_OK;
+}
+
+int bmv_results(bmv_ctx *c, int32_t *out_score, uint32_t *out_begin, uint64_t *out_cigar_offset, uint32_t *out_cigar) {
+    if (!c) return fail(BMV_ERR_ARG, "bmv_results: null context");
+    if (out_score) memcpy(out_score, c->h_score.data(), c->h_score.size() * sizeof(int32_t));
+    if (out_begin) memcpy(out_begin, c->h_begin.data(), c->h_begin.size() * sizeof(uint32_t));
+    if (out_cigar_offset) memcpy(out_cigar_offset, c->h_offset.data(), c->h_offset.size() * sizeof(uint64_t));
+    if (out_cigar && !c->h_cigar.empty()) memcpy(out_cigar, c->h_cigar.data(), c->h_cigar.size() * sizeof(uint32_t));
+    return BMV_OK;
+}
+
+int bmv_last_stats(bmv_ctx *c, float *ms_kernels, uint64_t *n_cells) {
+    if (!c) return fail(BMV_ERR_ARG, "bmv_last_stats: null context");
+    if (ms_kernels) *ms_kernels = c->ms_kernels;
+    if (n_cells) *n_cells = c->n_cells;
+    return BMV_OK;
+}
+
+}  // extern "C"

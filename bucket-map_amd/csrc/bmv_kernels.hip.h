@@ -1,0 +1,240 @@
+// bmv_kernels.hip.h -- gfx950 kernels of the alignment verifier (include/bmv.h).
+//
+// What the BM_ALIGN build of the reference asks of SeqAn3 per located candidate
+// (bucket_map/locator/bucket_locator.h:520-528,560-589): the edit distance of the whole query against
+// the best substring of the text (global alignment with free end gaps in sequence1), where that substring
+// begins, and the alignment itself as a CIGAR.
+//
+// Myers' bit-vector recurrence (Hyyro's block form): one 64-bit word carries 64 query rows of one text
+// column as +1/-1 vertical deltas (Pv, Mv); a column step is ~20 word operations.  A query of m bases is
+// ceil(m/64) words; they are laid over the lanes of a GROUP (CW consecutive words per lane) and the lanes
+// are skewed along the text: at step t lane l works on column t-l and takes the horizontal delta that
+// leaves lane l-1's last row (computed one step earlier) through a shuffle.  GROUP is the smallest
+// power of two that holds the query, so a wave verifies 64/GROUP candidates at once (16 for 150-bp reads,
+// 8 for 300-bp reads, 1 for 10-kbp reads).
+//
+// Per cell two bits are kept for the traceback: "the diagonal predecessor is valid" (match with diagonal
+// delta 0, or mismatch with diagonal delta 1: ~(Eq ^ D0)) and "the upper predecessor is valid" (vertical
+// delta +1: Pv); when neither holds the left one must be.  They go to HBM in step-major order (all lanes
+// of a step write one contiguous run).  The traceback walks from the LAST minimum of the bottom row,
+// trying diagonal, up, left in that order (include/bmv.h, tie rules 1-2), reading the trace
+// GROUP columns at a time, and leaves run-length CIGAR entries in reverse; bmv_gather_kernel reverses and
+// packs them.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace bmv {
+
+constexpr int kWave = 64;
+
+struct Job {
+    const uint8_t *genome;          // ASCII
+    const uint8_t *reads;           // ASCII
+    const uint8_t *lut;             // dna4 rank of a char (256 entries)
+    const uint64_t *text_start;     // per alignment of the batch
+    const uint32_t *text_len;
+    const uint8_t *text_rc;
+    const uint64_t *query_start;
+    const uint32_t *query_len;
+    uint32_t first, count;          // this launch handles alignments [first, first + count); slot = a - first
+    uint64_t *trace;                // count x trace_stride words
+    uint64_t trace_stride;
+    uint32_t *ops_rev;              // count x ops_stride reversed CIGAR entries
+    uint32_t ops_stride;
+    uint32_t text_lds_stride;       // bytes of LDS per group
+    int32_t *out_score;             // per alignment of the batch
+    uint32_t *out_begin;
+    uint32_t *out_nops;             // per slot
+};
+
+__device__ __forceinline__ uint64_t shfl64(uint64_t v, int src, int width) {
+    const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)v, src, width);
+    const uint32_t hi = (uint32_t)__shfl((int)(uint32_t)(v >> 32), src, width);
+    return ((uint64_t)hi << 32) | lo;
+}
+
+template <int GROUP, int CW>
+__global__ __launch_bounds__(kWave) void bmv_align_kernel(Job J) {
+    extern __shared__ uint8_t lds_text[];
+    constexpr int GPW = kWave / GROUP;                         // groups (alignments) per wave
+    const uint32_t lane = threadIdx.x, grp = lane / GROUP, gl = lane % GROUP;
+    const uint32_t slot = blockIdx.x * GPW + grp;
+    const bool have = slot < J.count;
+    const uint32_t a = J.first + (have ? slot : 0u);
+    const uint32_t n = have ? J.text_len[a] : 0u, m = have ? J.query_len[a] : 0u;
+    const uint32_t W = (m + 63u) >> 6;                         // words of the query
+    const uint32_t L = (W + CW - 1u) / CW;                     // lanes of the group that hold query rows
+    uint8_t *text = lds_text + (size_t)grp * J.text_lds_stride;
+
+    // text window -> dna4 ranks in LDS, reverse-complemented if asked (bucket_locator.h:562-567)
+    if (have) {
+        const uint8_t *src = J.genome + J.text_start[a];
+        const bool rc = J.text_rc[a] != 0;
+        for (uint32_t j = gl; j < n; j += GROUP) {
+            const uint8_t r = J.lut[rc ? src[n - 1u - j] : src[j]];
+            text[j] = rc ? (uint8_t)(3u - r) : r;
+        }
+    }
+    // match masks of this lane's words, one per base
+    uint64_t peq[4][CW];
+#pragma unroll
+    for (int c = 0; c < CW; c++) {
+        peq[0][c] = peq[1][c] = peq[2][c] = peq[3][c] = 0;
+        const uint32_t w = gl * CW + c;
+        if (have && w < W) {
+            const uint8_t *q = J.reads + J.query_start[a] + (size_t)w * 64u;
+            const uint32_t rows = m - w * 64u < 64u ? m - w * 64u : 64u;
+            for (uint32_t b = 0; b < rows; b++) {
+                const uint8_t r = J.lut[q[b]];
+                const uint64_t bit = 1ull << b;
+                peq[0][c] |= r == 0 ? bit : 0;
+                peq[1][c] |= r == 1 ? bit : 0;
+                peq[2][c] |= r == 2 ? bit : 0;
+                peq[3][c] |= r == 3 ? bit : 0;
+            }
+        }
+    }
+    __syncthreads();
+
+    uint64_t pv[CW], mv[CW];
+#pragma unroll
+    for (int c = 0; c < CW; c++) {
+        pv[c] = ~0ull;                                          // column 0: H[i][0] = i
+        mv[c] = 0;
+    }
+    int32_t score = (int32_t)m, best = (int32_t)m;              // tracked by the lane that holds row m
+    uint32_t best_j = 0;
+    const uint32_t last_lane = W ? (W - 1u) / CW : 0u, last_c = W ? (W - 1u) % CW : 0u, last_bit = (m - 1u) & 63u;
+    uint64_t *trace = J.trace + (size_t)slot * J.trace_stride;
+
+    // every group of the wave runs the same number of steps (shuffles need the whole wave)
+    uint32_t steps = (have && W) ? n + L - 1u : 0u;
+#pragma unroll
+    for (int o = GROUP; o < kWave; o <<= 1) {
+        const uint32_t other = (uint32_t)__shfl_xor((int)steps, o, kWave);
+        steps = other > steps ? other : steps;
+    }
+    int hout_prev = 0;
+    for (uint32_t t = 1; t <= steps; t++) {
+        int hin = __shfl_up(hout_prev, 1, GROUP);
+        if (gl == 0) hin = 0;                                   // row 0 is all zeros: free leading text gaps
+        const uint32_t j = t - gl;                              // 1-based text column of this lane
+        if (gl < L && j >= 1u && j <= n && t >= gl + 1u) {
+            const uint8_t ch = text[j - 1u];
+#pragma unroll
+            for (int c = 0; c < CW; c++) {
+                const uint32_t w = gl * CW + c;
+                if (w < W) {
+                    const uint64_t eq0 = ch == 0 ? peq[0][c] : (ch == 1 ? peq[1][c] : (ch == 2 ? peq[2][c] : peq[3][c]));
+                    const uint64_t hin_neg = hin < 0 ? 1ull : 0ull;
+                    const uint64_t xv = eq0 | mv[c];
+                    const uint64_t eq = eq0 | hin_neg;
+                    const uint64_t xh = (((eq & pv[c]) + pv[c]) ^ pv[c]) | eq;
+                    uint64_t ph = mv[c] | ~(xh | pv[c]);
+                    uint64_t mh = pv[c] & xh;
+                    const uint64_t d0 = xh | mv[c];            // diagonal delta is 0
+                    if (gl == last_lane && c == (int)last_c) {
+                        score += (int32_t)((ph >> last_bit) & 1ull) - (int32_t)((mh >> last_bit) & 1ull);
+                        if (score <= best) {                    // the LAST minimum of the bottom row
+                            best = score;
+                            best_j = j;
+                        }
+                    }
+                    const int hout = (int)(ph >> 63) - (int)(mh >> 63);
+                    ph = (ph << 1) | (hin > 0 ? 1ull : 0ull);
+                    mh = (mh << 1) | hin_neg;
+                    pv[c] = mh | ~(xv | ph);
+                    mv[c] = ph & xv;
+                    hin = hout;
+                    uint64_t *tr = trace + (((size_t)t * L + gl) * CW + c) * 2u;
+                    tr[0] = ~(eq0 ^ d0);                        // diagonal predecessor valid
+                    tr[1] = pv[c];                              // upper predecessor valid
+                }
+            }
+            hout_prev = hin;
+        }
+    }
+    __threadfence();
+    __syncthreads();
+    if (!have) return;
+
+    best = __shfl(best, (int)last_lane, GROUP);
+    best_j = (uint32_t)__shfl((int)best_j, (int)last_lane, GROUP);
+    if (m == 0) {                                               // H[0][j] = 0 everywhere: last column
+        best = 0;
+        best_j = n;
+    }
+
+    // traceback, the whole group in step; lane 0 of the group writes
+    uint32_t *ops = J.ops_rev + (size_t)slot * J.ops_stride;
+    uint32_t i = m, j = best_j, n_rev = 0, cur_op = 3, cur_len = 0;
+    uint32_t wc = 0xFFFFFFFFu, jc = 0;
+    uint64_t db = 0, ub = 0;
+    while (i > 0) {
+        uint32_t op;
+        if (j == 0) {                                           // column 0: only the upper predecessor
+            op = 1;
+            i--;
+        } else {
+            const uint32_t w = (i - 1u) >> 6;
+            if (w != wc || j > jc || j + GROUP <= jc) {         // (re)load GROUP columns of word w ending at j
+                wc = w;
+                jc = j;
+                const uint32_t owner = w / CW, c = w % CW;
+                if (jc > gl) {
+                    const uint32_t col = jc - gl;
+                    const uint64_t *tr = trace + (((size_t)(col + owner) * L + owner) * CW + c) * 2u;
+                    db = tr[0];
+                    ub = tr[1];
+                }
+            }
+            const int src = (int)(jc - j);
+            const uint64_t d = shfl64(db, src, GROUP), u = shfl64(ub, src, GROUP);
+            const uint32_t bit = (i - 1u) & 63u;
+            if ((d >> bit) & 1ull) {
+                op = 0;
+                i--;
+                j--;
+            } else if ((u >> bit) & 1ull) {
+                op = 1;
+                i--;
+            } else {
+                op = 2;
+                j--;
+            }
+        }
+        if (op == cur_op) {
+            cur_len++;
+        } else {
+            if (cur_len && gl == 0) ops[n_rev] = (cur_len << 4) | cur_op;
+            n_rev += cur_len ? 1u : 0u;
+            cur_op = op;
+            cur_len = 1;
+        }
+    }
+    if (cur_len) {
+        if (gl == 0) ops[n_rev] = (cur_len << 4) | cur_op;
+        n_rev++;
+    }
+    if (gl == 0) {
+        J.out_score[a] = -best;
+        J.out_begin[a] = j;
+        J.out_nops[slot] = n_rev;
+    }
+}
+
+// CIGAR entries of one chunk, reversed into reading order at their final offsets.
+__global__ void bmv_gather_kernel(const uint32_t *__restrict__ ops_rev, uint32_t ops_stride,
+                                  const uint32_t *__restrict__ nops, const uint32_t *__restrict__ offsets,
+                                  uint32_t count, uint32_t *__restrict__ out) {
+    const uint32_t slot = blockIdx.x * (blockDim.x / 8u) + threadIdx.x / 8u, t = threadIdx.x % 8u;
+    if (slot >= count) return;
+    const uint32_t c = nops[slot];
+    const uint32_t *src = ops_rev + (size_t)slot * ops_stride;
+    uint32_t *dst = out + offsets[slot];
+    for (uint32_t x = t; x < c; x += 8u) dst[x] = src[c - 1u - x];
+}
+
+}  // namespace bmv

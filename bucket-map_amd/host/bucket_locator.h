@@ -4,7 +4,8 @@
 //   query_sequences_storage / _prepare_read_query   :19-103, :292-347
 //   _locate: bucket loop and its ordering contract   :613-705
 //   _filter_best_locations                           :350-405
-//   locate (SAM)                                     :455-611  (non-BM_ALIGN branch)
+//   locate (SAM)                                     :455-611  (both branches: with a verifier plugged
+//                                                               in, the BM_ALIGN one)
 // The candidate scan itself -- _create_kmer_index (:162-177) + _find_offset (:209-290) for every
 // candidate (window, bucket, strand) -- sits behind bm::offset_scanner: the MI355X scan (include/bml.h)
 // in the product, the C oracle in the test build.  Order-sensitive details are kept on purpose
@@ -37,6 +38,21 @@ public:
                       const uint8_t *pair_rc, uint32_t n_pairs, int32_t *out_offset, uint32_t *out_votes) = 0;
 };
 
+// Where the BM_ALIGN branch's align_pairwise (:520-528,569) runs: the MI355X verifier (include/bmv.h) in the
+// product, the C oracle in the test build.  One call handles a batch of (text window, query) pairs given as
+// views into the genome string and into a buffer of reads.
+class alignment_verifier {
+public:
+    virtual ~alignment_verifier() = default;
+    virtual void load_genome(const uint8_t *bases, uint64_t n_bases) = 0;
+    // score = alignment.score(), begin = sequence1_begin_position(), CIGAR entries packed len << 4 | op
+    // (0 M, 1 I, 2 D); alignment a owns cigar[cigar_offset[a] .. cigar_offset[a + 1])
+    virtual void align(const uint8_t *reads, uint64_t n_read_bytes, const uint64_t *text_start, const uint32_t *text_len,
+                       const uint8_t *text_rc, const uint64_t *query_start, const uint32_t *query_len, uint32_t n,
+                       std::vector<int32_t> &score, std::vector<uint32_t> &begin, std::vector<uint64_t> &cigar_offset,
+                       std::vector<uint32_t> &cigar) = 0;
+};
+
 class bucket_locator {
 public:
     // (bucket id, offset in the bucket, window offset in the read, votes, true = read as-is)
@@ -45,8 +61,12 @@ public:
 private:
     mapper *_m;
     offset_scanner *_s;
+    alignment_verifier *_v = nullptr;            // non-null: the BM_ALIGN behaviour
     const Genome *genome_ = nullptr;
     std::vector<Bucket> buckets_;
+    std::vector<uint8_t> flat_;                  // the records back to back (kept for the verifier only)
+    std::vector<uint64_t> bstart_;               // bucket views into flat_
+    std::vector<uint32_t> blen_;
 
     unsigned int bucket_length, read_length, min_base_quality;
     uint8_t k;
@@ -171,6 +191,9 @@ public:
         min_base_quality = quality_threshold * k;                                         // :431
     }
 
+    // bucketmap_align: every located candidate is verified by a pairwise alignment before it is written
+    void set_verifier(alignment_verifier *v) { _v = v; }
+
     int get_allowed_mismatch() const { return allowed_mismatch; }
     int get_allowed_indel() const { return allowed_indel; }
 
@@ -190,16 +213,24 @@ public:
         {
             std::vector<uint64_t> rec_off(genome_->seqs.size() + 1, 0);
             for (size_t r = 0; r < genome_->seqs.size(); r++) rec_off[r + 1] = rec_off[r] + genome_->seqs[r].size();
-            std::vector<uint8_t> flat(rec_off.back());
+            std::vector<uint8_t> &flat = flat_;
+            flat.assign(rec_off.back(), 0);
             for (size_t r = 0; r < genome_->seqs.size(); r++)
                 std::copy(genome_->seqs[r].begin(), genome_->seqs[r].end(), flat.begin() + static_cast<std::ptrdiff_t>(rec_off[r]));
-            std::vector<uint64_t> bstart(buckets_.size());
-            std::vector<uint32_t> blen(buckets_.size());
+            std::vector<uint64_t> &bstart = bstart_;
+            std::vector<uint32_t> &blen = blen_;
+            bstart.assign(buckets_.size(), 0);
+            blen.assign(buckets_.size(), 0);
             for (size_t b = 0; b < buckets_.size(); b++) {
                 bstart[b] = rec_off[buckets_[b].record] + buckets_[b].start;
                 blen[b] = buckets_[b].end - buckets_[b].start;
             }
             _s->load_genome(flat.data(), flat.size(), bstart.data(), blen.data(), static_cast<uint32_t>(buckets_.size()));
+            if (_v) {
+                _v->load_genome(flat.data(), flat.size());
+            } else {
+                std::vector<uint8_t>().swap(flat_);
+            }
         }
         prepare_read_query(sequence_file);
 
@@ -256,17 +287,15 @@ public:
         return res;
     }
 
-    // locate (:455-611), non-BM_ALIGN branch: one SAM record per surviving location
-    void locate(const std::string &sequence_file, std::filesystem::path const &index_file,
-                std::filesystem::path const &sam_file, unsigned int quality_threshold = 30) {
-        (void)quality_threshold;   // only used under BM_ALIGN in the reference
-        auto locate_res = locate_reads(sequence_file);
-
-        // .bucket_id -> @SQ lines and per-bucket offsets (:473-503)
-        std::ifstream bucket_info(index_file);
+    // .bucket_id -> @SQ lines and per-bucket offsets (:473-503)
+    struct sam_header {
         std::vector<std::string> bucket_name, ref_ids;
         std::vector<unsigned int> bucket_offsets;
         std::vector<size_t> ref_lengths;
+    };
+    sam_header read_bucket_ids(std::filesystem::path const &index_file) const {
+        sam_header h;
+        std::ifstream bucket_info(index_file);
         std::string name, last_bucket_name;
         unsigned int bucket_index = 0;
         for (size_t i = 0; i < buckets_.size(); i++) {
@@ -274,45 +303,136 @@ public:
             name = name.substr(0, name.find(' '));
             if (name != last_bucket_name) {
                 if (bucket_index != 0) {
-                    ref_ids.push_back(last_bucket_name);
-                    ref_lengths.push_back(static_cast<size_t>(bucket_index) * bucket_length);
+                    h.ref_ids.push_back(last_bucket_name);
+                    h.ref_lengths.push_back(static_cast<size_t>(bucket_index) * bucket_length);
                 }
                 last_bucket_name = name;
                 bucket_index = 0;
             }
-            bucket_name.push_back(name);
-            bucket_offsets.push_back(bucket_index * bucket_length);
+            h.bucket_name.push_back(name);
+            h.bucket_offsets.push_back(bucket_index * bucket_length);
             bucket_index++;
         }
         if (bucket_index != 0) {
-            ref_ids.push_back(last_bucket_name);
-            ref_lengths.push_back(static_cast<size_t>(bucket_index) * bucket_length);
+            h.ref_ids.push_back(last_bucket_name);
+            h.ref_lengths.push_back(static_cast<size_t>(bucket_index) * bucket_length);
         }
+        return h;
+    }
+
+    // locate (:455-611): one SAM record per surviving location.  Without a verifier this is the plain
+    // `bucketmap` branch (best locations by votes, MAPQ from votes, no CIGAR); with one it is the BM_ALIGN
+    // branch (every location aligned, MAPQ = 60 + score, dropped below `quality_threshold`, CIGAR written).
+    void locate(const std::string &sequence_file, std::filesystem::path const &index_file,
+                std::filesystem::path const &sam_file, unsigned int quality_threshold = 30) {
+        auto locate_res = locate_reads(sequence_file);
+        const sam_header h = read_bucket_ids(index_file);
 
         // SAM as seqan3::sam_file_output writes it
         std::ofstream sam(sam_file, std::ios::binary);
         if (!sam) throw std::runtime_error("cannot write " + sam_file.string());
         sam << "@HD\tVN:1.6\n";
-        for (size_t i = 0; i < ref_ids.size(); i++) sam << "@SQ\tSN:" << ref_ids[i] << "\tLN:" << ref_lengths[i] << "\n";
+        for (size_t i = 0; i < h.ref_ids.size(); i++) sam << "@SQ\tSN:" << h.ref_ids[i] << "\tLN:" << h.ref_lengths[i] << "\n";
         unsigned int read_id = 0, mapped_locations = 0;
         auto t0 = std::chrono::steady_clock::now();
-        for_each_fastq(sequence_file, [&](const FastqRecord &rec) {
-            auto best = filter_best_locations(locate_res[read_id], static_cast<unsigned int>(rec.seq.size()));
-            for (auto &[bucket_id, offset, segment_offset, votes, is_original] : best) {
-                (void)segment_offset;
-                const unsigned int map_qual = std::min(60u, 6 * votes);                      // :591
-                const size_t ref_offset = static_cast<size_t>(bucket_offsets[bucket_id]) + offset;  // :592, 0-based
-                sam << rec.id << '\t' << (is_original ? 0 : 16) << '\t' << bucket_name[bucket_id] << '\t'
-                    << ref_offset + 1 << '\t' << map_qual << "\t*\t*\t0\t0\t" << rec.seq << '\t' << rec.qual << '\n';
-                mapped_locations++;
-            }
-            read_id++;
-        });
+        if (_v) {
+            mapped_locations = write_verified(sequence_file, locate_res, h, sam, quality_threshold, read_id);
+        } else {
+            for_each_fastq(sequence_file, [&](const FastqRecord &rec) {
+                auto best = filter_best_locations(locate_res[read_id], static_cast<unsigned int>(rec.seq.size()));   // :540
+                for (auto &[bucket_id, offset, segment_offset, votes, is_original] : best) {
+                    (void)segment_offset;
+                    const unsigned int map_qual = std::min(60u, 6 * votes);                      // :591
+                    const size_t ref_offset = static_cast<size_t>(h.bucket_offsets[bucket_id]) + offset;  // :592, 0-based
+                    sam << rec.id << '\t' << (is_original ? 0 : 16) << '\t' << h.bucket_name[bucket_id] << '\t'
+                        << ref_offset + 1 << '\t' << map_qual << "\t*\t*\t0\t0\t" << rec.seq << '\t' << rec.qual << '\n';
+                    mapped_locations++;
+                }
+                read_id++;
+            });
+        }
         const float s = std::chrono::duration<float>(std::chrono::steady_clock::now() - t0).count();
         std::cerr << "[BENCHMARK]\tTotal mapped locations: " << mapped_locations << " ("
                   << static_cast<float>(mapped_locations) / read_id << " per sequence).\n";
         std::cerr << "[BENCHMARK]\tTotal time used for alignment verification and output: " << s << " s ("
                   << s / mapped_locations * 1000 * 1000 << " μs per pairwise alignment).\n";
+    }
+
+private:
+    // BM_ALIGN branch of locate (:520-528,544-589), a block of reads at a time: the text window of every
+    // location (:549-550), one batch of alignments, then the records in read order.
+    //   * no _filter_best_locations in this branch (:538-541);
+    //   * width = min(len + 1 + (size_t)(n * len), bucket size - offset), the product in float32 (:550);
+    //   * map_qual = 60u + score in UNSIGNED arithmetic: below -60 it wraps to ~2^32 and so passes the
+    //     `< quality_threshold` test (:570-573); the SAM field is 8 bits wide, hence the truncation;
+    //   * POS = begin + bucket offset + offset + 1, also on the reverse strand, where `begin` counts in the
+    //     reverse-complemented window (:576) -- kept as the reference computes it.
+    // Deviation: a negative `offset` indexes before the bucket in the reference (undefined behaviour); here
+    // the window is clipped to start at the bucket's first base.
+    unsigned int write_verified(const std::string &sequence_file, const std::vector<std::vector<locate_t>> &locate_res,
+                                const sam_header &h, std::ofstream &sam, unsigned int quality_threshold, unsigned int &read_id) {
+        struct held { std::string id, seq, qual; uint64_t start; };
+        std::vector<held> block;
+        std::vector<uint8_t> bases;
+        std::vector<uint64_t> text_start, query_start, cigar_offset;
+        std::vector<uint32_t> text_len, query_len, begin, cigar;
+        std::vector<uint8_t> text_rc;
+        std::vector<int32_t> score;
+        unsigned int mapped_locations = 0, first_read = 0;
+        const size_t block_reads = 1u << 17, block_bases = 64u << 20;
+        auto flush = [&]() {
+            if (!text_start.empty())
+                _v->align(bases.data(), bases.size(), text_start.data(), text_len.data(), text_rc.data(), query_start.data(),
+                          query_len.data(), static_cast<uint32_t>(text_start.size()), score, begin, cigar_offset, cigar);
+            size_t a = 0;
+            std::string cg;
+            for (size_t r = 0; r < block.size(); r++) {
+                for (auto &[bucket_id, offset, segment_offset, votes, is_original] : locate_res[first_read + r]) {
+                    (void)segment_offset; (void)votes;
+                    const unsigned int wrapped = 60u + static_cast<unsigned int>(score[a]);          // :570
+                    const size_t map_qual = wrapped;
+                    if (!(map_qual < quality_threshold)) {                                            // :571-573
+                        const int clipped = offset < 0 ? 0 : offset;
+                        const size_t ref_offset = static_cast<size_t>(begin[a]) + h.bucket_offsets[bucket_id] + clipped;   // :576
+                        cg.clear();
+                        for (uint64_t x = cigar_offset[a]; x < cigar_offset[a + 1]; x++) {
+                            cg += std::to_string(cigar[x] >> 4);
+                            cg += "MID"[cigar[x] & 15u];
+                        }
+                        if (cg.empty()) cg = "*";
+                        sam << block[r].id << '\t' << (is_original ? 0 : 16) << '\t' << h.bucket_name[bucket_id] << '\t'
+                            << ref_offset + 1 << '\t' << static_cast<unsigned int>(static_cast<uint8_t>(map_qual)) << '\t' << cg
+                            << "\t*\t0\t0\t" << block[r].seq << '\t' << block[r].qual << '\n';
+                        mapped_locations++;
+                    }
+                    a++;
+                }
+            }
+            first_read += static_cast<unsigned int>(block.size());
+            block.clear(); bases.clear();
+            text_start.clear(); text_len.clear(); text_rc.clear(); query_start.clear(); query_len.clear();
+        };
+        for_each_fastq(sequence_file, [&](const FastqRecord &rec) {
+            const size_t len = rec.seq.size();
+            block.push_back({std::string(rec.id), std::string(rec.seq), std::string(rec.qual), bases.size()});
+            bases.insert(bases.end(), rec.seq.begin(), rec.seq.end());
+            for (auto &[bucket_id, offset, segment_offset, votes, is_original] : locate_res[read_id]) {
+                (void)segment_offset; (void)votes;
+                const size_t clipped = offset < 0 ? 0 : static_cast<size_t>(offset);
+                const size_t bucket_size = blen_[bucket_id];
+                const size_t width = std::min(len + 1 + static_cast<size_t>(allowed_indel_rate * len),   // :550
+                                              bucket_size - std::min(clipped, bucket_size));
+                text_start.push_back(bstart_[bucket_id] + std::min(clipped, bucket_size));
+                text_len.push_back(static_cast<uint32_t>(width));
+                text_rc.push_back(is_original ? 0 : 1);                                                 // :563-567
+                query_start.push_back(block.back().start);
+                query_len.push_back(static_cast<uint32_t>(len));
+            }
+            read_id++;
+            if (block.size() >= block_reads || bases.size() >= block_bases) flush();
+        });
+        flush();
+        return mapped_locations;
     }
 };
 

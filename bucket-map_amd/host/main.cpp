@@ -1,4 +1,6 @@
 // main.cpp -- the `bucketmap` command-line tool (bucket_map/main.cpp:135-234), MI355X edition.
+// Compiled a second time with -DBM_ALIGN it is `bucketmap_align` (bucket_map/CMakeLists.txt:138): every
+// located candidate is verified by a pairwise alignment and written with MAPQ = 60 + score and a CIGAR.
 //
 //   bucketmap -x -i <name> --genome ref.fa                       index only (writes into the cwd)
 //   bucketmap -i <name> -q reads.fq -o out.sam --genome ref.fa    map (indexes first if needed)
@@ -17,6 +19,8 @@
 // Defined per build: the product links make_mapper_gpu.cpp (MI355X filter + MI355X locator scan).
 std::unique_ptr<bm::mapper> bm_make_mapper(const bm::cmd_arguments &args, unsigned int num_buckets, unsigned int fault);
 std::unique_ptr<bm::offset_scanner> bm_make_scanner(const bm::cmd_arguments &args, int allowed_mismatch, int allowed_indel);
+// bucketmap_align only: where align_pairwise runs (the MI355X verifier in the product).
+std::unique_ptr<bm::alignment_verifier> bm_make_verifier(const bm::cmd_arguments &args);
 // --gpu-index: fills ix with the rows built on the device; false = not available in this build.
 bool bm_gpu_index(const bm::cmd_arguments &args, const bm::Genome &genome, unsigned int num_buckets, bm::QgramIndex &ix);
 
@@ -28,7 +32,11 @@ int main(int argc, char **argv) {
         std::cerr << "[ERROR]\t\t" << ext.what() << "\n";   // main.cpp:148-155
         return -1;
     }
+#ifdef BM_ALIGN
+    std::cerr << "[INFO]\t\tAllowing Smith-Waterman for alignment verifications.\n";   // main.cpp:159-163
+#else
     std::cerr << "[INFO]\t\tNot using Smith-Waterman for alignment verifications.\n";
+#endif
     if (args.genome_path.empty()) {
         // the reference prints this when BM_* are not defined at build time (main.cpp:227-231)
         std::cerr << "[ERROR]\t\tThe definition of BM_BUCKET_NUM, BM_BUCKET_LEN or BM_GENOME_FILE is not found. "
@@ -97,6 +105,10 @@ int main(int argc, char **argv) {
         bm::bucket_locator loc(map.get(), scanner.get(), args.bucket_len, args.max_read_length, args.query_seed_length,
                                args.allowed_seed_miss_rate, args.locator_allowed_indel_rate,
                                static_cast<unsigned int>(args.locator_sample_size), args.average_base_quality);
+#ifdef BM_ALIGN
+        std::unique_ptr<bm::alignment_verifier> verifier = bm_make_verifier(args);
+        loc.set_verifier(verifier.get());
+#endif
         run_indexer();
         loc.initialize(genome, cwd, args.index_indicator);                                    // main.cpp:221
         loc.locate(args.fastq_path.string(), cwd / (args.index_indicator + ".bucket_id"),     // main.cpp:224

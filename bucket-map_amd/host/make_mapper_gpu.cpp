@@ -3,6 +3,7 @@
 // (main.cpp:202-209: q_gram_mapper<BM_BUCKET_NUM> map(BM_BUCKET_LEN, read_len, k, q, S, fault, d, b))
 #include "bm_indexer.h"
 #include "cli.h"
+#include "gpu_alignment_verifier.h"
 #include "gpu_offset_scanner.h"
 #include "gpu_q_gram_mapper.h"
 
@@ -63,4 +64,8 @@ std::unique_ptr<bm::offset_scanner> bm_make_scanner(const bm::cmd_arguments &arg
     return std::make_unique<bm::gpu_offset_scanner>(args.query_seed_length, static_cast<uint32_t>(args.locator_sample_size),
                                                     allowed_mismatch, allowed_indel,
                                                     args.bucket_len + args.max_read_length, args.gpus.front());
+}
+
+std::unique_ptr<bm::alignment_verifier> bm_make_verifier(const bm::cmd_arguments &args) {
+    return std::make_unique<bm::gpu_alignment_verifier>(args.gpus.front());
 }

@@ -62,6 +62,9 @@ def lib() -> C.CDLL:
             "bmo_map_windows": (C.c_uint64, [vp, _u8p, _u8p, _u64p, _u32p, u32, _u32p, _u32p]),
             "bmlo_locate": (C.c_int, [C.POINTER(LocParams), _u8p, _u64p, _u32p, u32, _u32p, C.POINTER(C.c_uint16), _u32p,
                                       _u32p, _u32p, _u8p, u32, C.POINTER(C.c_int32), _u32p]),
+            "bmao_align": (C.c_int, [_u8p, u32, C.c_int, _u8p, u32, _i32p, _u32p, _u32p, u32]),
+            "bmao_align_batch": (C.c_int, [_u8p, _u8p, _u64p, _u32p, _u8p, _u64p, _u32p, u32, _i32p, _u32p, _u64p, _u32p,
+                                           C.c_uint64]),
         }
         for name, (res, args) in sig.items():
             fn = getattr(L, name)
@@ -133,6 +136,44 @@ def locate(k, num_samples, allowed_mismatch, allowed_indel, genome, bucket_start
     if rc:
         raise RuntimeError("oracle locator: bad bucket id")
     return off, votes
+
+
+def align(text: bytes, query: bytes, text_rc: bool = False):
+    """bmao_align: (score, begin, CIGAR string) of the whole query against the best substring of the text
+    (bucket_locator.h:520-528,569-576; tie rules in oracle/bm_align_oracle.h)."""
+    t = np.frombuffer(bytes(text), np.uint8) if len(text) else np.zeros(1, np.uint8)
+    q = np.frombuffer(bytes(query), np.uint8) if len(query) else np.zeros(1, np.uint8)
+    cap = len(text) + len(query) + 1
+    cg = np.zeros(cap, np.uint32)
+    score, begin = C.c_int32(), C.c_uint32()
+    n = lib().bmao_align(_p(t, _u8p), len(text), int(text_rc), _p(q, _u8p), len(query), C.byref(score), C.byref(begin),
+                         _p(cg, _u32p), cap)
+    if n < 0:
+        raise MemoryError("bmao_align")
+    return score.value, begin.value, cigar_string(cg[:n])
+
+
+def cigar_string(packed) -> str:
+    return "".join(f"{int(e) >> 4}{'MID'[int(e) & 15]}" for e in packed)
+
+
+def align_batch(genome, reads, text_start, text_len, text_rc, query_start, query_len):
+    """bmao_align_batch, buffer layout of bmv_align (include/bmv.h)."""
+    g = np.ascontiguousarray(genome, np.uint8)
+    r = np.ascontiguousarray(reads, np.uint8)
+    ts, tl = np.ascontiguousarray(text_start, np.uint64), np.ascontiguousarray(text_len, np.uint32)
+    trc = np.ascontiguousarray(text_rc, np.uint8)
+    qs, ql = np.ascontiguousarray(query_start, np.uint64), np.ascontiguousarray(query_len, np.uint32)
+    n = len(ts)
+    score, begin = np.zeros(n, np.int32), np.zeros(n, np.uint32)
+    off = np.zeros(n + 1, np.uint64)
+    cap = int(tl.astype(np.uint64).sum() + ql.astype(np.uint64).sum()) + n + 1
+    cg = np.zeros(cap, np.uint32)
+    rc = lib().bmao_align_batch(_p(g, _u8p), _p(r, _u8p), _p(ts, _u64p), _p(tl, _u32p), _p(trc, _u8p), _p(qs, _u64p),
+                                _p(ql, _u32p), n, _p(score, _i32p), _p(begin, _u32p), _p(off, _u64p), _p(cg, _u32p), cap)
+    if rc:
+        raise RuntimeError("oracle verifier failed")
+    return score, begin, off, cg[: int(off[n])].copy()
 
 
 class Index:

@@ -8,6 +8,7 @@
 #include "../../bucket-map_amd/host/bucket_locator.h"
 #include "../../bucket-map_amd/host/cli.h"
 #include "../../bucket-map_amd/host/gpu_q_gram_mapper.h"   // for bm::batched_mapper (host half of map())
+#include "../../oracle/bm_align_oracle.h"
 #include "../../oracle/bm_locator_oracle.h"
 #include "../../oracle/bm_oracle.h"
 
@@ -80,7 +81,30 @@ public:
     }
 };
 
+class oracle_verifier : public bm::alignment_verifier {
+    std::vector<uint8_t> genome_;
+
+public:
+    void load_genome(const uint8_t *bases, uint64_t n_bases) override { genome_.assign(bases, bases + n_bases); }
+    void align(const uint8_t *reads, uint64_t, const uint64_t *text_start, const uint32_t *text_len, const uint8_t *text_rc,
+               const uint64_t *query_start, const uint32_t *query_len, uint32_t n, std::vector<int32_t> &score,
+               std::vector<uint32_t> &begin, std::vector<uint64_t> &cigar_offset, std::vector<uint32_t> &cigar) override {
+        score.assign(n, 0);
+        begin.assign(n, 0);
+        cigar_offset.assign(static_cast<size_t>(n) + 1, 0);
+        uint64_t cap = 0;
+        for (uint32_t a = 0; a < n; a++) cap += static_cast<uint64_t>(text_len[a]) + query_len[a] + 1;
+        cigar.assign(cap, 0);
+        if (bmao_align_batch(genome_.data(), reads, text_start, text_len, text_rc, query_start, query_len, n, score.data(),
+                             begin.data(), cigar_offset.data(), cigar.data(), cap))
+            throw std::runtime_error("oracle verifier failed");
+        cigar.resize(cigar_offset[n]);
+    }
+};
+
 }  // namespace
+
+std::unique_ptr<bm::alignment_verifier> bm_make_verifier(const bm::cmd_arguments &) { return std::make_unique<oracle_verifier>(); }
 
 std::unique_ptr<bm::mapper> bm_make_mapper(const bm::cmd_arguments &args, unsigned int num_buckets, unsigned int fault) {
     return std::make_unique<oracle_mapper>(args, num_buckets, fault);

@@ -37,6 +37,17 @@ def test_locator_abi_symbols():
         assert hasattr(L, n), f"libbmf.so does not export {n}"
 
 
+def test_verifier_abi_symbols():
+    from bucket_map_amd import verify
+    text = open(os.path.join(ROOT, "include", "bmv.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    names = sorted(set(re.findall(r"\b(bmv_[a-z0-9_]+)\s*\(", text)))
+    assert names == sorted(verify.SYMBOLS), "python binding and include/bmv.h disagree"
+    L = verify.lib()
+    for n in names:
+        assert hasattr(L, n), f"libbmf.so does not export {n}"
+
+
 def test_float32_helpers_are_the_reference_derivations():
     L = bma.lib()
     assert L.bmf_fault_from_rate(15, 0.4) == 6
@@ -72,4 +83,5 @@ def test_product_does_not_link_the_oracle():
         for f in files:
             if f.endswith((".py", ".h", ".hip", ".cpp")):
                 text = open(os.path.join(root, f)).read()
-                assert "bm_oracle" not in text and "oracle_c" not in text, f"{f} references the oracle"
+                assert "bm_oracle" not in text and "oracle_c" not in text and "_oracle.h" not in text, \
+                    f"{f} references the oracle"

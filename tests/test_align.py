@@ -1,0 +1,293 @@
+"""Alignment verification (`bucketmap_align`; bucket_locator.h:520-528,560-589).
+
+CPU part: the C oracle (oracle/bm_align_oracle.c) against hand-worked cases, against an independent
+brute force for the score (which is unique), and against the consistency of its own CIGARs; the tie
+rules it ASSUMES of SeqAn3 (last minimal end column; diagonal, then up, then left) are pinned by cases
+built so that the other choice gives a different answer.
+GPU part: the Myers bit-vector kernel (through the C ABI, include/bmv.h) against the oracle, bit-exact:
+score, begin position and CIGAR, for every kernel shape (4/8/16/64 lanes per alignment, 1/2/4 words per
+lane), ragged and degenerate inputs, both strands, several chunks; and the `bucketmap_align` tool against
+the same tool with the oracle plugged in."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import oracle_c as oc
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+COMP = bytes.maketrans(b"ACGT", b"TGCA")
+
+
+def _edit_distance(a: bytes, b: bytes) -> int:
+    prev = list(range(len(b) + 1))
+    for i in range(1, len(a) + 1):
+        cur = [i] + [0] * len(b)
+        for j in range(1, len(b) + 1):
+            cur[j] = min(prev[j - 1] + (a[i - 1] != b[j - 1]), prev[j] + 1, cur[j - 1] + 1)
+        prev = cur
+    return prev[len(b)]
+
+
+def _brute_force(text: bytes, query: bytes):
+    """Best substring by exhaustive search: minimal distance and the LAST end position that reaches it."""
+    best, best_end = None, None
+    for e in range(len(text) + 1):
+        d = min(_edit_distance(query, text[b:e]) for b in range(e + 1))
+        if best is None or d <= best:
+            best, best_end = d, e
+    return best, best_end
+
+
+def _check_cigar(text: bytes, query: bytes, score: int, begin: int, cigar: str):
+    """A CIGAR is right if it consumes the whole query, stays inside the text and costs -score edits."""
+    import re
+    ops = [(int(n), o) for n, o in re.findall(r"(\d+)([MID])", cigar)]
+    assert "".join(f"{n}{o}" for n, o in ops) == cigar
+    i, j, cost = 0, begin, 0
+    for n, o in ops:
+        if o == "M":
+            cost += sum(query[i + x] != text[j + x] for x in range(n))
+            i, j = i + n, j + n
+        elif o == "I":
+            cost, i = cost + n, i + n
+        else:
+            cost, j = cost + n, j + n
+    assert i == len(query) and j <= len(text) and cost == -score
+    assert all(ops[x][1] != ops[x + 1][1] for x in range(len(ops) - 1)), "adjacent runs of one operation"
+    return j
+
+
+# ------------------------------------------------------------------------------------------------ CPU
+
+@pytest.mark.parametrize("text,query,rc,expect", [
+    (b"ACGTACGTAC", b"GTAC", False, (0, 6, "4M")),        # two exact hits: the LAST end column wins (rule 1)
+    (b"AAAA", b"AA", False, (0, 2, "2M")),
+    (b"AG", b"AAG", False, (-1, 0, "1I2M")),              # diagonal before up (rule 2); up first would give 1M1I1M
+    (b"AGC", b"AC", False, (-1, 1, "2M")),                # all three predecessors tie at (A, G): diagonal (a mismatch)
+    (b"CCACGTTCC", b"ACTT", False, (-1, 2, "2M1D2M")),    # ACGT (4M, one mismatch) ends earlier than AC-TT: rule 1
+    (b"TTACGGTCATT", b"ACGTCA", False, (-1, 2, "2M1D4M")),  # gap in a run of G: as far left as the diagonal walk gets
+    (b"TTACGTCATT", b"ACGGTCA", False, (-1, 2, "2M1I4M")),
+    (b"AACCG", b"GGT", True, (0, 1, "3M")),               # text reverse-complemented first: CGGTT
+    (b"ACGT", b"NCGT", False, (0, 0, "4M")),              # N folds to A (dna4)
+    (b"", b"ACG", False, (-3, 0, "3I")),                  # empty text window
+    (b"ACGT", b"", False, (0, 4, "")),                    # empty query: ends at the last column
+    (b"GGGG", b"TT", False, (-2, 2, "2M")),               # nothing matches: two mismatches at the last columns
+])
+def test_oracle_hand_worked_cases(text, query, rc, expect):
+    assert oc.align(text, query, rc) == expect
+
+
+def test_oracle_score_is_the_brute_force_minimum_and_cigars_are_consistent():
+    rng = np.random.default_rng(5)
+    for _ in range(120):
+        n, m = int(rng.integers(0, 14)), int(rng.integers(1, 9))
+        text = bytes(rng.choice(list(b"ACGT"), n).astype(np.uint8))
+        query = bytes(rng.choice(list(b"ACGT"), m).astype(np.uint8))
+        score, begin, cigar = oc.align(text, query)
+        d, end = _brute_force(text, query)
+        assert score == -d
+        assert _check_cigar(text, query, score, begin, cigar) == end      # rule 1: last minimal end column
+
+
+def test_oracle_reverse_complement_is_the_forward_alignment_of_the_flipped_text():
+    rng = np.random.default_rng(6)
+    for _ in range(40):
+        text = bytes(rng.choice(list(b"ACGT"), int(rng.integers(5, 60))).astype(np.uint8))
+        query = bytes(rng.choice(list(b"ACGT"), int(rng.integers(1, 30))).astype(np.uint8))
+        assert oc.align(text, query, True) == oc.align(text.translate(COMP)[::-1], query, False)
+
+
+def test_oracle_batch_layout():
+    genome = np.frombuffer(b"TTACGGTCATTACGTACGTAC", np.uint8)
+    reads = np.frombuffer(b"ACGTCAGTAC", np.uint8)
+    score, begin, off, cg = oc.align_batch(genome, reads, [0, 11], [11, 10], [0, 0], [0, 6], [6, 4])
+    assert score.tolist() == [-1, 0] and begin.tolist() == [2, 6]
+    assert [oc.cigar_string(cg[off[i]:off[i + 1]]) for i in range(2)] == ["2M1D4M", "4M"]
+
+
+# ------------------------------------------------------------------------------------------------ GPU
+
+def _mutate(rng, seq, sub, ins, dele):
+    out = []
+    for c in seq:
+        r = rng.random()
+        if r < dele:
+            continue
+        if r < dele + ins:
+            out.append(int(rng.choice(list(b"ACGT"))))
+        out.append(int(rng.choice(list(b"ACGT"))) if rng.random() < sub else int(c))
+    return np.array(out, np.uint8)
+
+
+def _random_batch(rng, genome, n, max_m, err):
+    """Queries cut from the genome (either strand) and mutated, plus unrelated and degenerate ones."""
+    reads, ts, tl, trc, qs, ql = [], [], [], [], [], []
+    at = 0
+    for a in range(n):
+        m = int(rng.integers(1, max_m + 1))
+        width = m + 1 + int(0.1 * m)
+        start = int(rng.integers(0, len(genome) - width))
+        rc = int(rng.integers(0, 2))
+        kind = a % 10
+        if kind == 0:                                   # unrelated query
+            q = rng.choice(list(b"ACGTNacgt"), m).astype(np.uint8)
+        else:
+            src = genome[start + 1: start + 1 + m]
+            if rc:
+                src = np.frombuffer(bytes(src).translate(COMP)[::-1], np.uint8)
+            q = _mutate(rng, src, *err)
+            if len(q) == 0:
+                q = np.frombuffer(b"A", np.uint8)
+        if kind == 1:
+            width = int(rng.integers(0, 5))             # text much shorter than the query (can be empty)
+        if kind == 2 and a > 20:
+            q = q[:0]                                   # empty query
+        reads.append(q)
+        ts.append(start); tl.append(width); trc.append(rc); qs.append(at); ql.append(len(q))
+        at += len(q)
+    return (np.concatenate(reads) if at else np.zeros(0, np.uint8), np.array(ts, np.uint64), np.array(tl, np.uint32),
+            np.array(trc, np.uint8), np.array(qs, np.uint64), np.array(ql, np.uint32))
+
+
+def _compare(v, genome, batch, what):
+    from bucket_map_amd import verify
+    s_ref, b_ref, o_ref, c_ref = oc.align_batch(genome, *batch)
+    s, b, o, c = v.align(*batch)
+    bad = np.nonzero(s != s_ref)[0]
+    assert bad.size == 0, f"{what}: scores differ at {bad[:10]}: {s[bad[:5]]} vs {s_ref[bad[:5]]}"
+    bad = np.nonzero(b != b_ref)[0]
+    assert bad.size == 0, f"{what}: begin positions differ at {bad[:10]}"
+    assert np.array_equal(o, o_ref), f"{what}: CIGAR lengths differ"
+    assert np.array_equal(c, c_ref), f"{what}: CIGARs differ"
+    return s
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("max_m,n,err", [
+    (150, 600, (0.02, 0.005, 0.005)),       # 4 lanes per alignment
+    (300, 600, (0.02, 0.005, 0.005)),       # 8
+    (500, 300, (0.05, 0.02, 0.02)),         # 8, noisier
+    (1000, 120, (0.03, 0.025, 0.025)),      # 16
+    (3000, 40, (0.03, 0.025, 0.025)),       # 64
+])
+def test_gpu_verifier_matches_oracle(max_m, n, err):
+    from bucket_map_amd import verify
+    rng = np.random.default_rng(max_m)
+    genome = rng.choice(list(b"ACGT"), 200_000).astype(np.uint8)
+    genome[rng.integers(0, len(genome), 200)] = ord("N")
+    v = verify.Verifier()
+    v.load_genome(genome)
+    s = _compare(v, genome, _random_batch(rng, genome, n, max_m, err), f"max_m={max_m}")
+    assert (s > -0.2 * max_m).mean() > 0.5          # most queries really align to their window
+    assert v.stats()["cells"] > 0 and v.stats()["ms_kernels"] > 0
+    v.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("m,n_align", [(6000, 3), (10000, 2), (16384, 1)])     # 2 and 4 words per lane
+def test_gpu_verifier_long_reads(m, n_align):
+    from bucket_map_amd import verify
+    rng = np.random.default_rng(m)
+    genome = rng.choice(list(b"ACGT"), 60_000).astype(np.uint8)
+    reads, ts, tl, trc, qs, ql = [], [], [], [], [], []
+    at = 0
+    for a in range(n_align):
+        start = int(rng.integers(0, 1000))
+        width = m + 1 + int(0.1 * m)
+        src = genome[start + 300: start + 300 + m]
+        rc = a % 2
+        if rc:
+            src = np.frombuffer(bytes(src).translate(COMP)[::-1], np.uint8)
+        q = _mutate(rng, src, 0.03, 0.025, 0.025)[:m]
+        reads.append(q)
+        ts.append(start); tl.append(width); trc.append(rc); qs.append(at); ql.append(len(q))
+        at += len(q)
+    batch = (np.concatenate(reads), np.array(ts, np.uint64), np.array(tl, np.uint32), np.array(trc, np.uint8),
+             np.array(qs, np.uint64), np.array(ql, np.uint32))
+    v = verify.Verifier()
+    v.load_genome(genome)
+    s = _compare(v, genome, batch, f"m={m}")
+    assert (s > -0.15 * m).all()
+    v.close()
+
+
+@pytest.mark.gpu
+def test_gpu_verifier_chunked_equals_one_pass():
+    from bucket_map_amd import verify
+    rng = np.random.default_rng(77)
+    genome = rng.choice(list(b"ACGT"), 100_000).astype(np.uint8)
+    batch = _random_batch(rng, genome, 900, 300, (0.02, 0.005, 0.005))
+    os.environ["BMV_SCRATCH_MB"] = "2"               # a few dozen alignments per chunk
+    try:
+        small = verify.Verifier()
+    finally:
+        del os.environ["BMV_SCRATCH_MB"]
+    small.load_genome(genome)
+    _compare(small, genome, batch, "chunked")
+    small.close()
+
+
+@pytest.mark.gpu
+def test_gpu_verifier_errors():
+    from bucket_map_amd import verify
+    v = verify.Verifier(max_query_len=100, max_text_len=120)
+    z64, z32, z8 = np.zeros(1, np.uint64), np.zeros(1, np.uint32), np.zeros(1, np.uint8)
+    with pytest.raises(verify.BmvError) as e:
+        v.align(np.zeros(10, np.uint8), z64, z32, z8, z64, z32)                     # before load_genome
+    assert e.value.code == 3
+    v.load_genome(np.frombuffer(b"ACGT" * 50, np.uint8))
+    with pytest.raises(verify.BmvError):
+        v.align(np.zeros(10, np.uint8), z64, z32, z8, z64, np.array([11], np.uint32))     # query outside the reads
+    with pytest.raises(verify.BmvError):
+        v.align(np.zeros(10, np.uint8), np.array([190], np.uint64), np.array([20], np.uint32), z8, z64, z32)  # text outside
+    with pytest.raises(verify.BmvError):
+        v.align(np.zeros(200, np.uint8), z64, z32, z8, z64, np.array([101], np.uint32))   # longer than max_query_len
+    s, b, o, c = v.align(np.zeros(0, np.uint8), z64[:0], z32[:0], z8[:0], z64[:0], z32[:0])   # empty batch
+    assert len(s) == 0 and o.tolist() == [0]
+    v.close()
+    with pytest.raises(verify.BmvError):
+        verify.Verifier(max_query_len=20000)
+
+
+def _run(exe, args, cwd, env=None):
+    r = subprocess.run([exe, *args], cwd=str(cwd), capture_output=True, text=True,
+                       env=None if env is None else {**os.environ, **env})
+    assert r.returncode == 0, r.stderr
+    return r.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("profile", ["short", "long"])
+def test_bucketmap_align_sam_identical_to_oracle_backed_run(tmp_path, profile):
+    """`bucketmap_align` end to end: GPU filter + GPU locator scan + GPU verifier against the same tool with the
+    three CPU oracles behind the same interfaces.  Also: CIGARs consume the reads, MAPQ = 60 - edits."""
+    from bucket_map_amd import host
+    gpu_cli = os.path.join(ROOT, "bucket-map_amd", "bucketmap_align")
+    cpu_cli = os.path.join(ROOT, "tests", "cpp", "bucketmap_align_oracle")
+    if profile == "short":
+        g = host.Genome.synth(31, [300_000, 120_000])
+        rd = host.Reads(g, 8192, 150, 150, 2000, sub=0.01, ins=0.002, dele=0.002, seed=9)
+        flags = ["-i", "idx", "--genome", "g.fa", "--bucket-len", "8192", "-r", "150", "-f", "1", "-q", "reads.fastq"]
+    else:   # benchmark/long_read/benchmark_map.sh:25
+        g = host.Genome.synth(32, [1_500_000])
+        rd = host.Reads(g, 262144, 300, 4000, 60, sub=0.03, ins=0.025, dele=0.025, seed=10)
+        flags = ["-i", "idx", "--genome", "g.fa", "--bucket-len", "262144", "-f", "1", "-s", "30", "-e", "0.9", "-n", "0.1",
+                 "-l", "12", "-p", "20", "-u", "5", "-q", "reads.fastq"]
+    g.write_fasta(str(tmp_path / "g.fa"))
+    rd.write_fastq(str(tmp_path / "reads"))
+    err = _run(gpu_cli, [*flags, "-o", "gpu.sam"], tmp_path)
+    assert "Allowing Smith-Waterman" in err and "GPU alignment verification" in err
+    _run(cpu_cli, [*flags, "-o", "cpu.sam"], tmp_path)
+    gpu_sam = (tmp_path / "gpu.sam").read_bytes()
+    assert gpu_sam == (tmp_path / "cpu.sam").read_bytes()
+    import re
+    records = [l.split(b"\t") for l in gpu_sam.split(b"\n") if l and not l.startswith(b"@")]
+    assert len({r[0] for r in records}) > (0.9 if profile == "short" else 0.5) * rd.n
+    for r in records[:500]:
+        ops = re.findall(rb"(\d+)([MID])", r[5])
+        assert sum(int(n) for n, o in ops if o in b"MI") == len(r[9])
+        # 60u + score wraps for more than 60 edits and is written through an 8-bit field (bucket_locator.h:570):
+        # a 4-kbp read at 8 % errors has ~300 edits, so only the short profile stays within 0..60
+        assert profile == "long" or int(r[4]) <= 60

@@ -175,6 +175,59 @@ def test_cli_index_then_map(cli_case):
     assert len(by_read) <= len(truth)
 
 
+def test_cli_align_build(cli_case, tmp_path):
+    """`bucketmap_align` (main.cpp + -DBM_ALIGN, bucket_locator.h:520-528,560-589) with the CPU oracles behind the
+    interfaces: every location verified, MAPQ = 60 + score, CIGAR written, records below -u dropped."""
+    import re
+    d, g, _ = cli_case
+    subprocess.run(["make", "-C", ROOT, "tests/cpp/bucketmap_align_oracle"], check=True, stdout=subprocess.DEVNULL)
+    exe = os.path.join(ROOT, "tests", "cpp", "bucketmap_align_oracle")
+    rd = host.Reads(g, 8192, 150, 150, 600, sub=0.02, ins=0.003, dele=0.003, seed=15)
+    rd.write_fastq(str(tmp_path / "noisy"))
+    common = ["-i", "idx", "--genome", "g.fa", "--bucket-len", "8192", "-r", "150", "-f", "1", "-q", str(tmp_path / "noisy.fastq")]
+    r = run_cli(exe, [*common, "-o", str(tmp_path / "a.sam")], d)
+    assert r.returncode == 0, r.stderr
+    assert "Allowing Smith-Waterman for alignment verifications" in r.stderr
+    header, recs = parse_sam(tmp_path / "a.sam")
+    assert header[0] == "@HD\tVN:1.6" and len(header) == 4
+    truth = [l.split() for l in open(tmp_path / "noisy.position_ground_truth")]
+    comp = bytes.maketrans(b"ACGT", b"TGCA")
+    correct, seen = 0, set()
+    for qname, flag, rname, pos, mapq, cigar, seq, qual in recs:
+        ops = [(int(n), o) for n, o in re.findall(r"(\d+)([MID])", cigar)]
+        assert "".join(f"{n}{o}" for n, o in ops) == cigar and cigar != "*"
+        assert sum(n for n, o in ops if o in "MI") == len(seq) == len(qual)
+        assert 40 <= mapq <= 60                                        # default -u 40 (main.cpp:36): at most 20 edits
+        t = truth[int(qname)]
+        ref, tpos, rc = int(t[0]), int(t[1]), int(t[2])
+        if flag == 0 and rname == f"synth{ref + 1}" and not rc:
+            # forward strand: POS is a genome coordinate; the CIGAR walks the reference and costs 60 - MAPQ edits
+            rec = bytes(g.record_seq(ref))
+            i, j, cost = 0, pos - 1, 0
+            for n, o in ops:
+                if o == "M":
+                    cost += sum(seq[i + x].encode() != rec[j + x: j + x + 1] for x in range(n))
+                    i, j = i + n, j + n
+                elif o == "I":
+                    cost, i = cost + n, i + n
+                else:
+                    cost, j = cost + n, j + n
+            assert cost == 60 - mapq
+            if abs(pos - tpos) <= 6 and qname not in seen:
+                correct += 1
+                seen.add(qname)
+        elif flag == 16 and rname == f"synth{ref + 1}" and rc and qname not in seen:
+            correct += 1                                               # (POS on this strand: see bucket_locator.h:576)
+            seen.add(qname)
+    # (the filter's own sensitivity at 2 % substitutions is ~80 %: reads without a candidate have no record)
+    assert len(seen) > 0.7 * len(truth) and correct >= 0.98 * len({x[0] for x in recs}), f"{correct}/{len(truth)}"
+    # a stricter -u drops records; MAPQ never falls below it
+    r = run_cli(exe, [*common, "-o", str(tmp_path / "b.sam"), "-u", "58"], d)
+    assert r.returncode == 0, r.stderr
+    _, strict = parse_sam(tmp_path / "b.sam")
+    assert 0 < len(strict) < len(recs) and all(x[4] >= 58 for x in strict)
+
+
 def test_cli_error_behaviour(cli_case):
     d, _, _ = cli_case
     exe = build_oracle_cli()
