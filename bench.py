@@ -243,6 +243,8 @@ def main():
         pruned = {"value": world * reads.n * args.steps / pruned_s, "unit": "reads/s", "ms_per_step": pruned_s / args.steps * 1e3,
                   "outputs_identical_to_headline_run": same, "flag": "BMF_FLAG_EARLY_EXIT",
                   "pass1_rows": fp.info()["pass1_rows"]}
+        if pruned["pass1_rows"]:
+            pruned["items_recounted"], pruned["items_slow_path"] = bp.pass2_counts()
         bp.close()
         fp.close()
 

@@ -17,6 +17,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -97,19 +98,39 @@ vote_fn pick_vote(int cpl, int planes, bool prune) {
 }
 
 // two-pass exact pruning (bmf_vote2.hip.h), unsliced geometries only
-template <int CPL>
-vote_fn pick_planes2(int planes) {
+using pass1_fn = void (*)(bmf::DevParams, const uint8_t *, const uint32_t *, const uint32_t *, uint32_t *, bmf::Pass2Queue);
+using recount_fn = void (*)(bmf::DevParams, const uint8_t *, const uint32_t *, uint32_t, uint32_t *, uint32_t *, bmf::Pass2Queue);
+using slow_fn = void (*)(bmf::DevParams, const uint8_t *, const uint32_t *, uint32_t *, uint32_t *, bmf::Pass2Queue);
+
+struct TwoPass {
+    pass1_fn pass1 = nullptr;
+    recount_fn recount = nullptr;
+    slow_fn slow = nullptr;
+};
+
+template <int CPL, int PLANES>
+TwoPass two_pass_of() {
     constexpr int D = depth_for(CPL);
-    switch (planes) {
-    case 2: return bmf::bmf_vote2_kernel<CPL, 2, D>;
-    case 3: return bmf::bmf_vote2_kernel<CPL, 3, D>;
-    case 4: return bmf::bmf_vote2_kernel<CPL, 4, D>;
-    case 5: return bmf::bmf_vote2_kernel<CPL, 5, D>;
+    pass1_fn p1 = bmf::bmf_pass1_kernel<CPL, PLANES, D>;
+    if constexpr (D > 2) {
+        const char *env = getenv("BMF_PASS1_SHALLOW");
+        if (env && env[0] == '1') p1 = bmf::bmf_pass1_kernel<CPL, PLANES, D - 1>;
     }
-    return nullptr;
+    return {p1, bmf::bmf_recount_kernel<PLANES>, bmf::bmf_vote2_slow_kernel<CPL, PLANES, D>};
 }
 
-vote_fn pick_vote2(int cpl, int planes) {
+template <int CPL>
+TwoPass pick_planes2(int planes) {
+    switch (planes) {
+    case 2: return two_pass_of<CPL, 2>();
+    case 3: return two_pass_of<CPL, 3>();
+    case 4: return two_pass_of<CPL, 4>();
+    case 5: return two_pass_of<CPL, 5>();
+    }
+    return {};
+}
+
+TwoPass pick_vote2(int cpl, int planes) {
     switch (cpl) {
     case 1: return pick_planes2<1>(planes);
     case 2: return pick_planes2<2>(planes);
@@ -120,7 +141,7 @@ vote_fn pick_vote2(int cpl, int planes) {
     case 7: return pick_planes2<7>(planes);
     case 8: return pick_planes2<8>(planes);
     }
-    return nullptr;
+    return {};
 }
 
 // P[Bin(n, p) >= m]
@@ -166,6 +187,8 @@ struct bmf_batch {
     DevBuf<uint64_t> win_start;
     DevBuf<uint32_t> win_len, lists, list_n, rows_anded, counts, buckets, offsets, compact;
     DevBuf<uint32_t> slice_min, slice_cnt, slice_ids;   // NB > 65 536 only
+    DevBuf<uint32_t> q_counters, q_slow, q_live_n;   // two-pass pruning only (bmf::Pass2Queue)
+    DevBuf<uint16_t> q_live_chunks;
 };
 
 struct bmf_ctx {
@@ -186,6 +209,7 @@ struct bmf_ctx {
     int cpl = 0, planes = 0, depth = 0;
     uint32_t n_slices = 1;           // > 1 when NB > 65 536: one wave per (item, 65 536-bucket slice)
     vote_fn vote = nullptr;
+    TwoPass two_pass;                // used instead of `vote` when dp.pass1_rows > 0
     size_t sample_lds = 0;
     // profiling
     bool profiling = false;
@@ -378,8 +402,8 @@ static int select_pruned_variant(bmf_ctx *c) {
     double best = 0.95 * prune_cost;
     for (uint32_t r = 1; r < d.G; r++) {
         const double live = (double)d.nb * binom_tail(d.S, pow(dens, (double)r), d.S - d.F + 1u);
-        if (live > 24.0) continue;   // beyond one lane per live chunk the recount falls back to whole rows
-        const double cost = (double)d.S * r * row_bytes + live * d.S * (r + 1.0) * sector + (double)d.S * d.G * sector;
+        if (live > 20.0) continue;   // more than kMaxLive live chunks send an item down the slow path
+        const double cost = (double)d.S * r * row_bytes + live * d.S * sector + 1.3 * d.S * d.G * sector;
         if (cost < best) {
             best = cost;
             best_r = r;
@@ -390,8 +414,8 @@ static int select_pruned_variant(bmf_ctx *c) {
         best_r = v > 0 && (uint32_t)v < d.G ? (uint32_t)v : 0u;
     }
     if (best_r) {
-        c->dp.pass1_rows = best_r;
-        c->vote = pick_vote2(c->cpl, c->planes);
+        c->two_pass = pick_vote2(c->cpl, c->planes);
+        if (c->two_pass.pass1) c->dp.pass1_rows = best_r;
     }
     return BMF_OK;
 }
@@ -618,6 +642,7 @@ void bmf_batch_destroy(bmf_ctx *c, bmf_batch *b) {
     b->lists.release(); b->list_n.release(); b->rows_anded.release(); b->counts.release(); b->buckets.release();
     b->offsets.release(); b->compact.release();
     b->slice_min.release(); b->slice_cnt.release(); b->slice_ids.release();
+    b->q_counters.release(); b->q_slow.release(); b->q_live_n.release(); b->q_live_chunks.release();
     delete b;
 }
 
@@ -694,7 +719,27 @@ int bmf_batch_run(bmf_ctx *c, bmf_batch *b) {
                        b->bases.p, b->quals.p, b->win_start.p, b->win_len.p, c->d_lut, c->d_qgram_ok, c->d_k2i, c->d_pos_table,
                        b->lists.p, b->list_n.p, b->rows_anded.p);
     if (prof) HIP_TRY(hipEventRecord(ev[1], c->stream));
-    if (c->n_slices == 1) {
+    if (c->dp.pass1_rows) {
+        // two-pass pruning: full-width lower-bound pass, then the queued items' exact recount (bmf_vote2.hip.h)
+        const size_t n_items = 2 * (size_t)b->n_windows;
+        HIP_TRY(b->q_counters.need(2));
+        HIP_TRY(b->q_slow.need(n_items));
+        HIP_TRY(b->q_live_n.need(n_items));
+        HIP_TRY(b->q_live_chunks.need(n_items * bmf::kMaxLive));
+        HIP_TRY(hipMemsetAsync(b->q_counters.p, 0, 2 * sizeof(uint32_t), c->stream));
+        const bmf::Pass2Queue q{b->q_counters.p, b->q_slow.p, b->q_live_n.p, b->q_live_chunks.p};
+        hipLaunchKernelGGL(c->two_pass.pass1, dim3(2 * b->n_windows), dim3(bmf::kWave), 0, c->stream, c->dp, c->d_rows,
+                           b->lists.p, b->list_n.p, b->counts.p, q);
+        // fixed grids: the recount walks all items (most keep a few live chunks), the slow kernel strides over
+        // the queue length it reads from HBM -- nothing comes back to the host in between
+        const unsigned recount_blocks = (unsigned)std::min<size_t>((n_items + 1) / 2, 32768);
+        const size_t recount_lds = 2 * (size_t)c->dp.S * c->dp.G * sizeof(uint32_t);
+        hipLaunchKernelGGL(c->two_pass.recount, dim3(recount_blocks), dim3(bmf::kWave), recount_lds, c->stream, c->dp, c->d_rows,
+                           b->lists.p, (uint32_t)n_items, b->counts.p, b->buckets.p, q);
+        const unsigned slow_blocks = (unsigned)std::min<size_t>(n_items, 2048);
+        hipLaunchKernelGGL(c->two_pass.slow, dim3(slow_blocks), dim3(bmf::kWave), 0, c->stream, c->dp, c->d_rows, b->lists.p,
+                           b->counts.p, b->buckets.p, q);
+    } else if (c->n_slices == 1) {
         hipLaunchKernelGGL(c->vote, dim3(2 * b->n_windows), dim3(bmf::kWave), 0, c->stream, c->dp, c->d_rows, b->lists.p,
                            b->list_n.p, b->counts.p, b->buckets.p, (uint32_t *)nullptr);
     } else {
@@ -833,6 +878,17 @@ int bmf_info(bmf_ctx *c, uint32_t *row_pitch_bytes, uint32_t *chunks_per_lane, u
     if (chunks_per_lane) *chunks_per_lane = (uint32_t)c->cpl;
     if (planes) *planes = (uint32_t)c->planes;
     if (rows_in_flight) *rows_in_flight = (uint32_t)c->depth;
+    return BMF_OK;
+}
+
+int bmf_batch_pass2_counts(bmf_ctx *c, bmf_batch *b, uint32_t *recounted, uint32_t *slow) {
+    if (!c || !b) return fail(BMF_ERR_ARG, "bmf_batch_pass2_counts: null argument");
+    uint32_t v[2] = {0, 0};
+    HIP_TRY(hipSetDevice(c->p.device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->dp.pass1_rows && b->q_counters.p) HIP_TRY(hipMemcpy(v, b->q_counters.p, sizeof v, hipMemcpyDeviceToHost));
+    if (recounted) *recounted = v[0];
+    if (slow) *slow = v[1];
     return BMF_OK;
 }
 

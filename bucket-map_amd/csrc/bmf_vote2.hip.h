@@ -4,41 +4,86 @@
 // of FEWER rows has MORE bits set, so the miss count of a bucket computed from only r of the G q-gram rows
 // of every sample is a LOWER bound of its true miss count.
 //
-//   pass 1 : stream r rows per sample at full width (S*r rows instead of S*G).  A bucket whose lower bound
-//            already reaches F is dead for good (q_gram_mapper.h:75-102: it is in no level of the filter).
-//            For a 22 %-dense index and the default S=15, F=6, r=1 leaves a handful of live buckets.
-//   pass 2 : the exact miss counts of the few 128-bucket chunks that still hold a live bucket, from ALL
-//            S*G rows but only 16 bytes of each: lane i takes live chunk i and streams its 16-byte column
-//            (up to 64 live chunks, 16-32 rows in flight), first with r+1 rows per sample, which kills most
-//            chunks that survived pass 1 by chance, then with all G.  With more than 64 live chunks the
-//            exact recount falls back to the predicated full-layout stream of the PRUNE kernel.
-//   emit   : best_results over the exact counts (dead buckets keep a count >= F and can never be in it).
+//   bmf_pass1_kernel    one wave per (window, orientation): streams r rows per sample at full width (S*r
+//                       rows instead of S*G).  A bucket whose lower bound already reaches F is dead for good
+//                       (q_gram_mapper.h:75-102: it is in no level of the filter).  No live bucket: the
+//                       result is empty, done.  Otherwise the ids of the 128-bucket chunks that still hold a
+//                       live bucket go to HBM (ascending, <= kMaxLive of them) with their number.
+//   bmf_recount_kernel  kMaxLive lanes per item, two items per wave: lane i recounts live chunk i
+//                       exactly from its 16-byte column of ALL S*G rows -- after one more lower bound from a
+//                       row per sample that pass 1 has not seen, which kills most chunks that survived
+//                       pass 1 by chance for S sectors instead of S*G -- and the
+//                       group emits best_results over the exact counts.  Small register footprint, so many
+//                       waves hide the latency of these short dependent streams.
+//   bmf_vote2_slow_kernel  the rare items with more than kMaxLive live chunks: pass 1 again, then the exact
+//                       recount at full width with loads predicated per chunk (or one lane per chunk up to 64).
+//
+// Almost every item keeps a few live chunks after pass 1 (a handful of unrelated buckets survive by chance),
+// so the recount kernel simply walks all items and reads their live counts -- a queue would cost one atomic
+// on one address per item, which alone is slower than pass 1.  Only the rare slow items are queued; their
+// kernel runs a fixed grid and strides over the queue length it reads from HBM, so nothing is read back by
+// the host between the launches.
 //
 // r is chosen on the host from the measured density of the index rows (bmf_api.hip), so that the expected
-// number of live buckets after pass 1 stays small; r == G means "no gain", and the PRUNE kernel is used.
+// number of live buckets after pass 1 stays small; when no r < G pays, the single-pass PRUNE kernel is used.
 #pragma once
 
 #include "bmf_kernels.hip.h"
 
 namespace bmf {
 
-// rows in flight in the 16-byte-column recount: as many as the registers pass 1 no longer needs can hold
-constexpr int depth2_for(int cpl) { return cpl >= 3 && cpl <= 5 ? 32 : 16; }
+constexpr int kMaxLive = 32;    // live chunks (= lanes) per item in the recount kernel
+constexpr int kDepthCol = 16;   // rows in flight in a 16-byte-column stream
 
-// Streams `n_rows` rows through a DEPTH-deep ring: list entry of row t is list[(t / r) * G + t % r]
-// (r rows of every sample; r == G walks the whole list).  ACT: per-slot load predicate.
-template <int CPL, int PLANES, int DEPTH, bool EXIT>
+constexpr uint32_t kSlowItem = 0xFFFFFFFFu;   // live_n of an item that went to the slow queue
+
+struct Pass2Queue {
+    uint32_t *counters;         // [0] items bmf_recount_kernel has work for (statistics), [1] length of slow_items
+    uint32_t *slow_items;
+    uint32_t *live_n;           // per item: live chunks after pass 1 (0: result already final), or kSlowItem
+    uint16_t *live_chunks;      // per item: kMaxLive chunk ids, ascending
+};
+
+// Counters in this file are BIASED: a bucket starts at 2^PLANES-1-F instead of 0, so that "F misses or more"
+// is exactly "the saturating counter is all ones" -- one AND per plane instead of a bit-sliced comparison
+// (the argmin and its ties do not move; emit_best is handed F = 2^PLANES-1 to match).
+template <int PLANES>
+__device__ __forceinline__ uint32_t start_word(const DevParams &P, uint32_t bucket_bits, int p) {
+    const uint32_t bias = (1u << PLANES) - 1u - P.F;
+    return ~bucket_bits | (((bias >> p) & 1u) ? 0xFFFFFFFFu : 0u);   // bits that are no bucket: saturated
+}
+template <int CPL, int PLANES>
+__device__ __forceinline__ uint32_t alive_word(const u128 (&cnt)[PLANES][CPL], int j, int x) {
+    uint32_t sat = cnt[0][j].v[x];
+#pragma unroll
+    for (int p = 1; p < PLANES; p++) sat &= cnt[p][j].v[x];
+    return ~sat;
+}
+template <int PLANES>
+__device__ __forceinline__ DevParams for_emit(const DevParams &P) {
+    DevParams E = P;
+    E.F = (1u << PLANES) - 1u;
+    return E;
+}
+
+// Streams S*r rows through a DEPTH-deep ring: r rows of every sample (list entries s*G + g, g < r;
+// r == G walks the whole list).  PRED: act is a per-slot load predicate (an inactive slot ANDs zeros, which
+// only pushes counters that are >= F already further up); without it every slot loads (coff is clamped to
+// the row, as in bmf_vote_kernel).  EXIT: stop when every bucket has >= F misses.
+template <int CPL, int PLANES, int DEPTH, bool EXIT, bool PRED = true>
 __device__ __forceinline__ bool stream_rows(const DevParams &P, const uint8_t *__restrict__ rows,
                                             const uint32_t *__restrict__ list, uint32_t r, const uint32_t (&coff)[CPL],
                                             const bool (&act)[CPL], u128 (&cnt)[PLANES][CPL]) {
     const uint32_t n_rows = P.S * r;
     u128 ring[DEPTH][CPL];
+    if (PRED) {
 #pragma unroll
-    for (int d = 0; d < DEPTH; d++)
+        for (int d = 0; d < DEPTH; d++)
 #pragma unroll
-        for (int j = 0; j < CPL; j++)
+            for (int j = 0; j < CPL; j++)
 #pragma unroll
-            for (int x = 0; x < 4; x++) ring[d][j].v[x] = 0;
+                for (int x = 0; x < 4; x++) ring[d][j].v[x] = 0;
+    }
     uint32_t ps = 0, pg = 0;   // prefetch cursor: sample, q-gram
     auto next_row = [&]() -> const uint8_t * {
         const uint8_t *rp = rows + (size_t)list[ps * P.G + pg] * P.pitch;
@@ -54,7 +99,7 @@ __device__ __forceinline__ bool stream_rows(const DevParams &P, const uint8_t *_
             const uint8_t *rp = next_row();
 #pragma unroll
             for (int j = 0; j < CPL; j++)
-                if (act[j]) ring[d][j] = load_chunk(rp + coff[j]);
+                if (!PRED || act[j]) ring[d][j] = load_chunk(rp + coff[j]);
         }
     }
     u128 bf[CPL];
@@ -63,6 +108,7 @@ __device__ __forceinline__ bool stream_rows(const DevParams &P, const uint8_t *_
 #pragma unroll
         for (int x = 0; x < 4; x++) bf[j].v[x] = 0xFFFFFFFFu;
     uint32_t g = 0, samples_done = 0;
+    bool check = false;
     for (uint32_t t = 0; t < n_rows; t += DEPTH) {
 #pragma unroll
         for (int d = 0; d < DEPTH; d++) {
@@ -75,46 +121,94 @@ __device__ __forceinline__ bool stream_rows(const DevParams &P, const uint8_t *_
                     const uint8_t *rp = next_row();
 #pragma unroll
                     for (int j = 0; j < CPL; j++)
-                        if (act[j]) ring[d][j] = load_chunk(rp + coff[j]);
+                        if (!PRED || act[j]) ring[d][j] = load_chunk(rp + coff[j]);
                 }
                 if (++g == r) {
                     g = 0;
                     count_misses<CPL, PLANES>(bf, cnt);
                     ++samples_done;
-                    if (EXIT && samples_done >= P.F && samples_done < P.S) {
-                        uint32_t alive = 0;
-#pragma unroll
-                        for (int j = 0; j < CPL; j++)
-#pragma unroll
-                            for (int x = 0; x < 4; x++) alive |= ~count_ge<CPL, PLANES>(cnt, j, x, P.F);
-                        if (__ballot(alive != 0) == 0) return false;   // every bucket is dead: result is empty
-                    }
+                    check = true;
                 }
             }
+        }
+        // once per ring round (one copy of this code instead of DEPTH): is any bucket still below F misses?
+        if (EXIT && check && samples_done >= P.F && samples_done < P.S) {
+            uint32_t alive = 0;
+#pragma unroll
+            for (int j = 0; j < CPL; j++)
+#pragma unroll
+                for (int x = 0; x < 4; x++) alive |= alive_word<CPL, PLANES>(cnt, j, x);
+            if (__ballot(alive != 0) == 0) return false;   // every bucket is dead: result is empty
+        }
+        check = false;
+    }
+    return true;
+}
+
+// Pass 1's stream, branch-free like bmf_vote_kernel's: every slot loads (coff is clamped to the row) and the
+// row ids past the last one are the all-ones row, so the compiler can wait for exactly the oldest row in
+// flight and the kernel needs fewer registers than the predicated form.  The all-dead test runs once per
+// ring round (one copy of that code instead of DEPTH).
+template <int CPL, int PLANES, int DEPTH>
+__device__ __forceinline__ bool stream_pass1(const DevParams &P, const uint8_t *__restrict__ rows,
+                                             const uint32_t *__restrict__ list, uint32_t r, const uint32_t (&coff)[CPL],
+                                             u128 (&cnt)[PLANES][CPL]) {
+    const uint32_t n_rows = P.S * r;
+    const uint32_t n_iter = (n_rows + DEPTH - 1) / DEPTH * DEPTH;
+    u128 ring[DEPTH][CPL];
+    uint32_t ps = 0, pg = 0;
+    auto next_row = [&]() -> const uint8_t * {
+        const uint32_t id = ps < P.S ? list[ps * P.G + pg] : P.ones_row;
+        if (++pg == r) {
+            pg = 0;
+            ++ps;
+        }
+        return rows + (size_t)id * P.pitch;
+    };
+#pragma unroll
+    for (int d = 0; d < DEPTH; d++) {
+        const uint8_t *rp = next_row();
+#pragma unroll
+        for (int j = 0; j < CPL; j++) ring[d][j] = load_chunk(rp + coff[j]);
+    }
+    u128 bf[CPL];
+#pragma unroll
+    for (int j = 0; j < CPL; j++)
+#pragma unroll
+        for (int x = 0; x < 4; x++) bf[j].v[x] = 0xFFFFFFFFu;
+    uint32_t g = 0, samples_done = 0;
+    for (uint32_t t = 0; t < n_iter; t += DEPTH) {
+#pragma unroll
+        for (int d = 0; d < DEPTH; d++) {
+#pragma unroll
+            for (int j = 0; j < CPL; j++)
+#pragma unroll
+                for (int x = 0; x < 4; x++) bf[j].v[x] &= ring[d][j].v[x];
+            const uint8_t *rp = next_row();
+#pragma unroll
+            for (int j = 0; j < CPL; j++) ring[d][j] = load_chunk(rp + coff[j]);
+            if (++g == r) {
+                g = 0;
+                count_misses<CPL, PLANES>(bf, cnt);
+                ++samples_done;
+            }
+        }
+        if (samples_done >= P.F && samples_done < P.S) {
+            uint32_t alive = 0;
+#pragma unroll
+            for (int j = 0; j < CPL; j++)
+#pragma unroll
+                for (int x = 0; x < 4; x++) alive |= alive_word<CPL, PLANES>(cnt, j, x);
+            if (__ballot(alive != 0) == 0) return false;
         }
     }
     return true;
 }
 
-template <int CPL, int PLANES, int DEPTH>
-__global__ __launch_bounds__(kWave) void bmf_vote2_kernel(DevParams P, const uint8_t *__restrict__ rows,
-                                                         const uint32_t *__restrict__ row_lists,
-                                                         const uint32_t *__restrict__ list_n,
-                                                         uint32_t *__restrict__ out_counts,
-                                                         uint32_t *__restrict__ out_buckets, uint32_t *__restrict__) {
-    constexpr int kDepth2 = depth2_for(CPL);
-    __shared__ uint32_t live_chunk[kWave];
-    const uint32_t item = blockIdx.x;          // 2*window + orientation
-    const uint32_t lane = threadIdx.x;
-    if (list_n[item >> 1] == 0) {              // window rejected by the sample kernel
-        if (lane == 0) out_counts[item] = 0;
-        return;
-    }
-    const uint32_t *__restrict__ list = row_lists + (size_t)item * P.list_len;
-
-    uint32_t cidx[CPL], coff[CPL];
-    bool act[CPL];
-    u128 cnt[PLANES][CPL];
+// Slot layout of a full-width wave and its counters at "no sample seen yet".
+template <int CPL, int PLANES>
+__device__ __forceinline__ void full_width_slots(const DevParams &P, uint32_t lane, uint32_t (&cidx)[CPL],
+                                                 uint32_t (&coff)[CPL], bool (&act)[CPL], u128 (&cnt)[PLANES][CPL]) {
 #pragma unroll
     for (int j = 0; j < CPL; j++) {
         cidx[j] = lane + kWave * j;
@@ -122,25 +216,247 @@ __global__ __launch_bounds__(kWave) void bmf_vote2_kernel(DevParams P, const uin
         coff[j] = (act[j] ? cidx[j] : P.n_chunks - 1u) * 16u;
 #pragma unroll
         for (int x = 0; x < 4; x++) {
-            const uint32_t dead = ~bucket_mask(P, cidx[j], x);   // non-bucket bits: saturated from the start
+            const uint32_t bits = bucket_mask(P, cidx[j], x);
 #pragma unroll
-            for (int p = 0; p < PLANES; p++) cnt[p][j].v[x] = dead;
+            for (int p = 0; p < PLANES; p++) cnt[p][j].v[x] = start_word<PLANES>(P, bits, p);
         }
     }
+}
 
-    // ---- pass 1: lower bounds of the miss counts from r rows per sample
+template <int CPL, int PLANES, int DEPTH>
+__device__ __forceinline__ void pass1_item(const DevParams &P, const uint8_t *__restrict__ rows,
+                                           const uint32_t *__restrict__ row_lists, const uint32_t *__restrict__ list_n,
+                                           uint32_t *__restrict__ out_counts, const Pass2Queue &Q) {
+    const uint32_t item = blockIdx.x;          // 2*window + orientation
+    const uint32_t lane = threadIdx.x;
+    if (list_n[item >> 1] == 0) {              // window rejected by the sample kernel
+        if (lane == 0) {
+            out_counts[item] = 0;
+            Q.live_n[item] = 0;
+        }
+        return;
+    }
+    const uint32_t *__restrict__ list = row_lists + (size_t)item * P.list_len;
+    uint32_t cidx[CPL], coff[CPL];
+    bool act[CPL];
+    u128 cnt[PLANES][CPL];
+    full_width_slots<CPL, PLANES>(P, lane, cidx, coff, act, cnt);
+    if (!stream_pass1<CPL, PLANES, DEPTH>(P, rows, list, P.pass1_rows, coff, cnt)) {
+        if (lane == 0) {
+            out_counts[item] = 0;
+            Q.live_n[item] = 0;
+        }
+        return;
+    }
+    // chunks that still hold a bucket with < F misses, in ascending chunk order
+    uint32_t n_live = 0;
+#pragma unroll
+    for (int j = 0; j < CPL; j++) {
+        uint32_t a = 0;
+#pragma unroll
+        for (int x = 0; x < 4; x++) a |= alive_word<CPL, PLANES>(cnt, j, x);
+        const bool live = a != 0;
+        const uint64_t m = __ballot(live);
+        const uint32_t at = n_live + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        if (live && at < (uint32_t)kMaxLive) Q.live_chunks[(size_t)item * kMaxLive + at] = (uint16_t)cidx[j];
+        n_live += (uint32_t)__popcll(m);
+    }
+    if (lane == 0) {
+        if (n_live == 0) out_counts[item] = 0;
+        if (n_live > (uint32_t)kMaxLive) {
+            Q.slow_items[atomicAdd(&Q.counters[1], 1u)] = item;
+            n_live = kSlowItem;
+        }
+        Q.live_n[item] = n_live;
+    }
+}
+
+template <int CPL, int PLANES, int DEPTH>
+__global__ __launch_bounds__(kWave) void bmf_pass1_kernel(DevParams P, const uint8_t *__restrict__ rows,
+                                                         const uint32_t *__restrict__ row_lists,
+                                                         const uint32_t *__restrict__ list_n,
+                                                         uint32_t *__restrict__ out_counts, Pass2Queue Q) {
+    pass1_item<CPL, PLANES, DEPTH>(P, rows, row_lists, list_n, out_counts, Q);
+}
+
+// best_results (q_gram_mapper.h:90-102,471-476) over the kMaxLive lanes of one item: lane i holds the exact
+// counters of one 128-bucket chunk, chunks ascending with the lane.  Group-wide steps use wave ballots
+// masked to the group, so the two items of a wave need not agree on anything.
+template <int PLANES>
+__device__ __forceinline__ void emit_best_group(const DevParams &P, const u128 (&cnt)[PLANES], bool have, uint32_t item,
+                                                uint32_t lane, uint32_t chunk, uint32_t *__restrict__ out_counts,
+                                                uint32_t *__restrict__ out_buckets) {
+    const uint32_t gl = lane % kMaxLive;
+    const uint64_t gmask = ((1ull << kMaxLive) - 1ull) << (lane - gl);
+    uint32_t cand[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+    uint32_t m_min = 0;
+#pragma unroll
+    for (int p = PLANES - 1; p >= 0; p--) {
+        uint32_t any = 0;
+#pragma unroll
+        for (int x = 0; x < 4; x++) any |= cand[x] & ~cnt[p].v[x];
+        const bool some = (__ballot(any != 0) & gmask) != 0;     // a candidate with a 0 in this plane
+#pragma unroll
+        for (int x = 0; x < 4; x++) cand[x] = some ? cand[x] & ~cnt[p].v[x] : cand[x];
+        m_min |= some ? 0u : 1u << p;
+    }
+    const uint32_t pc = __popc(cand[0]) + __popc(cand[1]) + __popc(cand[2]) + __popc(cand[3]);
+    uint32_t incl = pc;
+#pragma unroll
+    for (int o = 1; o < kMaxLive; o <<= 1) {
+        const uint32_t t = __shfl_up(incl, o, kMaxLive);
+        if (gl >= (uint32_t)o) incl += t;
+    }
+    const uint32_t total = __shfl(incl, kMaxLive - 1, kMaxLive);
+    if (!have) return;
+    if (m_min == (1u << PLANES) - 1u || total > P.max_cand) {   // biased counters: all ones = F misses or more
+        if (gl == 0) out_counts[item] = 0;
+        return;
+    }
+    uint32_t *__restrict__ out = out_buckets + (size_t)item * P.max_cand;
+    uint32_t pos = incl - pc;
+#pragma unroll
+    for (int x = 0; x < 4; x++) {
+        uint32_t bits = cand[x];
+        while (bits) {
+            out[pos++] = chunk * 128u + x * 32u + (uint32_t)__builtin_ctz(bits);
+            bits &= bits - 1u;
+        }
+    }
+    if (gl == 0) out_counts[item] = total;
+}
+
+// S*r rows of a 16-byte column per lane -- rows g0 .. g0+r-1 of every sample; every lane has its own row-id
+// list (its item's).
+template <int PLANES>
+__device__ __forceinline__ void stream_column(const DevParams &P, const uint8_t *__restrict__ rows,
+                                              const uint32_t *__restrict__ list, uint32_t g0, uint32_t r, uint32_t off,
+                                              bool act, u128 (&cnt)[PLANES]) {
+    const uint32_t n_rows = P.S * r;
+    u128 ring[kDepthCol];
+#pragma unroll
+    for (int d = 0; d < kDepthCol; d++)
+#pragma unroll
+        for (int x = 0; x < 4; x++) ring[d].v[x] = 0;
+    uint32_t ps = 0, pg = 0;
+    auto fetch = [&](u128 &dst) {
+        if (act) dst = load_chunk(rows + (size_t)list[ps * P.G + g0 + pg] * P.pitch + off);
+        if (++pg == r) {
+            pg = 0;
+            ++ps;
+        }
+    };
+#pragma unroll
+    for (int d = 0; d < kDepthCol; d++)
+        if ((uint32_t)d < n_rows) fetch(ring[d]);
+    u128 bf[1];
+    u128 c1[PLANES][1];
+#pragma unroll
+    for (int x = 0; x < 4; x++) bf[0].v[x] = 0xFFFFFFFFu;
+#pragma unroll
+    for (int p = 0; p < PLANES; p++) c1[p][0] = cnt[p];
+    uint32_t g = 0;
+    for (uint32_t t = 0; t < n_rows; t += kDepthCol) {
+#pragma unroll
+        for (int d = 0; d < kDepthCol; d++) {
+            if (t + d < n_rows) {
+#pragma unroll
+                for (int x = 0; x < 4; x++) bf[0].v[x] &= ring[d].v[x];
+                if (t + d + kDepthCol < n_rows) fetch(ring[d]);
+                if (++g == r) {
+                    g = 0;
+                    count_misses<1, PLANES>(bf, c1);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < PLANES; p++) cnt[p] = c1[p][0];
+}
+
+template <int PLANES>
+__global__ __launch_bounds__(kWave) void bmf_recount_kernel(DevParams P, const uint8_t *__restrict__ rows,
+                                                           const uint32_t *__restrict__ row_lists, uint32_t n_items,
+                                                           uint32_t *__restrict__ out_counts,
+                                                           uint32_t *__restrict__ out_buckets, Pass2Queue Q) {
+    extern __shared__ uint32_t lds_lists[];      // the row-id lists of the wave's two items: every lane of a
+    constexpr uint32_t kPerWave = kWave / kMaxLive;   // group reads the same entry at every step
+    const uint32_t lane = threadIdx.x, grp = lane / kMaxLive, gl = lane % kMaxLive;
+    const uint32_t n_ids = P.S * P.G;
+    uint32_t *list = lds_lists + grp * n_ids;
+    uint32_t recounted = 0;
+    for (uint32_t base = blockIdx.x * kPerWave; base < n_items; base += gridDim.x * kPerWave) {
+        const uint32_t item = base + grp;
+        uint32_t n_live = item < n_items ? Q.live_n[item] : 0u;
+        if (n_live == kSlowItem) n_live = 0;
+        const bool have = n_live != 0;
+        if (__ballot(have) == 0) continue;       // both results are final already
+        recounted += (have && gl == 0) ? 1u : 0u;
+        __syncthreads();                          // (one wave per block: orders the LDS reuse between rounds)
+        if (have)
+            for (uint32_t i = gl; i < n_ids; i += kMaxLive) list[i] = row_lists[(size_t)item * P.list_len + i];
+        __syncthreads();
+        const bool mine = gl < n_live;
+        const uint32_t chunk = mine ? Q.live_chunks[(size_t)item * kMaxLive + gl] : 0u;
+        u128 cnt[PLANES];
+        auto reset = [&](bool on) {
+#pragma unroll
+            for (int x = 0; x < 4; x++) {
+                const uint32_t bits = on ? bucket_mask(P, chunk, x) : 0u;
+#pragma unroll
+                for (int p = 0; p < PLANES; p++) cnt[p].v[x] = start_word<PLANES>(P, bits, p);
+            }
+        };
+        reset(mine);
+        bool act = mine;
+        // First one row per sample that pass 1 has NOT seen, on its own: its miss count is an independent lower
+        // bound, so a chunk that survived pass 1 by chance (probability ~1e-4 per bucket) dies here with the
+        // same odds, for S sectors instead of G*S.  Not worth a dependent round of loads when there is next
+        // to nothing to kill.
+        if (P.pass1_rows + 1u < P.G) {
+            const bool thin = mine && n_live > 3u;
+            stream_column<PLANES>(P, rows, list, P.pass1_rows, 1u, chunk * 16u, thin, cnt);
+            if (thin) {
+                u128 c1[PLANES][1];
+#pragma unroll
+                for (int p = 0; p < PLANES; p++) c1[p][0] = cnt[p];
+                uint32_t a = 0;
+#pragma unroll
+                for (int x = 0; x < 4; x++) a |= alive_word<1, PLANES>(c1, 0, x);
+                act = a != 0;
+            }
+            reset(act);
+        }
+        stream_column<PLANES>(P, rows, list, 0u, P.G, chunk * 16u, act, cnt);
+        emit_best_group<PLANES>(P, cnt, have, item, lane, chunk, out_counts, out_buckets);
+    }
+    // statistics only (bmf_batch_pass2_counts): one atomic per wave, not per item
+    recounted += (uint32_t)__shfl_xor((int)recounted, kMaxLive, kWave);
+    if (lane == 0 && recounted) atomicAdd(&Q.counters[0], recounted);
+}
+
+// One item the slow way: pass 1, then the exact recount of the live chunks -- one lane per chunk up to 64,
+// else at full width with loads predicated per chunk.
+template <int CPL, int PLANES, int DEPTH>
+__device__ __forceinline__ void vote2_item(const DevParams &P, const uint8_t *__restrict__ rows,
+                                           const uint32_t *__restrict__ list, uint32_t item, uint32_t lane,
+                                           uint32_t *live_chunk, uint32_t *__restrict__ out_counts,
+                                           uint32_t *__restrict__ out_buckets) {
+    uint32_t cidx[CPL], coff[CPL];
+    bool act[CPL];
+    u128 cnt[PLANES][CPL];
+    full_width_slots<CPL, PLANES>(P, lane, cidx, coff, act, cnt);
     if (!stream_rows<CPL, PLANES, DEPTH, true>(P, rows, list, P.pass1_rows, coff, act, cnt)) {
         if (lane == 0) out_counts[item] = 0;
         return;
     }
-    // chunks that still hold a bucket with < F misses, compacted in ascending chunk order
     bool live[CPL];
     uint32_t n_live = 0;
 #pragma unroll
     for (int j = 0; j < CPL; j++) {
         uint32_t a = 0;
 #pragma unroll
-        for (int x = 0; x < 4; x++) a |= ~count_ge<CPL, PLANES>(cnt, j, x, P.F);
+        for (int x = 0; x < 4; x++) a |= alive_word<CPL, PLANES>(cnt, j, x);
         live[j] = a != 0;
         const uint64_t m = __ballot(live[j]);
         const uint32_t at = n_live + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
@@ -151,9 +467,7 @@ __global__ __launch_bounds__(kWave) void bmf_vote2_kernel(DevParams P, const uin
         if (lane == 0) out_counts[item] = 0;
         return;
     }
-
     if (n_live <= (uint32_t)kWave) {
-        // ---- pass 2, few live chunks: lane i recounts chunk i exactly from its 16-byte column of ALL rows
         __syncthreads();
         const bool mine = lane < n_live;
         uint32_t c1[1] = {mine ? live_chunk[lane] : 0u};
@@ -162,51 +476,43 @@ __global__ __launch_bounds__(kWave) void bmf_vote2_kernel(DevParams P, const uin
         u128 cnt1[PLANES][1];
 #pragma unroll
         for (int x = 0; x < 4; x++) {
-            const uint32_t dead = mine ? ~bucket_mask(P, c1[0], x) : 0xFFFFFFFFu;
+            const uint32_t bits = mine ? bucket_mask(P, c1[0], x) : 0u;
 #pragma unroll
-            for (int p = 0; p < PLANES; p++) cnt1[p][0].v[x] = dead;
+            for (int p = 0; p < PLANES; p++) cnt1[p][0].v[x] = start_word<PLANES>(P, bits, p);
         }
-        // one more row per sample first: most chunks that survived pass 1 by chance die here, for
-        // (r+1)*S sectors instead of G*S
-        // (not worth a dependent round of loads when there is next to nothing to kill)
-        const uint32_t r2 = P.pass1_rows + 1u;
-        if (r2 < P.G && n_live > 3u) {
-            stream_rows<1, PLANES, kDepth2, false>(P, rows, list, r2, off1, act1, cnt1);
-            uint32_t a = 0;
-#pragma unroll
-            for (int x = 0; x < 4; x++) a |= ~count_ge<1, PLANES>(cnt1, 0, x, P.F);
-            act1[0] = mine && a != 0;
-            if (__ballot(act1[0]) == 0) {
-                if (lane == 0) out_counts[item] = 0;
-                return;
-            }
-#pragma unroll
-            for (int x = 0; x < 4; x++) {
-                const uint32_t dead = act1[0] ? ~bucket_mask(P, c1[0], x) : 0xFFFFFFFFu;
-#pragma unroll
-                for (int p = 0; p < PLANES; p++) cnt1[p][0].v[x] = dead;
-            }
-        }
-        stream_rows<1, PLANES, kDepth2, false>(P, rows, list, P.G, off1, act1, cnt1);
-        emit_best<1, PLANES, false>(P, cnt1, item, lane, c1, out_counts, out_buckets, nullptr);
+        stream_rows<1, PLANES, kDepthCol, false>(P, rows, list, P.G, off1, act1, cnt1);
+        emit_best<1, PLANES, false>(for_emit<PLANES>(P), cnt1, item, lane, c1, out_counts, out_buckets, nullptr);
+        __syncthreads();
         return;
     }
-
-    // ---- pass 2, many live chunks: exact recount in the full layout, loading only the live chunks.
-    // Chunks that are not live keep their pass-1 counters: every bucket in them is already at >= F.
+    // chunks that are not live keep their pass-1 counters: every bucket in them is already at >= F
 #pragma unroll
     for (int j = 0; j < CPL; j++) {
         if (live[j]) {
 #pragma unroll
             for (int x = 0; x < 4; x++) {
-                const uint32_t dead = ~bucket_mask(P, cidx[j], x);
+                const uint32_t bits = bucket_mask(P, cidx[j], x);
 #pragma unroll
-                for (int p = 0; p < PLANES; p++) cnt[p][j].v[x] = dead;
+                for (int p = 0; p < PLANES; p++) cnt[p][j].v[x] = start_word<PLANES>(P, bits, p);
             }
         }
     }
     stream_rows<CPL, PLANES, DEPTH, false>(P, rows, list, P.G, coff, live, cnt);
-    emit_best<CPL, PLANES, false>(P, cnt, item, lane, cidx, out_counts, out_buckets, nullptr);
+    emit_best<CPL, PLANES, false>(for_emit<PLANES>(P), cnt, item, lane, cidx, out_counts, out_buckets, nullptr);
+}
+
+template <int CPL, int PLANES, int DEPTH>
+__global__ __launch_bounds__(kWave) void bmf_vote2_slow_kernel(DevParams P, const uint8_t *__restrict__ rows,
+                                                              const uint32_t *__restrict__ row_lists,
+                                                              uint32_t *__restrict__ out_counts,
+                                                              uint32_t *__restrict__ out_buckets, Pass2Queue Q) {
+    __shared__ uint32_t live_chunk[kWave];
+    const uint32_t n_slow = Q.counters[1];
+    for (uint32_t i = blockIdx.x; i < n_slow; i += gridDim.x) {
+        const uint32_t item = Q.slow_items[i];
+        vote2_item<CPL, PLANES, DEPTH>(P, rows, row_lists + (size_t)item * P.list_len, item, threadIdx.x, live_chunk,
+                                       out_counts, out_buckets);
+    }
 }
 
 }  // namespace bmf

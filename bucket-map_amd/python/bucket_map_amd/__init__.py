@@ -71,6 +71,7 @@ SYMBOLS = {
     "bmf_pinned_free": (None, [C.c_void_p]),
     "bmf_info": (C.c_int, [C.c_void_p, _u32p, _u32p, _u32p, _u32p]),
     "bmf_pass1_rows": (C.c_int, [C.c_void_p, _u32p]),
+    "bmf_batch_pass2_counts": (C.c_int, [C.c_void_p, C.c_void_p, _u32p, _u32p]),
 }
 
 _lib = None
@@ -195,6 +196,12 @@ class Batch:
         v = C.c_uint64()
         _check(lib().bmf_batch_rows_anded(self._flt._h, self._h, C.byref(v)))
         return int(v.value)
+
+    def pass2_counts(self):
+        """(items recounted by the packed kernel, items on the slow path) of the last run; two-pass pruning only."""
+        a, b = C.c_uint32(), C.c_uint32()
+        _check(lib().bmf_batch_pass2_counts(self._flt._h, self._h, C.byref(a), C.byref(b)))
+        return int(a.value), int(b.value)
 
     def close(self) -> None:
         if self._h:

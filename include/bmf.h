@@ -159,6 +159,10 @@ int  bmf_info(bmf_ctx *ctx, uint32_t *row_pitch_bytes, uint32_t *chunks_per_lane
 /* BMF_FLAG_EARLY_EXIT only: index rows per sample the first pass of the two-pass pruning kernel streams
  * for the loaded index; 0 = the single-pass pruning kernel (or no pruning) serves it. */
 int  bmf_pass1_rows(bmf_ctx *ctx, uint32_t *out);
+/* Two-pass pruning, after a run of `batch`: how many (window, orientation) items still had a live bucket after
+ * the first pass and went to the packed recount kernel, and how many took the slow full-width path.  Both 0
+ * when another kernel served the run.  Synchronises. */
+int  bmf_batch_pass2_counts(bmf_ctx *ctx, bmf_batch *batch, uint32_t *recounted, uint32_t *slow);
 
 #ifdef __cplusplus
 }
