@@ -213,19 +213,19 @@ int bmv_align(bmv_ctx *c, const uint8_t *reads, uint64_t n_read_bytes, const uin
     const uint32_t words = (max_m + 63u) / 64u;
     const Shape sh = pick_shape(words ? words : 1u);
     const uint32_t l_max = std::max(1u, (words + (uint32_t)sh.cw - 1u) / (uint32_t)sh.cw);
-    const uint64_t trace_stride = (uint64_t)(max_n + l_max + 1u) * l_max * (uint32_t)sh.cw * 2u;   // 64-bit words
-    const uint32_t ops_stride = max_m + max_n + 1u;
-    const uint32_t lds_stride = (max_n + 15u) & ~15u;
     const uint32_t gpw = 64u / (uint32_t)sh.group;
-    const size_t lds = (size_t)gpw * lds_stride;
+    const uint64_t trace_stride = (uint64_t)(max_n + l_max + 1u) * gpw * l_max * (uint32_t)sh.cw * 2u;   // words per wave
+    const uint32_t ops_stride = max_m + max_n + 1u;
+    const uint32_t lds_stride = (max_n + 15u) & ~15u, qry_stride = std::max(64u, (max_m + 63u) & ~63u);
+    const size_t lds = 256 + (size_t)gpw * (lds_stride + qry_stride);
     if (lds > 64 * 1024) return fail(BMV_ERR_UNSUPPORTED, "text windows of %u bases need %zu B of LDS", max_n, lds);
     if (lds > 48 * 1024)
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(sh.fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    const uint64_t per_slot = trace_stride * 8u + (uint64_t)ops_stride * 4u;
+    const uint64_t per_slot = trace_stride / gpw * 8u + (uint64_t)ops_stride * 4u;
     uint64_t chunk = std::max<uint64_t>(gpw, c->scratch_bytes / per_slot);
     chunk = std::min<uint64_t>(chunk / gpw * gpw, (uint64_t)n);
     if (chunk == 0) chunk = n;
-    HIP_TRY(c->trace.need((size_t)(chunk * trace_stride)));
+    HIP_TRY(c->trace.need((size_t)((chunk + gpw - 1u) / gpw * trace_stride)));
     HIP_TRY(c->ops_rev.need((size_t)(chunk * ops_stride)));
     HIP_TRY(c->nops.need((size_t)chunk));
     HIP_TRY(c->offsets.need((size_t)chunk));
@@ -249,9 +249,11 @@ int bmv_align(bmv_ctx *c, const uint8_t *reads, uint64_t n_read_bytes, const uin
         j.count = count;
         j.trace = c->trace.p;
         j.trace_stride = trace_stride;
+        j.trace_lanes = l_max;
         j.ops_rev = c->ops_rev.p;
         j.ops_stride = ops_stride;
         j.text_lds_stride = lds_stride;
+        j.query_lds_stride = qry_stride;
         j.out_score = c->out_score.p;
         j.out_begin = c->out_begin.p;
         j.out_nops = c->nops.p;

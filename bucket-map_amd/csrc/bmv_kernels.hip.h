@@ -15,8 +15,10 @@
 //
 // Per cell two bits are kept for the traceback: "the diagonal predecessor is valid" (match with diagonal
 // delta 0, or mismatch with diagonal delta 1: ~(Eq ^ D0)) and "the upper predecessor is valid" (vertical
-// delta +1: Pv); when neither holds the left one must be.  They go to HBM in step-major order (all lanes
-// of a step write one contiguous run).  The traceback walks from the LAST minimum of the bottom row,
+// delta +1: Pv); when neither holds the left one must be.  They go to HBM in step-major order per WAVE: the
+// entries all alignments of a wave write in one step are one contiguous run (640 B for 300-bp reads), and
+// a wave's steps follow each other in memory -- per-alignment streams of 80-byte pieces ran at a fifth of
+// the write bandwidth.  The traceback walks from the LAST minimum of the bottom row,
 // trying diagonal, up, left in that order (include/bmv.h, tie rules 1-2), reading the trace
 // GROUP columns at a time, and leaves run-length CIGAR entries in reverse; bmv_gather_kernel reverses and
 // packs them.
@@ -39,11 +41,13 @@ struct Job {
     const uint64_t *query_start;
     const uint32_t *query_len;
     uint32_t first, count;          // this launch handles alignments [first, first + count); slot = a - first
-    uint64_t *trace;                // count x trace_stride words
+    uint64_t *trace;                // one region of trace_stride words per wave (64/GROUP alignments)
     uint64_t trace_stride;
+    uint32_t trace_lanes;           // lanes per alignment that own trace entries in this batch (>= every L)
     uint32_t *ops_rev;              // count x ops_stride reversed CIGAR entries
     uint32_t ops_stride;
-    uint32_t text_lds_stride;       // bytes of LDS per group
+    uint32_t text_lds_stride;       // bytes of LDS per group for the text window ...
+    uint32_t query_lds_stride;      // ... and for the query (a multiple of 64)
     int32_t *out_score;             // per alignment of the batch
     uint32_t *out_begin;
     uint32_t *out_nops;             // per slot
@@ -66,17 +70,27 @@ __global__ __launch_bounds__(kWave) void bmv_align_kernel(Job J) {
     const uint32_t n = have ? J.text_len[a] : 0u, m = have ? J.query_len[a] : 0u;
     const uint32_t W = (m + 63u) >> 6;                         // words of the query
     const uint32_t L = (W + CW - 1u) / CW;                     // lanes of the group that hold query rows
-    uint8_t *text = lds_text + (size_t)grp * J.text_lds_stride;
-
-    // text window -> dna4 ranks in LDS, reverse-complemented if asked (bucket_locator.h:562-567)
+    // LDS: the dna4 folding table, then per group the text window and the query, both as ranks
+    uint8_t *lut = lds_text;
+    uint8_t *text = lds_text + 256 + (size_t)grp * (J.text_lds_stride + J.query_lds_stride);
+    uint8_t *qry = text + J.text_lds_stride;
+    reinterpret_cast<uint32_t *>(lut)[lane] = reinterpret_cast<const uint32_t *>(J.lut)[lane];
+    __syncthreads();
     if (have) {
+        // text window, reverse-complemented if asked (bucket_locator.h:562-567)
         const uint8_t *src = J.genome + J.text_start[a];
         const bool rc = J.text_rc[a] != 0;
+#pragma unroll 4
         for (uint32_t j = gl; j < n; j += GROUP) {
-            const uint8_t r = J.lut[rc ? src[n - 1u - j] : src[j]];
+            const uint8_t r = lut[rc ? src[n - 1u - j] : src[j]];
             text[j] = rc ? (uint8_t)(3u - r) : r;
         }
+        const uint8_t *q = J.reads + J.query_start[a];
+        const uint32_t padded = W * 64u;             // rows past the query match nothing
+#pragma unroll 4
+        for (uint32_t i = gl; i < padded; i += GROUP) qry[i] = i < m ? lut[q[i]] : (uint8_t)0xFF;
     }
+    __syncthreads();
     // match masks of this lane's words, one per base
     uint64_t peq[4][CW];
 #pragma unroll
@@ -84,19 +98,22 @@ __global__ __launch_bounds__(kWave) void bmv_align_kernel(Job J) {
         peq[0][c] = peq[1][c] = peq[2][c] = peq[3][c] = 0;
         const uint32_t w = gl * CW + c;
         if (have && w < W) {
-            const uint8_t *q = J.reads + J.query_start[a] + (size_t)w * 64u;
-            const uint32_t rows = m - w * 64u < 64u ? m - w * 64u : 64u;
-            for (uint32_t b = 0; b < rows; b++) {
-                const uint8_t r = J.lut[q[b]];
-                const uint64_t bit = 1ull << b;
-                peq[0][c] |= r == 0 ? bit : 0;
-                peq[1][c] |= r == 1 ? bit : 0;
-                peq[2][c] |= r == 2 ? bit : 0;
-                peq[3][c] |= r == 3 ? bit : 0;
+            const uint64_t *q8 = reinterpret_cast<const uint64_t *>(qry + (size_t)w * 64u);
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const uint64_t v = q8[k];
+#pragma unroll
+                for (int t = 0; t < 8; t++) {
+                    const uint32_t r = (uint32_t)(v >> (8 * t)) & 0xFFu;
+                    const uint64_t bit = 1ull << (8 * k + t);
+                    peq[0][c] |= r == 0 ? bit : 0;
+                    peq[1][c] |= r == 1 ? bit : 0;
+                    peq[2][c] |= r == 2 ? bit : 0;
+                    peq[3][c] |= r == 3 ? bit : 0;
+                }
             }
         }
     }
-    __syncthreads();
 
     uint64_t pv[CW], mv[CW];
 #pragma unroll
@@ -107,7 +124,9 @@ __global__ __launch_bounds__(kWave) void bmv_align_kernel(Job J) {
     int32_t score = (int32_t)m, best = (int32_t)m;              // tracked by the lane that holds row m
     uint32_t best_j = 0;
     const uint32_t last_lane = W ? (W - 1u) / CW : 0u, last_c = W ? (W - 1u) % CW : 0u, last_bit = (m - 1u) & 63u;
-    uint64_t *trace = J.trace + (size_t)slot * J.trace_stride;
+    // trace entries of one step of the whole wave are contiguous: ((t * GPW + grp) * lanes + gl) * CW + c
+    uint64_t *trace = J.trace + (size_t)blockIdx.x * J.trace_stride;
+    const uint32_t TL = J.trace_lanes;
 
     // every group of the wave runs the same number of steps (shuffles need the whole wave)
     uint32_t steps = (have && W) ? n + L - 1u : 0u;
@@ -148,7 +167,7 @@ __global__ __launch_bounds__(kWave) void bmv_align_kernel(Job J) {
                     pv[c] = mh | ~(xv | ph);
                     mv[c] = ph & xv;
                     hin = hout;
-                    uint64_t *tr = trace + (((size_t)t * L + gl) * CW + c) * 2u;
+                    uint64_t *tr = trace + ((((size_t)t * GPW + grp) * TL + gl) * CW + c) * 2u;
                     tr[0] = ~(eq0 ^ d0);                        // diagonal predecessor valid
                     tr[1] = pv[c];                              // upper predecessor valid
                 }
@@ -185,7 +204,7 @@ __global__ __launch_bounds__(kWave) void bmv_align_kernel(Job J) {
                 const uint32_t owner = w / CW, c = w % CW;
                 if (jc > gl) {
                     const uint32_t col = jc - gl;
-                    const uint64_t *tr = trace + (((size_t)(col + owner) * L + owner) * CW + c) * 2u;
+                    const uint64_t *tr = trace + ((((size_t)(col + owner) * GPW + grp) * TL + owner) * CW + c) * 2u;
                     db = tr[0];
                     ub = tr[1];
                 }
