@@ -20,9 +20,10 @@ def pytest_configure(config):
     # Build in-tree libraries if they are missing (the GPU box receives them prebuilt).
     need = [os.path.join(ROOT, "bucket-map_amd", "libbmf.so"), os.path.join(ROOT, "bucket-map_amd", "libbmhost.so"),
             os.path.join(ROOT, "oracle", "libbm_oracle.so"), os.path.join(ROOT, "bucket-map_amd", "bucketmap"),
-            os.path.join(ROOT, "tests", "cpp", "bucketmap_oracle")]
+            os.path.join(ROOT, "tests", "cpp", "bucketmap_oracle"), os.path.join(ROOT, "bucket-map_amd", "bucketmap_align"),
+            os.path.join(ROOT, "tests", "cpp", "bucketmap_align_oracle")]
     if not all(os.path.exists(p) for p in need):
-        subprocess.run(["make", "-C", ROOT], check=True, stdout=subprocess.DEVNULL)
+        subprocess.run(["make", "-C", ROOT, "-j4"], check=True, stdout=subprocess.DEVNULL)
 
 
 def have_gpu() -> bool:
