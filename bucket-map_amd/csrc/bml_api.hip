@@ -7,10 +7,12 @@
 
 #include <hipcub/hipcub.hpp>
 
+#include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
 
+#include <algorithm>
 #include <vector>
 
 namespace {
@@ -78,6 +80,12 @@ struct bml_ctx {
     DevBuf<uint16_t> sample_pos;
     DevBuf<int32_t> prop_key, out_offset;
     DevBuf<bml::Chunk> chunks;
+    // bml_sample_windows
+    DevBuf<uint8_t> s_bases, s_quals, s_has;
+    DevBuf<uint64_t> s_win_start;
+    DevBuf<uint32_t> s_win_len, s_hash;
+    DevBuf<uint16_t> s_pos, s_table;
+    uint32_t s_table_len = 0;        // windows up to this length are tabulated
     DevBuf<unsigned long long> occ_count;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     float ms[3] = {0, 0, 0};
@@ -138,10 +146,74 @@ void bml_destroy(bml_ctx *c) {
     c->bucket_len.release(); c->sample_hash.release(); c->seg_len.release(); c->pair_window.release();
     c->prop_votes.release(); c->out_votes.release(); c->sample_pos.release(); c->prop_key.release();
     c->out_offset.release(); c->chunks.release(); c->occ_count.release();
+    c->s_bases.release(); c->s_quals.release(); c->s_has.release(); c->s_win_start.release(); c->s_win_len.release();
+    c->s_hash.release(); c->s_pos.release(); c->s_table.release();
     for (auto &e : c->ev)
         if (e) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
+}
+
+int bml_sample_windows(bml_ctx *c, const uint8_t *bases, const uint8_t *quals, uint64_t n_bytes, const uint64_t *win_start,
+                       const uint32_t *win_len, uint32_t n_windows, uint32_t min_base_quality, uint32_t *out_hash,
+                       uint16_t *out_pos, uint8_t *out_has) {
+    if (!c) return fail(BML_ERR_ARG, "bml_sample_windows: null context");
+    if (n_windows == 0) return BML_OK;
+    if (!win_start || !win_len || !out_hash || !out_pos || !out_has || (n_bytes && (!bases || !quals)))
+        return fail(BML_ERR_ARG, "bml_sample_windows: null argument");
+    uint32_t max_len = 1;
+    for (uint32_t w = 0; w < n_windows; w++) {
+        if (win_start[w] > n_bytes || win_len[w] > n_bytes - win_start[w])
+            return fail(BML_ERR_ARG, "window %u lies outside the read buffer", w);
+        if (win_len[w] > 0xFFFFu) return fail(BML_ERR_UNSUPPORTED, "window %u is %u bases long (positions are 16-bit)", w, win_len[w]);
+        max_len = std::max(max_len, win_len[w]);
+    }
+    const uint32_t k = c->p.k, p = c->p.num_samples;
+    const size_t lds = bml::sample_lds_bytes(max_len, k);
+    if (lds > 160 * 1024) return fail(BML_ERR_UNSUPPORTED, "windows of %u bases need %zu B of LDS", max_len, lds);
+    HIP_TRY(hipSetDevice(c->p.device));
+    if (lds > 48 * 1024)
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(bml::bml_sample_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    // Sampler(p).sample_deterministically(n - 1) for every possible selection size n (utils.h:160-178), in
+    // fp64 on the host so that device rounding can never differ
+    if (max_len > c->s_table_len) {
+        const uint32_t max_nk = max_len >= k ? max_len - k + 1 : 0;
+        std::vector<uint16_t> tab((size_t)(max_nk + 1) * p, 0);
+        for (uint32_t n = 1; n <= max_nk; n++) {
+            const uint32_t ub = n - 1;
+            double delta = 0.0;
+            if (p != 1) delta = (double)(ub + 1u) / (double)(p - 1u);
+            for (uint32_t s = 0; s + 1 < p; s++) tab[(size_t)n * p + s] = (uint16_t)floor((double)s * delta);
+            tab[(size_t)n * p + p - 1] = (uint16_t)ub;
+        }
+        HIP_TRY(c->s_table.need(tab.size()));
+        HIP_TRY(hipMemcpy(c->s_table.p, tab.data(), tab.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+        c->s_table_len = max_len;
+    }
+    HIP_TRY(c->s_bases.need((size_t)n_bytes));
+    HIP_TRY(c->s_quals.need((size_t)n_bytes));
+    HIP_TRY(c->s_win_start.need(n_windows));
+    HIP_TRY(c->s_win_len.need(n_windows));
+    HIP_TRY(c->s_hash.need((size_t)n_windows * p));
+    HIP_TRY(c->s_pos.need((size_t)n_windows * p));
+    HIP_TRY(c->s_has.need(n_windows));
+    if (n_bytes) {
+        HIP_TRY(hipMemcpyAsync(c->s_bases.p, bases, (size_t)n_bytes, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(c->s_quals.p, quals, (size_t)n_bytes, hipMemcpyHostToDevice, c->stream));
+    }
+    HIP_TRY(hipMemcpyAsync(c->s_win_start.p, win_start, (size_t)n_windows * 8, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->s_win_len.p, win_len, (size_t)n_windows * 4, hipMemcpyHostToDevice, c->stream));
+    // the table is indexed by selection size for THIS table's p; sizes beyond the current windows are unused
+    hipLaunchKernelGGL(bml::bml_sample_kernel, dim3(n_windows), dim3(64), lds, c->stream, k, p, min_base_quality, max_len,
+                       c->s_bases.p, c->s_quals.p, c->s_win_start.p, c->s_win_len.p, c->lut.p, c->s_table.p, c->s_hash.p,
+                       c->s_pos.p, c->s_has.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(out_hash, c->s_hash.p, (size_t)n_windows * p * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(out_pos, c->s_pos.p, (size_t)n_windows * p * 2, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(out_has, c->s_has.p, (size_t)n_windows, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return BML_OK;
 }
 
 int bml_load_genome(bml_ctx *c, const uint8_t *bases, uint64_t n_bases, const uint64_t *bucket_start,

@@ -213,4 +213,74 @@ __global__ __launch_bounds__(kThreads) void bml_replay_kernel(
     out_votes[pair] = votes;
 }
 
+// --------------------------------------------------------------------------------------------------
+// _prepare_read_query (bucket_locator.h:292-347): the p (hash, position) pairs the locator asks of every
+// window.  One wave per window.  LDS (dynamic): lut[256] | code[max_len] | qrank[max_len] | pad | good[max_nk] u16
+// --------------------------------------------------------------------------------------------------
+__host__ __device__ inline size_t sample_lds_bytes(uint32_t max_len, uint32_t k) {
+    const uint32_t max_nk = max_len >= k ? max_len - k + 1 : 1;
+    return ((256 + 2 * (size_t)max_len + 3) & ~(size_t)3) + 2 * (size_t)max_nk;
+}
+
+__global__ __launch_bounds__(64) void bml_sample_kernel(uint32_t k, uint32_t p, uint32_t minq, uint32_t max_len,
+                                                       const uint8_t *__restrict__ bases, const uint8_t *__restrict__ quals,
+                                                       const uint64_t *__restrict__ win_start,
+                                                       const uint32_t *__restrict__ win_len,
+                                                       const uint8_t *__restrict__ dna4_lut,
+                                                       const uint16_t *__restrict__ pos_table,
+                                                       uint32_t *__restrict__ out_hash, uint16_t *__restrict__ out_pos,
+                                                       uint8_t *__restrict__ out_has) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t sample_smem[];
+    uint8_t *lut = sample_smem;
+    uint8_t *code = sample_smem + 256;
+    uint8_t *qrank = code + max_len;
+    uint16_t *good = reinterpret_cast<uint16_t *>(sample_smem + ((256 + 2 * (size_t)max_len + 3) & ~(size_t)3));
+    const uint32_t w = blockIdx.x, lane = threadIdx.x;
+    const uint64_t off = win_start[w];
+    const uint32_t len = win_len[w];
+    reinterpret_cast<uint32_t *>(lut)[lane] = reinterpret_cast<const uint32_t *>(dna4_lut)[lane];
+    __syncthreads();
+    for (uint32_t i = lane; i < len; i += 64) {
+        code[i] = lut[bases[off + i]];
+        qrank[i] = (uint8_t)(quals[off + i] - 33u);
+    }
+    __syncthreads();
+    const uint32_t nk = len >= k ? len - k + 1 : 0;
+    if (nk == 0) {                                   // window shorter than k: nothing to sample
+        for (uint32_t s = lane; s < p; s += 64) {
+            out_hash[(size_t)w * p + s] = 0;
+            out_pos[(size_t)w * p + s] = 0;
+        }
+        if (lane == 0) out_has[w] = 0;
+        return;
+    }
+    // indices of the k-mers whose quality sum reaches the threshold (:325-327), ascending
+    uint32_t n_good = 0;
+    for (uint32_t base = 0; base < nk; base += 64) {
+        const uint32_t j = base + lane;
+        bool ok = false;
+        if (j < nk) {
+            uint32_t qs = 0;
+            for (uint32_t t = 0; t < k; t++) qs += qrank[j + t];
+            ok = qs >= minq;
+        }
+        const uint64_t m = __ballot(ok);
+        if (ok) good[n_good + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)j;
+        n_good += (uint32_t)__popcll(m);
+    }
+    __syncthreads();
+    const bool all = n_good == 0;                    // none is high-quality: consider all of them (:330-332)
+    const uint32_t n_sel = all ? nk : n_good;
+    for (uint32_t s = lane; s < p; s += 64) {        // Sampler(p) over the selection (:333-335), tabulated in fp64
+        const uint32_t at = pos_table[(size_t)n_sel * p + s];
+        const uint32_t j = all ? at : good[at];
+        uint32_t h = 0;
+        for (uint32_t t = 0; t < k; t++) h = (h << 2) | code[j + t];
+        out_hash[(size_t)w * p + s] = h;
+        out_pos[(size_t)w * p + s] = (uint16_t)j;
+    }
+    if (lane == 0) out_has[w] = 1;
+}
+
+
 }  // namespace bml

@@ -24,10 +24,16 @@
 
 namespace bm {
 
-// Where _create_kmer_index + _find_offset run.  One call handles every candidate of a _locate pass.
+// Where _prepare_read_query's sampling and _create_kmer_index + _find_offset run.  One scan call handles
+// every candidate of a _locate pass; sampling is called per block of reads.
 class offset_scanner {
 public:
     virtual ~offset_scanner() = default;
+    // _prepare_read_query (:292-347) for windows given as views into bases / quals: p (hash, position) pairs
+    // per window, has[w] = 0 for a window shorter than k
+    virtual void sample_windows(const uint8_t *bases, const uint8_t *quals, uint64_t n_bytes, const uint64_t *win_start,
+                                const uint32_t *win_len, uint32_t n_windows, uint32_t min_base_quality,
+                                uint32_t *out_hash, uint16_t *out_pos, uint8_t *out_has) = 0;
     // genome as one byte string; bucket b = [bucket_start[b], +bucket_len[b])
     virtual void load_genome(const uint8_t *bases, uint64_t n_bases, const uint64_t *bucket_start,
                              const uint32_t *bucket_len, uint32_t n_buckets) = 0;
@@ -97,46 +103,46 @@ private:
         throw std::runtime_error("the mapper returned a (read, window) pair the locator never sampled");
     }
 
-    // _prepare_read_query (:292-347)
+    // _prepare_read_query (:292-347): the FASTQ pass and the windowing (:303-316) stay here; the sampling of
+    // every window (:317-343) runs behind offset_scanner::sample_windows, a block of reads at a time.
     void prepare_read_query(const std::string &fastq) {
         first_window.clear(); window_start.clear(); sample_hash.clear(); sample_pos.clear();
         segment_length.clear(); window_has_samples.clear(); read_lengths.clear();
+        std::vector<uint8_t> bases, quals;
+        std::vector<uint64_t> win_start;
+        std::vector<uint32_t> win_len;
+        const size_t block_bases = 256u << 20;
+        auto flush = [&]() {
+            const size_t n = win_start.size(), at = sample_hash.size();
+            if (n == 0) return;
+            sample_hash.resize(at + n * num_samples);
+            sample_pos.resize(at + n * num_samples);
+            const size_t has_at = window_has_samples.size();
+            window_has_samples.resize(has_at + n);
+            _s->sample_windows(bases.data(), quals.data(), bases.size(), win_start.data(), win_len.data(),
+                               static_cast<uint32_t>(n), min_base_quality, sample_hash.data() + at, sample_pos.data() + at,
+                               window_has_samples.data() + has_at);
+            bases.clear(); quals.clear(); win_start.clear(); win_len.clear();
+        };
         for_each_fastq(fastq, [&](const FastqRecord &rec) {
             const uint32_t len = static_cast<uint32_t>(rec.seq.size());
             first_window.push_back(static_cast<uint32_t>(window_start.size()));
             std::vector<uint32_t> starting_positions{0};
             if (len > 2 * read_length) starting_positions = sample_deterministically(num_segment_samples, len - read_length - 1);
+            const uint64_t at = bases.size();
+            bases.insert(bases.end(), rec.seq.begin(), rec.seq.end());
+            quals.insert(quals.end(), rec.qual.begin(), rec.qual.end());
             for (uint32_t i : starting_positions) {
-                const uint32_t begin = i, end = std::min(i + read_length, len);
-                const uint32_t seg_len = end - begin;
-                const int num_kmers = seg_len >= k ? static_cast<int>(seg_len - k + 1) : 0;
-                // quality filter only (:325-327): sum of phred ranks over the k bases >= b*k
-                std::vector<uint16_t> good_indices;
-                for (int j = 0; j < num_kmers; j++) {
-                    unsigned int qs = 0;
-                    for (uint32_t t = 0; t < k; t++) qs += static_cast<uint8_t>(rec.qual[begin + j + t]) - 33u;
-                    if (qs >= min_base_quality) good_indices.push_back(static_cast<uint16_t>(j));
-                }
-                if (good_indices.empty())   // consider all k-mers if none is high-quality (:330-332)
-                    for (int j = 0; j < num_kmers; j++) good_indices.push_back(static_cast<uint16_t>(j));
+                const uint32_t end = std::min(i + read_length, len);
                 window_start.push_back(static_cast<int>(i));
-                segment_length.push_back(seg_len);
-                window_has_samples.push_back(good_indices.empty() ? 0 : 1);
-                if (good_indices.empty()) {
-                    sample_hash.insert(sample_hash.end(), num_samples, 0u);
-                    sample_pos.insert(sample_pos.end(), num_samples, 0);
-                } else {
-                    // Sampler(p) over the good k-mers (:333-335)
-                    for (uint32_t p : sample_deterministically(static_cast<uint32_t>(num_samples),
-                                                               static_cast<uint32_t>(good_indices.size() - 1))) {
-                        const uint16_t j = good_indices[p];
-                        sample_pos.push_back(j);
-                        sample_hash.push_back(kmer_hash_at(rec.seq.data() + begin + j, k));
-                    }
-                }
+                segment_length.push_back(end - i);
+                win_start.push_back(at + i);
+                win_len.push_back(end - i);
             }
             read_lengths.push_back(len);
+            if (bases.size() >= block_bases) flush();
         });
+        flush();
         first_window.push_back(static_cast<uint32_t>(window_start.size()));
     }
 

@@ -1,6 +1,6 @@
 // gpu_offset_scanner.h -- the MI355X locator scan (include/bml.h) behind bm::offset_scanner.
-// Replaces _create_kmer_index + _find_offset (bucket_map/locator/bucket_locator.h:162-177,209-290) for
-// all candidates of one _locate pass.  Fails loudly (throws) when the device path fails: no CPU fallback.
+// Replaces _prepare_read_query's sampling (bucket_map/locator/bucket_locator.h:317-343) and
+// _create_kmer_index + _find_offset (:162-177,209-290) for all candidates of one _locate pass.  Fails loudly (throws) when the device path fails: no CPU fallback.
 #pragma once
 
 #include "../../include/bml.h"
@@ -30,6 +30,14 @@ public:
                      uint32_t n_buckets) override {
         if (bml_load_genome(ctx_, bases, n_bases, bucket_start, bucket_len, n_buckets) != BML_OK)
             throw std::runtime_error(std::string("uploading the genome failed: ") + bml_last_error());
+    }
+
+    void sample_windows(const uint8_t *bases, const uint8_t *quals, uint64_t n_bytes, const uint64_t *win_start,
+                        const uint32_t *win_len, uint32_t n_windows, uint32_t min_base_quality, uint32_t *out_hash,
+                        uint16_t *out_pos, uint8_t *out_has) override {
+        if (bml_sample_windows(ctx_, bases, quals, n_bytes, win_start, win_len, n_windows, min_base_quality, out_hash,
+                               out_pos, out_has) != BML_OK)
+            throw std::runtime_error(std::string("the GPU k-mer sampling failed: ") + bml_last_error());
     }
 
     void scan(const uint32_t *sample_hash, const uint16_t *sample_pos, const uint32_t *seg_len, uint32_t n_windows,

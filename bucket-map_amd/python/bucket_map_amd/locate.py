@@ -28,6 +28,7 @@ SYMBOLS = {
     "bml_create": (C.c_int, [C.POINTER(_Params), C.POINTER(C.c_void_p)]),
     "bml_destroy": (None, [C.c_void_p]),
     "bml_load_genome": (C.c_int, [C.c_void_p, _u8p, C.c_uint64, _u64p, _u32p, C.c_uint32]),
+    "bml_sample_windows": (C.c_int, [C.c_void_p, _u8p, _u8p, C.c_uint64, _u64p, _u32p, C.c_uint32, C.c_uint32, _u32p, _u16p, _u8p]),
     "bml_locate": (C.c_int, [C.c_void_p, _u32p, _u16p, _u32p, C.c_uint32, _u32p, _u32p, _u8p, C.c_uint32, _i32p, _u32p]),
     "bml_last_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float), _u64p]),
 }
@@ -70,6 +71,18 @@ class LocatorScan:
         bs = np.ascontiguousarray(bucket_start, np.uint64)
         bl = np.ascontiguousarray(bucket_len, np.uint32)
         _check(lib().bml_load_genome(self._h, _p(bases, _u8p), len(bases), _p(bs, _u64p), _p(bl, _u32p), len(bs)))
+
+    def sample_windows(self, bases, quals, win_start, win_len, min_base_quality: int):
+        """_prepare_read_query's sampling: (hash u32[n, p], pos u16[n, p], has u8[n])."""
+        b, q = np.ascontiguousarray(bases, np.uint8), np.ascontiguousarray(quals, np.uint8)
+        ws, wl = np.ascontiguousarray(win_start, np.uint64), np.ascontiguousarray(win_len, np.uint32)
+        n = len(ws)
+        h = np.zeros((n, self.p), np.uint32)
+        pos = np.zeros((n, self.p), np.uint16)
+        has = np.zeros(n, np.uint8)
+        _check(lib().bml_sample_windows(self._h, _p(b, _u8p), _p(q, _u8p), len(b), _p(ws, _u64p), _p(wl, _u32p), n,
+                                        min_base_quality, _p(h, _u32p), _p(pos, _u16p), _p(has, _u8p)))
+        return h, pos, has
 
     def locate(self, sample_hash, sample_pos, seg_len, pair_bucket, pair_window, pair_rc):
         sh = np.ascontiguousarray(sample_hash, np.uint32)

@@ -8,13 +8,13 @@
  *   --------------------------------------------------------  ---------------------------------
  *   bucket_locator ctor: allowed_mismatch/indel   :419-420     bml_create
  *   _initialize_kmer_index (bucket sequences)     :151-160     bml_load_genome
+ *   _prepare_read_query (k-mer sampling)          :292-347     bml_sample_windows
  *   _create_kmer_index + _find_offset, per bucket :162-177,    bml_locate  (all candidates of one
  *     and per candidate, inside _locate's loop    :209-290,      _locate call in one batch)
  *                                                 :651-695
  *
- * What stays on the host (bucket-map_amd/host/bucket_locator.h): sampling the locator k-mers of each
- * window (_prepare_read_query :292-347), the order in which results are appended per read (:651-693),
- * _filter_best_locations (:350-405) and SAM output (:455-611).
+ * What stays on the host (bucket-map_amd/host/bucket_locator.h): FASTQ parsing and windowing, the order in
+ * which results are appended per read (:651-693), _filter_best_locations (:350-405) and SAM output (:455-611).
  *
  * Instead of one hash multimap per bucket (65 k node allocations per bucket in the reference) the
  * device scans each candidate bucket once against the few hundred k-mers actually asked of it, sorts
@@ -54,6 +54,17 @@ void bml_destroy(bml_ctx *ctx);
  * (start, length) views into it (iterate_through_buckets, utils.h:72-97).  Uploaded once. */
 int  bml_load_genome(bml_ctx *ctx, const uint8_t *bases, uint64_t n_bases, const uint64_t *bucket_start,
                      const uint32_t *bucket_len, uint32_t n_buckets);
+
+/* _prepare_read_query (:292-347) for a batch of windows: window w is the view [win_start[w], +win_len[w]) of
+ * `bases` (ASCII, dna4 folding) and `quals` (phred+33), as in bmf_map_windows.  Per window: the k-mers whose
+ * quality sum over their k bases is >= min_base_quality (:325-327; all k-mers if none is, :330-332),
+ * Sampler(p) over them (utils.h:160-178, tabulated in fp64 on the host), and for each sampled k-mer
+ *   out_hash[w*p + s]  its hash,   out_pos[w*p + s]  its start in the window (u16, as the reference stores it);
+ *   out_has[w] = 0 for a window shorter than k (its entries are zeros and it must not be located).
+ * The arrays are exactly bml_locate's sample_hash / sample_pos. */
+int  bml_sample_windows(bml_ctx *ctx, const uint8_t *bases, const uint8_t *quals, uint64_t n_bytes,
+                        const uint64_t *win_start, const uint32_t *win_len, uint32_t n_windows,
+                        uint32_t min_base_quality, uint32_t *out_hash, uint16_t *out_pos, uint8_t *out_has);
 
 /* One batch of candidates.
  *   windows : sample_hash[w*p + s], sample_pos[w*p + s] (start of the k-mer in the window, u16 as

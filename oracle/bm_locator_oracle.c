@@ -7,6 +7,7 @@
  */
 #include "bm_locator_oracle.h"
 
+#include <math.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -190,4 +191,47 @@ int bmlo_locate(const bmlo_params *p, const uint8_t *genome, const uint64_t *buc
     }
     bmlo_index_free(ix);
     return 0;
+}
+
+/* bucket_locator.h:292-347 */
+void bmlo_sample_windows(uint32_t k, uint32_t p, uint32_t min_base_quality, const uint8_t *bases, const uint8_t *quals,
+                         const uint64_t *win_start, const uint32_t *win_len, uint32_t n_windows, uint32_t *out_hash,
+                         uint16_t *out_pos, uint8_t *out_has) {
+    for (uint32_t w = 0; w < n_windows; w++) {
+        const uint8_t *b = bases + win_start[w], *q = quals + win_start[w];
+        const uint32_t len = win_len[w];
+        const uint32_t nk = len >= k ? len - k + 1 : 0;
+        uint32_t *hash = out_hash + (size_t)w * p;
+        uint16_t *pos = out_pos + (size_t)w * p;
+        out_has[w] = nk ? 1 : 0;
+        if (!nk) {
+            for (uint32_t s = 0; s < p; s++) {
+                hash[s] = 0;
+                pos[s] = 0;
+            }
+            continue;
+        }
+        uint16_t *good = (uint16_t *)malloc((size_t)nk * sizeof(uint16_t));
+        uint32_t n_good = 0;
+        for (uint32_t j = 0; j < nk; j++) {                       /* :325-327 */
+            uint32_t qs = 0;
+            for (uint32_t t = 0; t < k; t++) qs += (uint32_t)q[j + t] - 33u;
+            if (qs >= min_base_quality) good[n_good++] = (uint16_t)j;
+        }
+        if (n_good == 0)                                          /* :330-332 */
+            for (uint32_t j = 0; j < nk; j++) good[n_good++] = (uint16_t)j;
+        /* Sampler(p).sample_deterministically(n_good - 1), utils.h:160-178 */
+        const uint32_t ub = n_good - 1;
+        double delta = 0.0;
+        if (p != 1) delta = (double)(ub + 1u) / (double)(p - 1u);
+        for (uint32_t s = 0; s < p; s++) {
+            const uint32_t at = s + 1 < p ? (uint32_t)floor((double)s * delta) : ub;
+            const uint16_t j = good[at];
+            uint32_t h = 0;
+            for (uint32_t t = 0; t < k; t++) h = (h << 2) | dna4_rank(b[j + t]);
+            hash[s] = h;
+            pos[s] = j;
+        }
+        free(good);
+    }
 }

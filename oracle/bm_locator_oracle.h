@@ -46,6 +46,16 @@ int bmlo_locate(const bmlo_params *p, const uint8_t *genome, const uint64_t *buc
                 const uint32_t *pair_window, const uint8_t *pair_rc, uint32_t n_pairs, int32_t *out_offset,
                 uint32_t *out_votes);
 
+/* _prepare_read_query (bucket_map/locator/bucket_locator.h:292-347) for a batch of windows, buffer layout
+ * of bml_sample_windows (include/bml.h): window w is the view [win_start[w], +win_len[w]) of `bases` (ASCII)
+ * and `quals` (phred+33).  Per window: the k-mers whose quality sum over their k bases is >=
+ * min_base_quality (:325-327; all k-mers if none is, :330-332), Sampler(p) over them (:333-335, utils.h:
+ * 160-178 in fp64), and for each sampled k-mer its hash and its start position in the window.
+ * out_has[w] = 0 for a window shorter than k (its p entries are zeros). */
+void bmlo_sample_windows(uint32_t k, uint32_t p, uint32_t min_base_quality, const uint8_t *bases, const uint8_t *quals,
+                         const uint64_t *win_start, const uint32_t *win_len, uint32_t n_windows, uint32_t *out_hash,
+                         uint16_t *out_pos, uint8_t *out_has);
+
 #ifdef __cplusplus
 }
 #endif

@@ -62,6 +62,7 @@ def lib() -> C.CDLL:
             "bmo_map_windows": (C.c_uint64, [vp, _u8p, _u8p, _u64p, _u32p, u32, _u32p, _u32p]),
             "bmlo_locate": (C.c_int, [C.POINTER(LocParams), _u8p, _u64p, _u32p, u32, _u32p, C.POINTER(C.c_uint16), _u32p,
                                       _u32p, _u32p, _u8p, u32, C.POINTER(C.c_int32), _u32p]),
+            "bmlo_sample_windows": (None, [u32, u32, u32, _u8p, _u8p, _u64p, _u32p, u32, _u32p, C.POINTER(C.c_uint16), _u8p]),
             "bmao_align": (C.c_int, [_u8p, u32, C.c_int, _u8p, u32, _i32p, _u32p, _u32p, u32]),
             "bmao_align_batch": (C.c_int, [_u8p, _u8p, _u64p, _u32p, _u8p, _u64p, _u32p, u32, _i32p, _u32p, _u64p, _u32p,
                                            C.c_uint64]),
@@ -136,6 +137,19 @@ def locate(k, num_samples, allowed_mismatch, allowed_indel, genome, bucket_start
     if rc:
         raise RuntimeError("oracle locator: bad bucket id")
     return off, votes
+
+
+def sample_windows(k, p, min_base_quality, bases, quals, win_start, win_len):
+    """bmlo_sample_windows: _prepare_read_query's sampling (bucket_locator.h:292-347)."""
+    b, q = np.ascontiguousarray(bases, np.uint8), np.ascontiguousarray(quals, np.uint8)
+    ws, wl = np.ascontiguousarray(win_start, np.uint64), np.ascontiguousarray(win_len, np.uint32)
+    n = len(ws)
+    h = np.zeros((n, p), np.uint32)
+    pos = np.zeros((n, p), np.uint16)
+    has = np.zeros(n, np.uint8)
+    lib().bmlo_sample_windows(k, p, min_base_quality, _p(b, _u8p), _p(q, _u8p), _p(ws, _u64p), _p(wl, _u32p), n,
+                              _p(h, _u32p), _p(pos, C.POINTER(C.c_uint16)), _p(has, _u8p))
+    return h, pos, has
 
 
 def align(text: bytes, query: bytes, text_rc: bool = False):

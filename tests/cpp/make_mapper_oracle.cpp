@@ -72,6 +72,12 @@ public:
         bstart_.assign(bucket_start, bucket_start + n_buckets);
         blen_.assign(bucket_len, bucket_len + n_buckets);
     }
+    void sample_windows(const uint8_t *bases, const uint8_t *quals, uint64_t, const uint64_t *win_start,
+                        const uint32_t *win_len, uint32_t n_windows, uint32_t min_base_quality, uint32_t *out_hash,
+                        uint16_t *out_pos, uint8_t *out_has) override {
+        bmlo_sample_windows(p_.k, p_.num_samples, min_base_quality, bases, quals, win_start, win_len, n_windows, out_hash,
+                            out_pos, out_has);
+    }
     void scan(const uint32_t *sample_hash, const uint16_t *sample_pos, const uint32_t *seg_len, uint32_t,
               const uint32_t *pair_bucket, const uint32_t *pair_window, const uint8_t *pair_rc, uint32_t n_pairs,
               int32_t *out_offset, uint32_t *out_votes) override {

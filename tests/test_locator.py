@@ -204,3 +204,52 @@ def test_gpu_scan_errors():
     off, votes = s.locate(np.zeros((1, 10)), np.zeros((1, 10)), [100], np.zeros(0), np.zeros(0), np.zeros(0))
     assert len(off) == 0
     s.close()
+
+
+# ------------------------------------------------------------------ _prepare_read_query's sampling (:292-347)
+
+def _sample_case(rng, n, max_len, k):
+    lens = rng.integers(0, max_len + 1, n)
+    lens[: n // 3] = max_len
+    lens[n // 3: n // 3 + 5] = [0, 1, k - 1, k, k + 1][: 5]
+    off = np.concatenate(([0], np.cumsum(lens))).astype(np.uint64)
+    bases = np.frombuffer(b"ACGTNacgt", np.uint8)[rng.integers(0, 9, int(off[-1]))]
+    quals = rng.integers(33, 33 + 42, int(off[-1])).astype(np.uint8)
+    # windows inside the reads too (long-read style): every fifth window is a shifted, shortened view
+    ws, wl = off[:-1].copy(), lens.astype(np.uint32)
+    for w in range(0, n, 5):
+        if wl[w] > 20:
+            ws[w] += 7
+            wl[w] -= 11
+    return bases, quals, ws, wl
+
+
+def test_oracle_sampling_hand_worked():
+    # k = 3, p = 4, threshold 3*35 = 105 on phred+33 qualities: window ACGTACGT, qualities I(40) x4 then #(2) x4
+    bases = np.frombuffer(b"ACGTACGT", np.uint8)
+    quals = np.frombuffer(b"IIII####", np.uint8)
+    h, pos, has = oc.sample_windows(3, 4, 105, bases, quals, [0], [8])
+    # quality sums of the 6 k-mers: 120 120 82 44 6 6 -> good = {0, 1}; Sampler(4) over 2: floor(i * 2/3) = 0 0 1, last = 1
+    assert has.tolist() == [1] and pos[0].tolist() == [0, 0, 1, 1]
+    assert h[0].tolist() == [0b000110, 0b000110, 0b011011, 0b011011]          # ACG, ACG, CGT, CGT
+    # nothing reaches the threshold: all 6 k-mers are candidates (:330-332): floor(i * 6/3) = 0 2 4, last = 5
+    h, pos, has = oc.sample_windows(3, 4, 999, bases, quals, [0], [8])
+    assert pos[0].tolist() == [0, 2, 4, 5]
+    # shorter than k: no samples
+    h, pos, has = oc.sample_windows(3, 4, 0, bases, quals, [0, 6], [2, 2])
+    assert has.tolist() == [0, 0] and not h.any() and not pos.any()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k,p,max_len,minq", [(12, 10, 300, 25 * 12), (12, 20, 300, 10 * 12), (9, 5, 150, 0), (16, 10, 997, 30 * 16),
+                                              (12, 10, 300, 10 ** 6), (12, 64, 80, 20 * 12), (12, 10, 16384, 25 * 12)])
+def test_gpu_sampling_equals_oracle(k, p, max_len, minq):
+    from bucket_map_amd import locate
+    rng = np.random.default_rng(k * 1000 + p)
+    bases, quals, ws, wl = _sample_case(rng, 40 if max_len > 5000 else 700, max_len, k)
+    want = oc.sample_windows(k, p, minq, bases, quals, ws, wl)
+    scan = locate.LocatorScan(k, p, 4, 6, 70000)
+    got = scan.sample_windows(bases, quals, ws, wl, minq)
+    for a, b, what in zip(want, got, ("hash", "position", "has-samples")):
+        assert np.array_equal(a, b), what
+    scan.close()
