@@ -433,12 +433,11 @@ void bmf_destroy(bmf_ctx *c) {
     delete c;
 }
 
-int bmf_load_index(bmf_ctx *c, const uint8_t *rows, uint64_t n_rows, const int32_t *kmer_to_index,
-                   uint64_t n_kmers) {
-    if (!c) return fail(BMF_ERR_ARG, "bmf_load_index: null context");
+// The three steps of an index upload, shared by bmf_load_index (rows in memory) and bmf_load_index_files
+// (rows streamed from the .qgram file through pinned staging buffers).
+static int upload_begin(bmf_ctx *c, uint64_t n_rows, const int32_t *kmer_to_index, uint64_t n_kmers) {
     // q_gram_mapper.h:325-328: "The q-gram index is not empty. Terminating load."
     if (c->loaded) return fail(BMF_ERR_STATE, "the q-gram index is not empty; call bmf_reset first");
-    if (n_rows && !rows) return fail(BMF_ERR_ARG, "rows is null");
     if (n_kmers && !kmer_to_index) return fail(BMF_ERR_ARG, "kmer_to_index is null");
     if (n_kmers != 0 && n_kmers != (1ull << (2 * c->p.q)))
         return fail(BMF_ERR_ARG, "kmer_to_index must have 4^q = %llu entries (got %llu)",
@@ -449,7 +448,7 @@ int bmf_load_index(bmf_ctx *c, const uint8_t *rows, uint64_t n_rows, const int32
             return fail(BMF_ERR_ARG, "kmer_to_index[%llu] = %d is not a row (n_rows = %llu)", (unsigned long long)i,
                         kmer_to_index[i], (unsigned long long)n_rows);
     HIP_TRY(hipSetDevice(c->p.device));
-    const uint32_t pitch = c->dp.pitch, row_bytes = (c->p.num_buckets + 7u) >> 3;
+    const uint32_t pitch = c->dp.pitch;
     const uint64_t n_words = ((1ull << (2 * c->p.q)) + 31) / 32;
     HIP_TRY(dev_alloc(&c->d_rows, (size_t)(n_rows + 1) * pitch));
     HIP_TRY(dev_alloc(&c->d_k2i, (size_t)n_kmers));
@@ -457,14 +456,33 @@ int bmf_load_index(bmf_ctx *c, const uint8_t *rows, uint64_t n_rows, const int32
     HIP_TRY(dev_alloc(&c->d_qgram_ok, (size_t)n_words));
     HIP_TRY(hipMemsetAsync(c->d_rows, 0, (size_t)n_rows * pitch, c->stream));
     HIP_TRY(hipMemsetAsync(c->d_rows + (size_t)n_rows * pitch, 0xFF, pitch, c->stream));
+    if (n_kmers) HIP_TRY(hipMemcpyAsync(c->d_k2i, kmer_to_index, (size_t)n_kmers * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    if (n_rows) {
-        HIP_TRY(hipMemcpy2D(c->d_rows, pitch, rows, row_bytes, row_bytes, (size_t)n_rows, hipMemcpyHostToDevice));
-    }
-    if (n_kmers) HIP_TRY(hipMemcpy(c->d_k2i, kmer_to_index, (size_t)n_kmers * sizeof(int32_t), hipMemcpyHostToDevice));
     c->n_rows = n_rows;
     c->dp.ones_row = (uint32_t)n_rows;
     c->dp.n_kmers = (uint32_t)n_kmers;
+    return BMF_OK;
+}
+
+// rows [first, first + n) in the .qgram layout, to their 128-byte-pitched slots: one flat copy into a device
+// staging buffer, then bmf_repitch_kernel (a strided 2-D copy from the host runs at ~0.45 GB/s here)
+static hipError_t upload_rows(bmf_ctx *c, uint64_t first, uint64_t n, const uint8_t *rows, uint8_t *d_stage) {
+    const uint32_t pitch = c->dp.pitch, row_bytes = (c->p.num_buckets + 7u) >> 3;
+    hipError_t e = hipMemcpyAsync(d_stage, rows, (size_t)n * row_bytes, hipMemcpyHostToDevice, c->stream);
+    if (e != hipSuccess) return e;
+    const uint64_t work = n * ((row_bytes + 3u) / 4u);
+    hipLaunchKernelGGL(bmf::bmf_repitch_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, c->stream, d_stage,
+                       c->d_rows + (size_t)first * pitch, n, row_bytes, pitch);
+    return hipGetLastError();
+}
+
+// rows per piece of an upload (32 MiB)
+static uint64_t piece_rows_of(uint32_t row_bytes) { return std::max<uint64_t>(1, ((uint64_t)32 << 20) / std::max(1u, row_bytes)); }
+
+static int upload_finish(bmf_ctx *c) {
+    const uint32_t pitch = c->dp.pitch;
+    const uint64_t n_rows = c->n_rows, n_kmers = c->dp.n_kmers;
+    const uint64_t n_words = ((1ull << (2 * c->p.q)) + 31) / 32;
     if (n_rows) {
         hipLaunchKernelGGL(bmf::bmf_sanitize_rows_kernel, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, c->stream,
                            c->d_rows, n_rows, pitch, c->p.num_buckets);
@@ -477,6 +495,30 @@ int bmf_load_index(bmf_ctx *c, const uint8_t *rows, uint64_t n_rows, const int32
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->loaded = true;
     return select_pruned_variant(c);
+}
+
+int bmf_load_index(bmf_ctx *c, const uint8_t *rows, uint64_t n_rows, const int32_t *kmer_to_index,
+                   uint64_t n_kmers) {
+    if (!c) return fail(BMF_ERR_ARG, "bmf_load_index: null context");
+    if (n_rows && !rows && !c->loaded) return fail(BMF_ERR_ARG, "rows is null");
+    int rc = upload_begin(c, n_rows, kmer_to_index, n_kmers);
+    if (rc != BMF_OK) return rc;
+    if (n_rows) {
+        const uint32_t row_bytes = (c->p.num_buckets + 7u) >> 3;
+        const uint64_t piece_rows = piece_rows_of(row_bytes);
+        uint8_t *d_stage = nullptr;
+        hipError_t e = hipMalloc(reinterpret_cast<void **>(&d_stage), (size_t)piece_rows * row_bytes);
+        for (uint64_t first = 0; e == hipSuccess && first < n_rows; first += piece_rows) {
+            e = upload_rows(c, first, std::min(piece_rows, n_rows - first), rows + (size_t)first * row_bytes, d_stage);
+            if (e == hipSuccess) e = hipStreamSynchronize(c->stream);   // one staging buffer: pageable source
+        }
+        (void)hipFree(d_stage);
+        if (e != hipSuccess) {
+            free_index(c);
+            return fail(BMF_ERR_HIP, "uploading the index rows failed: %s", hipGetErrorString(e));
+        }
+    }
+    return upload_finish(c);
 }
 
 // GPU form of bucket_indexer::index (bucket_indexer.h:49-61,170-216): see bmi_kernels.hip.h.
@@ -573,8 +615,21 @@ int bmf_index_download(bmf_ctx *c, uint8_t *rows_out, uint64_t *n_rows_out) {
     if (!rows_out) return BMF_OK;
     HIP_TRY(hipSetDevice(c->p.device));
     const uint32_t row_bytes = (c->p.num_buckets + 7u) >> 3;
-    if (c->n_rows)
-        HIP_TRY(hipMemcpy2D(rows_out, row_bytes, c->d_rows, c->dp.pitch, row_bytes, (size_t)c->n_rows, hipMemcpyDeviceToHost));
+    // packed on the device piece by piece, then flat copies (a strided 2-D copy takes microseconds per row)
+    const uint64_t piece_rows = piece_rows_of(row_bytes);
+    uint8_t *d_stage = nullptr;
+    hipError_t e = c->n_rows ? hipMalloc(reinterpret_cast<void **>(&d_stage), (size_t)piece_rows * row_bytes) : hipSuccess;
+    for (uint64_t first = 0; e == hipSuccess && first < c->n_rows; first += piece_rows) {
+        const uint64_t n = std::min<uint64_t>(piece_rows, c->n_rows - first), bytes = n * row_bytes;
+        hipLaunchKernelGGL(bmf::bmf_pack_rows_kernel, dim3((unsigned)((bytes + 255) / 256)), dim3(256), 0, c->stream,
+                           c->d_rows + (size_t)first * c->dp.pitch, d_stage, n, row_bytes, c->dp.pitch);
+        e = hipGetLastError();
+        if (e == hipSuccess)
+            e = hipMemcpyAsync(rows_out + (size_t)first * row_bytes, d_stage, (size_t)bytes, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    }
+    (void)hipFree(d_stage);
+    if (e != hipSuccess) return fail(BMF_ERR_HIP, "bmf_index_download: %s", hipGetErrorString(e));
     return BMF_OK;
 }
 
@@ -601,19 +656,56 @@ int bmf_load_index_files(bmf_ctx *c, const char *index_dir, const char *indicato
         }
         fclose(f);
     }
-    // q_gram_mapper.h:345-358: `sampled` rows of ceil(NB/8) bytes
+    // q_gram_mapper.h:345-358: `sampled` rows of ceil(NB/8) bytes.  The file is read in pieces into two
+    // page-locked buffers; the copy of one piece to HBM overlaps the read of the next.
     const uint32_t row_bytes = (c->p.num_buckets + 7u) >> 3;
-    std::vector<uint8_t> rows((size_t)sampled * row_bytes);
-    {
-        FILE *f = fopen((base + ".qgram").c_str(), "rb");
-        if (!f) return fail(BMF_ERR_IO, "cannot open %s.qgram", base.c_str());
-        size_t got = fread(rows.data(), row_bytes, (size_t)sampled, f);
+    FILE *f = fopen((base + ".qgram").c_str(), "rb");
+    if (!f) return fail(BMF_ERR_IO, "cannot open %s.qgram", base.c_str());
+    int rc = upload_begin(c, sampled, k2i.data(), n_kmers);
+    if (rc != BMF_OK) {
         fclose(f);
-        if (got != sampled)
-            return fail(BMF_ERR_IO, "%s.qgram holds %zu rows of %u bytes, expected %llu", base.c_str(), got, row_bytes,
-                        (unsigned long long)sampled);
+        return rc;
     }
-    return bmf_load_index(c, rows.data(), sampled, k2i.data(), n_kmers);
+    const uint64_t piece_rows = piece_rows_of(row_bytes);
+    uint8_t *stage[2] = {nullptr, nullptr}, *d_stage[2] = {nullptr, nullptr};
+    hipEvent_t done[2] = {nullptr, nullptr};
+    hipError_t e = hipSuccess;
+    for (int i = 0; i < 2 && e == hipSuccess; i++) {
+        e = hipHostMalloc(reinterpret_cast<void **>(&stage[i]), (size_t)piece_rows * row_bytes, hipHostMallocDefault);
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&d_stage[i]), (size_t)piece_rows * row_bytes);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&done[i], hipEventDisableTiming);
+    }
+    uint64_t got_rows = 0;
+    bool short_file = false;
+    for (uint64_t first = 0, piece = 0; e == hipSuccess && first < sampled; first += piece_rows, piece++) {
+        const int slot = (int)(piece & 1);
+        const uint64_t n = std::min(piece_rows, sampled - first);
+        if (piece >= 2) e = hipEventSynchronize(done[slot]);       // the buffer's previous copy has left it
+        if (e != hipSuccess) break;
+        const size_t got = fread(stage[slot], row_bytes, (size_t)n, f);
+        got_rows += got;
+        if (got != n) {
+            short_file = true;
+            break;
+        }
+        e = upload_rows(c, first, n, stage[slot], d_stage[slot]);
+        if (e == hipSuccess) e = hipEventRecord(done[slot], c->stream);
+    }
+    fclose(f);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    for (int i = 0; i < 2; i++) {
+        if (stage[i]) (void)hipHostFree(stage[i]);
+        if (d_stage[i]) (void)hipFree(d_stage[i]);
+        if (done[i]) (void)hipEventDestroy(done[i]);
+    }
+    if (short_file || e != hipSuccess) {
+        free_index(c);
+        if (short_file)
+            return fail(BMF_ERR_IO, "%s.qgram holds %llu rows of %u bytes, expected %llu", base.c_str(),
+                        (unsigned long long)got_rows, row_bytes, (unsigned long long)sampled);
+        return fail(BMF_ERR_HIP, "uploading %s.qgram failed: %s", base.c_str(), hipGetErrorString(e));
+    }
+    return upload_finish(c);
 }
 
 int bmf_reset(bmf_ctx *c) {

@@ -65,6 +65,32 @@ __device__ __forceinline__ uint32_t hash_reverse_complement(uint32_t h, uint32_t
 
 // Clears the bits >= NB of the last index byte of every row (the reference's _bitset_from_bytes,
 // q_gram_mapper.h:238-248, never reads them) so popcounts and ANDs see exactly NB bits.
+// .qgram rows (row_bytes apart, any alignment) -> their 128-byte-pitched slots.  A strided 2-D copy from the
+// host takes ~7 us per row (1.9 s for 262 144 rows); one flat copy plus this kernel takes milliseconds.
+__global__ void bmf_repitch_kernel(const uint8_t *__restrict__ packed, uint8_t *__restrict__ rows, uint64_t n_rows,
+                                   uint32_t row_bytes, uint32_t pitch) {
+    const uint32_t words = (row_bytes + 3u) / 4u;
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_rows * words) return;
+    const uint64_t r = i / words;
+    const uint32_t b = (uint32_t)(i % words) * 4u;
+    const uint8_t *src = packed + r * row_bytes + b;
+    uint32_t v = 0;
+#pragma unroll
+    for (uint32_t t = 0; t < 4; t++)
+        if (b + t < row_bytes) v |= (uint32_t)src[t] << (8 * t);
+    *reinterpret_cast<uint32_t *>(rows + r * pitch + b) = v;
+}
+
+// The inverse, for bmf_index_download: pitched rows -> the packed .qgram layout, byte by byte (packed rows
+// start at any alignment).
+__global__ void bmf_pack_rows_kernel(const uint8_t *__restrict__ rows, uint8_t *__restrict__ packed, uint64_t n_rows,
+                                     uint32_t row_bytes, uint32_t pitch) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_rows * row_bytes) return;
+    packed[i] = rows[(i / row_bytes) * pitch + i % row_bytes];
+}
+
 __global__ void bmf_sanitize_rows_kernel(uint8_t *rows, uint64_t n_rows, uint32_t pitch, uint32_t nb) {
     uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_rows || (nb & 7u) == 0) return;

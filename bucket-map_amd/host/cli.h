@@ -51,7 +51,8 @@ struct cmd_arguments {
     uint64_t hash_seed = 20240004;
     unsigned int host_threads = 0;
     bool early_exit = false;   // BMF_FLAG_EARLY_EXIT (identical output, fewer index rows read)
-    bool gpu_index = false;    // build the index rows on the device (identical files)
+    int gpu_index = -1;        // index rows built on the device (identical files): 1 = --gpu-index, 0 = --host-index,
+                               // -1 = on the device where its kernels cover the seed length (3 <= -k <= 10)
 };
 
 struct parser_error : std::runtime_error {
@@ -149,7 +150,8 @@ inline cmd_arguments parse_arguments(int argc, char **argv) {
         else if (opt == "--gpus") a.gpus = parse_gpu_list(value());
         else if (opt == "--hash-seed") a.hash_seed = as_uint(value());
         else if (opt == "--early-exit") a.early_exit = true;
-        else if (opt == "--gpu-index") a.gpu_index = true;
+        else if (opt == "--gpu-index") a.gpu_index = 1;
+        else if (opt == "--host-index") a.gpu_index = 0;
         else if (opt == "--threads") a.host_threads = static_cast<unsigned>(as_uint(value()));
         else throw parser_error("Unknown option " + opt + ". In case this is meant to be a non-option/argument/parameter, please specify the start of non-options with '--'.");
     }

@@ -44,7 +44,10 @@ int main(int argc, char **argv) {
         return -1;
     }
     try {
+        auto t_fa = std::chrono::steady_clock::now();
         bm::Genome genome = bm::read_fasta(args.genome_path.string());
+        std::cerr << "[BENCHMARK]\tElapsed time for reading the reference genome: "
+                  << std::chrono::duration<float>(std::chrono::steady_clock::now() - t_fa).count() << " s.\n";
         const unsigned int num_buckets = args.num_buckets ? args.num_buckets : bm::awk_bucket_num(genome, args.bucket_len);
         std::cerr << "[INFO]\t\tInitializing indexer and mapper with bucket length: " << args.bucket_len
                   << ", and number of buckets: " << num_buckets << ".\n";
@@ -60,10 +63,13 @@ int main(int argc, char **argv) {
             }
             std::cerr << "[INFO]\t\tSet index seed length to be: " << static_cast<int>(args.index_seed_length) << ".\n";
             auto t0 = std::chrono::steady_clock::now();
-            // indexing is a host job in the reference and by default here; --gpu-index builds the same rows
-            // in HBM (bmf_build_index, byte-identical) and copies them back for the files
+            // indexing is a host job in the reference; here the same rows are built in HBM (bmf_build_index,
+            // byte-identical) and copied back for the files wherever the build's factory offers it and the
+            // seed length is one its kernels cover; --host-index / --gpu-index force either way
             bm::QgramIndex ix;
-            if (!(args.gpu_index && bm_gpu_index(args, genome, num_buckets, ix)))
+            const bool on_device = args.gpu_index == 1 ||
+                                   (args.gpu_index < 0 && args.index_seed_length >= 3 && args.index_seed_length <= 10);
+            if (!(on_device && bm_gpu_index(args, genome, num_buckets, ix)))
                 ix = bm::build_index(genome, num_buckets, static_cast<int>(args.bucket_len),
                                      static_cast<int>(args.max_read_length), args.index_seed_length,
                                      bm::FracMinHash::from_seed(args.hash_seed), args.frac_min_hash, args.host_threads);

@@ -83,7 +83,7 @@ def test_gpu_index_writes_identical_files(tmp_path, frac):
     g = host.Genome.synth(24, [500_000, 90_000])
     g.write_fasta(str(tmp_path / "g.fa"))
     common = ["--genome", "g.fa", "--bucket-len", "4096", "-r", "150", "-f", frac]
-    _run(GPU_CLI, ["-x", "-i", "host", *common], tmp_path)
+    _run(GPU_CLI, ["-x", "-i", "host", "--host-index", *common], tmp_path)
     err = _run(GPU_CLI, ["-x", "-i", "gpu", "--gpu-index", *common], tmp_path)
     assert "stored in" in err
     for ext in ("qgram", "kmers_index", "bucket_id"):

@@ -23,6 +23,7 @@ ap.add_argument("--reads", type=int, default=1_000_000)
 ap.add_argument("--dir", default="/tmp/bm_e2e")
 ap.add_argument("--out", default="")
 ap.add_argument("--extra", default="", help="extra CLI flags, e.g. '--early-exit'")
+ap.add_argument("--align", action="store_true", help="run bucketmap_align (alignment verification + CIGAR)")
 args = ap.parse_args()
 
 total_bp, bucket_len, read_len, _ = bench.WORKLOADS[args.workload]
@@ -52,9 +53,10 @@ t = time.perf_counter()
 r = subprocess.run([exe, "-x", *common], cwd=args.dir, capture_output=True, text=True)
 say(f"[e2e] index: exit {r.returncode}, {time.perf_counter() - t:.1f} s")
 t = time.perf_counter()
-r = subprocess.run([exe, *common, "-q", "reads.fastq", "-o", "out.sam", *args.extra.split()], cwd=args.dir,
+map_exe = exe + "_align" if args.align else exe
+r = subprocess.run([map_exe, *common, "-q", "reads.fastq", "-o", "out.sam", *args.extra.split()], cwd=args.dir,
                    capture_output=True, text=True)
-say(f"[e2e] map: exit {r.returncode}, {time.perf_counter() - t:.1f} s wall")
+say(f"[e2e] map ({os.path.basename(map_exe)} {args.extra}): exit {r.returncode}, {time.perf_counter() - t:.1f} s wall")
 for line in r.stderr.splitlines():
     if "[BENCHMARK]" in line or "[ERROR]" in line:
         say("    " + line)
