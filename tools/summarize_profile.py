@@ -17,16 +17,24 @@ root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 dst = os.path.join(root, "profiles", tag)
 os.makedirs(dst, exist_ok=True)
 stem = f"bench_{workload}_{params}"
-shutil.copy(glob.glob(os.path.join(src, "kt", "*", "*_kernel_stats.csv"))[0], os.path.join(dst, stem + "_kernel_stats.csv"))
+
+
+def newest(pattern):
+    """gpurun merges every call's files into the same directory: take the latest run's."""
+    return max(glob.glob(pattern), key=os.path.getmtime)
+
+
+shutil.copy(newest(os.path.join(src, "kt", "*", "*_kernel_stats.csv")), os.path.join(dst, stem + "_kernel_stats.csv"))
 summary = {}
 for d in ("pmc_fetch", "pmc_l2"):
     agg = collections.defaultdict(list)
-    for r in csv.DictReader(open(glob.glob(os.path.join(src, d, "*", "*_counter_collection.csv"))[0])):
+    for r in csv.DictReader(open(newest(os.path.join(src, d, "*", "*_counter_collection.csv")))):
         agg[(r["Kernel_Name"].split("(")[0], r["Counter_Name"])].append(float(r["Counter_Value"]))
     for (k, c), v in sorted(agg.items()):
         summary.setdefault(k, {})[c] = {"dispatches": len(v), "mean": sum(v) / len(v)}
 json.dump(summary, open(os.path.join(dst, stem + "_pmc_summary.json"), "w"), indent=1)
-vote = next(k for k in summary if "bmf_vote_kernel" in k)
+# the headline kernel: the vote kernel without pruning (template arguments ..., false, false>)
+vote = next(k for k in summary if "bmf_vote_kernel" in k and k.rstrip().endswith("false, false>"))
 fetch_kib = summary[vote]["FETCH_SIZE"]["mean"]
 latest = {
     "workload": workload, "params": params, "reads": reads, "kernel": vote,
@@ -36,5 +44,9 @@ latest = {
     "l2_hit_rate": summary[vote]["TCC_HIT_sum"]["mean"] / (summary[vote]["TCC_HIT_sum"]["mean"] + summary[vote]["TCC_MISS_sum"]["mean"]),
     "source": f"profiles/{tag}/{stem}_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE, own pass; x1024 x2)",
 }
+# bytes the pruning kernels really fetched, for DESIGN.md 4.2 (same x1024 x2 correction)
+for k in summary:
+    if "FETCH_SIZE" in summary[k] and any(n in k for n in ("bmf_pass1_kernel", "bmf_recount_kernel", "bmf_vote2_slow_kernel")):
+        latest.setdefault("pruning_kernels_traffic_bytes", {})[k] = int(summary[k]["FETCH_SIZE"]["mean"] * 1024 * 2)
 json.dump(latest, open(os.path.join(root, "profiles", "pmc_latest.json"), "w"), indent=1)
 print(json.dumps(latest, indent=1))
