@@ -119,8 +119,13 @@ int bmv_create(const bmv_params *params, bmv_ctx **out) {
     HIP_TRY(hipSetDevice(params->device));
     bmv_ctx *c = new bmv_ctx();
     c->p = *params;
-    // traceback bits of the alignments in flight; BMV_SCRATCH_MB overrides (tests use it to force chunking)
+    // traceback bits of the alignments in flight: a quarter of the free HBM, 1..48 GiB (a 10-kbp alignment
+    // keeps 28 MB of trace and is one wave: long reads want thousands in flight); BMV_SCRATCH_MB overrides
+    // (tests use it to force chunking)
+    size_t free_b = 0, total_b = 0;
     c->scratch_bytes = (size_t)8 << 30;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
+        c->scratch_bytes = std::min<size_t>(std::max<size_t>(free_b / 4, (size_t)1 << 30), (size_t)48 << 30);
     if (const char *env = getenv("BMV_SCRATCH_MB")) {
         const long v = strtol(env, nullptr, 10);
         if (v > 0) c->scratch_bytes = (size_t)v << 20;
