@@ -291,3 +291,33 @@ def test_bucketmap_align_sam_identical_to_oracle_backed_run(tmp_path, profile):
         # 60u + score wraps for more than 60 edits and is written through an 8-bit field (bucket_locator.h:570):
         # a 4-kbp read at 8 % errors has ~300 edits, so only the short profile stays within 0..60
         assert profile == "long" or int(r[4]) <= 60
+
+
+# ------------------------------------------------------------------------------------------------ golden
+
+def _golden_align():
+    import json
+    return json.load(open(os.path.join(ROOT, "tests", "golden", "align_small.json")))["cases"]
+
+
+def test_oracle_matches_golden_alignments():
+    """tests/golden/align_small.json comes from a plain-Python restatement (tests/golden/make_golden.py)."""
+    for c in _golden_align():
+        assert oc.align(c["text"].encode(), c["query"].encode(), c["rc"]) == (c["score"], c["begin"], c["cigar"]), c
+
+
+@pytest.mark.gpu
+def test_gpu_verifier_matches_golden_alignments():
+    from bucket_map_amd import verify
+    cases = _golden_align()
+    genome = np.frombuffer("".join(c["text"] for c in cases).encode() + b"A", np.uint8)
+    reads = np.frombuffer("".join(c["query"] for c in cases).encode() + b"A", np.uint8)
+    ts = np.cumsum([0] + [len(c["text"]) for c in cases])[:-1].astype(np.uint64)
+    qs = np.cumsum([0] + [len(c["query"]) for c in cases])[:-1].astype(np.uint64)
+    v = verify.Verifier()
+    v.load_genome(genome)
+    s, b, off, cg = v.align(reads, ts, [len(c["text"]) for c in cases], [int(c["rc"]) for c in cases], qs,
+                            [len(c["query"]) for c in cases])
+    for i, c in enumerate(cases):
+        assert (int(s[i]), int(b[i]), verify.cigar_string(cg[off[i]:off[i + 1]])) == (c["score"], c["begin"], c["cigar"]), c
+    v.close()

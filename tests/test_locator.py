@@ -253,3 +253,40 @@ def test_gpu_sampling_equals_oracle(k, p, max_len, minq):
     for a, b, what in zip(want, got, ("hash", "position", "has-samples")):
         assert np.array_equal(a, b), what
     scan.close()
+
+
+def _golden_sampling():
+    import json
+    here = os.path.dirname(os.path.abspath(__file__))
+    return json.load(open(os.path.join(here, "golden", "sampling_small.json")))["groups"]
+
+
+def _sampling_batch(group):
+    bases = np.frombuffer("".join(w["bases"] for w in group["windows"]).encode() + b"A", np.uint8)
+    quals = np.frombuffer("".join(w["quals"] for w in group["windows"]).encode() + b"I", np.uint8)
+    lens = [len(w["bases"]) for w in group["windows"]]
+    ws = np.cumsum([0] + lens)[:-1].astype(np.uint64)
+    want = (np.array([w["hash"] for w in group["windows"]], np.uint32), np.array([w["pos"] for w in group["windows"]], np.uint16),
+            np.array([w["has"] for w in group["windows"]], np.uint8))
+    return bases, quals, ws, np.array(lens, np.uint32), want
+
+
+def test_oracle_sampling_matches_golden():
+    """tests/golden/sampling_small.json comes from a plain-Python restatement (tests/golden/make_golden.py)."""
+    for g in _golden_sampling():
+        bases, quals, ws, wl, want = _sampling_batch(g)
+        got = oc.sample_windows(g["k"], g["p"], g["min_base_quality"], bases, quals, ws, wl)
+        for a, b, what in zip(want, got, ("hash", "position", "has-samples")):
+            assert np.array_equal(a, b), (g["k"], g["p"], what)
+
+
+@pytest.mark.gpu
+def test_gpu_sampling_matches_golden():
+    from bucket_map_amd import locate
+    for g in _golden_sampling():
+        bases, quals, ws, wl, want = _sampling_batch(g)
+        scan = locate.LocatorScan(g["k"], g["p"], 4, 6, 70000)
+        got = scan.sample_windows(bases, quals, ws, wl, g["min_base_quality"])
+        for a, b, what in zip(want, got, ("hash", "position", "has-samples")):
+            assert np.array_equal(a, b), (g["k"], g["p"], what)
+        scan.close()
