@@ -1,3 +1,8 @@
+"""Times the index upload paths on the GPU box: bmf_load_index_files (streamed .qgram) twice, a plain Python read of
+the same file, and bmf_load_index from memory.  Expects the files tools/e2e_cli.py leaves in /tmp/bm_e2e.
+
+    python tools/e2e_cli.py --reads 1000 && python tools/time_index_load.py
+"""
 import sys, time, os
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")); sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "bucket-map_amd", "python"))
 import numpy as np
