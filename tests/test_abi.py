@@ -75,6 +75,17 @@ def test_no_silent_cpu_fallback():
     assert e.value.code == bma.BMF_ERR_HIP
 
 
+@pytest.mark.skipif(os.path.exists("/dev/kfd"), reason="only meaningful without a GPU")
+def test_no_silent_cpu_fallback_in_locator_and_verifier():
+    from bucket_map_amd import locate, verify
+    with pytest.raises(locate.BmlError) as e:
+        locate.LocatorScan(12, 10, 4, 6, 65836)
+    assert e.value.code == 2                                         # BML_ERR_HIP
+    with pytest.raises(verify.BmvError) as e:
+        verify.Verifier()
+    assert e.value.code == 2                                         # BMV_ERR_HIP
+
+
 def test_product_does_not_link_the_oracle():
     import subprocess
     out = subprocess.run(["ldd", bma.LIBBMF_PATH], capture_output=True, text=True).stdout
