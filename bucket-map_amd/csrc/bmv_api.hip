@@ -219,7 +219,10 @@ int bmv_align(bmv_ctx *c, const uint8_t *reads, uint64_t n_read_bytes, const uin
     const Shape sh = pick_shape(words ? words : 1u);
     const uint32_t l_max = std::max(1u, (words + (uint32_t)sh.cw - 1u) / (uint32_t)sh.cw);
     const uint32_t gpw = 64u / (uint32_t)sh.group;
-    const uint64_t trace_stride = (uint64_t)(max_n + l_max + 1u) * gpw * l_max * (uint32_t)sh.cw * 2u;   // words per wave
+    // checkpoints every 16 columns: (Pv, Mv) per word, plus one 32-bit word of horizontal deltas per word and block
+    const uint32_t n_blocks = (max_n + 15u) / 16u + 1u;
+    const uint64_t n_entries = (uint64_t)n_blocks * gpw * l_max * (uint32_t)sh.cw;
+    const uint64_t trace_stride = n_entries * 2u + (n_entries + 1u) / 2u;   // 64-bit words per wave
     const uint32_t ops_stride = max_m + max_n + 1u;
     const uint32_t lds_stride = (max_n + 15u) & ~15u, qry_stride = std::max(64u, (max_m + 63u) & ~63u);
     const size_t lds = 256 + (size_t)gpw * (lds_stride + qry_stride);
@@ -255,6 +258,7 @@ int bmv_align(bmv_ctx *c, const uint8_t *reads, uint64_t n_read_bytes, const uin
         j.trace = c->trace.p;
         j.trace_stride = trace_stride;
         j.trace_lanes = l_max;
+        j.trace_blocks = n_blocks;
         j.ops_rev = c->ops_rev.p;
         j.ops_stride = ops_stride;
         j.text_lds_stride = lds_stride;

@@ -13,15 +13,18 @@
 // power of two that holds the query, so a wave verifies 64/GROUP candidates at once (16 for 150-bp reads,
 // 8 for 300-bp reads, 1 for 10-kbp reads).
 //
-// Per cell two bits are kept for the traceback: "the diagonal predecessor is valid" (match with diagonal
-// delta 0, or mismatch with diagonal delta 1: ~(Eq ^ D0)) and "the upper predecessor is valid" (vertical
-// delta +1: Pv); when neither holds the left one must be.  They go to HBM in step-major order per WAVE: the
-// entries all alignments of a wave write in one step are one contiguous run (640 B for 300-bp reads), and
-// a wave's steps follow each other in memory -- per-alignment streams of 80-byte pieces ran at a fifth of
-// the write bandwidth.  The traceback walks from the LAST minimum of the bottom row,
-// trying diagonal, up, left in that order (include/bmv.h, tie rules 1-2), reading the trace
-// GROUP columns at a time, and leaves run-length CIGAR entries in reverse; bmv_gather_kernel reverses and
-// packs them.
+// Traceback.  Per cell two bits decide the walk: "the diagonal predecessor is valid" (match with diagonal
+// delta 0, or mismatch with diagonal delta 1: ~(Eq ^ D0)) and "the upper predecessor is valid" (vertical delta
+// +1: Pv); when neither holds the left one must be.  Writing them for every cell is 16 B per word and column
+// -- 25 KB per 300x307 alignment, 28 MB per 10-kbp alignment -- and the stores, not the arithmetic, set the
+// kernel's time.  So the forward pass keeps only CHECKPOINTS: every kBlock = 16 columns the vertical state
+// (Pv, Mv) of each word, and for every column the horizontal delta that leaves each word (2 bits, 16 columns
+// per 32-bit word): 1.25 B per word and column.  The traceback walks from the LAST minimum of the bottom row,
+// trying diagonal, up, left in that order (include/bmv.h, tie rules 1-2); when it enters a (word, column
+// block) it recomputes that block's 16 column steps from the checkpoint -- the horizontal deltas entering
+// the word are the stored ones of the word above, so one word is recomputed on its own -- and the lanes of
+// the group keep the 16 pairs of trace words in registers.  Run-length CIGAR entries are left in reverse;
+// bmv_gather_kernel reverses and packs them.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -41,9 +44,10 @@ struct Job {
     const uint64_t *query_start;
     const uint32_t *query_len;
     uint32_t first, count;          // this launch handles alignments [first, first + count); slot = a - first
-    uint64_t *trace;                // one region of trace_stride words per wave (64/GROUP alignments)
-    uint64_t trace_stride;
-    uint32_t trace_lanes;           // lanes per alignment that own trace entries in this batch (>= every L)
+    uint64_t *trace;                // one region of trace_stride words per wave (64/GROUP alignments):
+    uint64_t trace_stride;          //   checkpoints (Pv, Mv) [block][group][lane][c], then horizontal deltas
+    uint32_t trace_lanes;           // lanes per alignment that own words in this batch (>= every L)
+    uint32_t trace_blocks;          // column blocks reserved per alignment (>= every ceil(n / 16) + 1)
     uint32_t *ops_rev;              // count x ops_stride reversed CIGAR entries
     uint32_t ops_stride;
     uint32_t text_lds_stride;       // bytes of LDS per group for the text window ...
@@ -57,6 +61,29 @@ __device__ __forceinline__ uint64_t shfl64(uint64_t v, int src, int width) {
     const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)v, src, width);
     const uint32_t hi = (uint32_t)__shfl((int)(uint32_t)(v >> 32), src, width);
     return ((uint64_t)hi << 32) | lo;
+}
+
+constexpr uint32_t kBlock = 16;   // columns between checkpoints = horizontal deltas per 32-bit word
+
+// One column step of one 64-row word (Myers 1999 in Hyyro's block form).  eq0: rows that match the text
+// base; hin: horizontal delta entering the word from above (-1, 0, +1).  Updates (pv, mv) to this column,
+// returns the delta leaving the word; ph / mh are the horizontal deltas of the rows BEFORE the shift (bit r =
+// row r of the word), d0 the rows whose diagonal delta is 0.
+__device__ __forceinline__ int myers_step(uint64_t eq0, int hin, uint64_t &pv, uint64_t &mv, uint64_t &ph, uint64_t &mh,
+                                          uint64_t &d0) {
+    const uint64_t hin_neg = hin < 0 ? 1ull : 0ull;
+    const uint64_t xv = eq0 | mv;
+    const uint64_t eq = eq0 | hin_neg;
+    const uint64_t xh = (((eq & pv) + pv) ^ pv) | eq;
+    ph = mv | ~(xh | pv);
+    mh = pv & xh;
+    d0 = xh | mv;
+    const int hout = (int)(ph >> 63) - (int)(mh >> 63);
+    const uint64_t phs = (ph << 1) | (hin > 0 ? 1ull : 0ull);
+    const uint64_t mhs = (mh << 1) | hin_neg;
+    pv = mhs | ~(xv | phs);
+    mv = phs & xv;
+    return hout;
 }
 
 template <int GROUP, int CW>
@@ -124,9 +151,11 @@ __global__ __launch_bounds__(kWave) void bmv_align_kernel(Job J) {
     int32_t score = (int32_t)m, best = (int32_t)m;              // tracked by the lane that holds row m
     uint32_t best_j = 0;
     const uint32_t last_lane = W ? (W - 1u) / CW : 0u, last_c = W ? (W - 1u) % CW : 0u, last_bit = (m - 1u) & 63u;
-    // trace entries of one step of the whole wave are contiguous: ((t * GPW + grp) * lanes + gl) * CW + c
-    uint64_t *trace = J.trace + (size_t)blockIdx.x * J.trace_stride;
+    // checkpoint entry of (block b, this group, lane l, word c of the lane): ((b * GPW + grp) * TL + l) * CW + c
     const uint32_t TL = J.trace_lanes;
+    uint64_t *ckpt = J.trace + (size_t)blockIdx.x * J.trace_stride;
+    uint32_t *hbuf = reinterpret_cast<uint32_t *>(ckpt + (size_t)J.trace_blocks * GPW * TL * CW * 2u);
+    auto entry = [&](uint32_t b, uint32_t l, uint32_t c) { return (((size_t)b * GPW + grp) * TL + l) * CW + c; };
 
     // every group of the wave runs the same number of steps (shuffles need the whole wave)
     uint32_t steps = (have && W) ? n + L - 1u : 0u;
@@ -136,24 +165,24 @@ __global__ __launch_bounds__(kWave) void bmv_align_kernel(Job J) {
         steps = other > steps ? other : steps;
     }
     int hout_prev = 0;
+    uint32_t hacc[CW];                                          // horizontal deltas of the current block, 2 bits each
+#pragma unroll
+    for (int c = 0; c < CW; c++) hacc[c] = 0;
     for (uint32_t t = 1; t <= steps; t++) {
         int hin = __shfl_up(hout_prev, 1, GROUP);
         if (gl == 0) hin = 0;                                   // row 0 is all zeros: free leading text gaps
         const uint32_t j = t - gl;                              // 1-based text column of this lane
         if (gl < L && j >= 1u && j <= n && t >= gl + 1u) {
             const uint8_t ch = text[j - 1u];
+            const uint32_t x = (j - 1u) % kBlock;
+            const bool block_end = x == kBlock - 1u || j == n;
 #pragma unroll
             for (int c = 0; c < CW; c++) {
                 const uint32_t w = gl * CW + c;
                 if (w < W) {
                     const uint64_t eq0 = ch == 0 ? peq[0][c] : (ch == 1 ? peq[1][c] : (ch == 2 ? peq[2][c] : peq[3][c]));
-                    const uint64_t hin_neg = hin < 0 ? 1ull : 0ull;
-                    const uint64_t xv = eq0 | mv[c];
-                    const uint64_t eq = eq0 | hin_neg;
-                    const uint64_t xh = (((eq & pv[c]) + pv[c]) ^ pv[c]) | eq;
-                    uint64_t ph = mv[c] | ~(xh | pv[c]);
-                    uint64_t mh = pv[c] & xh;
-                    const uint64_t d0 = xh | mv[c];            // diagonal delta is 0
+                    uint64_t ph, mh, d0;
+                    const int hout = myers_step(eq0, hin, pv[c], mv[c], ph, mh, d0);
                     if (gl == last_lane && c == (int)last_c) {
                         score += (int32_t)((ph >> last_bit) & 1ull) - (int32_t)((mh >> last_bit) & 1ull);
                         if (score <= best) {                    // the LAST minimum of the bottom row
@@ -161,21 +190,23 @@ __global__ __launch_bounds__(kWave) void bmv_align_kernel(Job J) {
                             best_j = j;
                         }
                     }
-                    const int hout = (int)(ph >> 63) - (int)(mh >> 63);
-                    ph = (ph << 1) | (hin > 0 ? 1ull : 0ull);
-                    mh = (mh << 1) | hin_neg;
-                    pv[c] = mh | ~(xv | ph);
-                    mv[c] = ph & xv;
                     hin = hout;
-                    uint64_t *tr = trace + ((((size_t)t * GPW + grp) * TL + gl) * CW + c) * 2u;
-                    tr[0] = ~(eq0 ^ d0);                        // diagonal predecessor valid
-                    tr[1] = pv[c];                              // upper predecessor valid
+                    hacc[c] |= (uint32_t)(hout + 1) << (2u * x);
+                    if (block_end) {
+                        hbuf[entry((j - 1u) / kBlock, gl, c)] = hacc[c];
+                        hacc[c] = 0;
+                        if (j < n) {                            // state the next block starts from
+                            uint64_t *ck = ckpt + entry(j / kBlock, gl, c) * 2u;
+                            ck[0] = pv[c];
+                            ck[1] = mv[c];
+                        }
+                    }
                 }
             }
             hout_prev = hin;
         }
     }
-    // the traceback reads trace words other lanes of this wave wrote: same wave, same L1, lines never read
+    // the traceback reads checkpoints other lanes of this wave wrote: same wave, same L1, lines never read
     // before, so completing the stores (workgroup scope) is all the ordering that is needed -- a device-wide
     // fence here cost 3.7 ms per million alignments
     __threadfence_block();
@@ -189,51 +220,111 @@ __global__ __launch_bounds__(kWave) void bmv_align_kernel(Job J) {
         best_j = n;
     }
 
-    // traceback, the whole group in step; lane 0 of the group writes
-    uint32_t *ops = J.ops_rev + (size_t)slot * J.ops_stride;
-    uint32_t i = m, j = best_j, n_rev = 0, cur_op = 3, cur_len = 0;
-    uint32_t wc = 0xFFFFFFFFu, jc = 0;
-    uint64_t db = 0, ub = 0;
-    while (i > 0) {
-        uint32_t op;
-        if (j == 0) {                                           // column 0: only the upper predecessor
-            op = 1;
-            i--;
-        } else {
-            const uint32_t w = (i - 1u) >> 6;
-            if (w != wc || j > jc || j + GROUP <= jc) {         // (re)load GROUP columns of word w ending at j
-                wc = w;
-                jc = j;
-                const uint32_t owner = w / CW, c = w % CW;
-                if (jc > gl) {
-                    const uint32_t col = jc - gl;
-                    const uint64_t *tr = trace + ((((size_t)(col + owner) * GPW + grp) * TL + owner) * CW + c) * 2u;
-                    db = tr[0];
-                    ub = tr[1];
+    // traceback, the whole group in step; lane 0 of the group writes.  The trace words of the current
+    // (word, column block) live in registers: lane x % kHold keeps column x of the block in slot x / kHold.
+    constexpr uint32_t kHold = GROUP < (int)kBlock ? (uint32_t)GROUP : kBlock;
+    constexpr int kSlots = (int)(kBlock / kHold);
+    uint64_t db[kSlots], ub[kSlots];
+#pragma unroll
+    for (int q = 0; q < kSlots; q++) db[q] = ub[q] = 0;
+    // checkpoint of (word w, block b): vertical state the block starts from, and the deltas entering the word
+    // = the deltas that left the word above (row 0 for the first word: all zero)
+    struct Checkpoint {
+        uint64_t pv, mv;
+        uint32_t hw;
+    };
+    auto load_checkpoint = [&](uint32_t w, uint32_t b) {
+        Checkpoint k{~0ull, 0ull, 0x55555555u};                 // block 0 starts from column 0: H[i][0] = i
+        if (b) {
+            const uint64_t *ck = ckpt + entry(b, w / CW, w % CW) * 2u;
+            k.pv = ck[0];
+            k.mv = ck[1];
+        }
+        if (w) k.hw = hbuf[entry(b, (w - 1u) / CW, (w - 1u) % CW)];
+        return k;
+    };
+    auto refill = [&](uint32_t w, uint32_t b, Checkpoint k) {
+        const uint32_t owner = w / CW, c = w % CW;
+        uint64_t pm[4];                                         // the word's match masks, from the lane that owns it
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            uint64_t v = peq[r][0];
+#pragma unroll
+            for (int cc = 1; cc < CW; cc++) v = c == (uint32_t)cc ? peq[r][cc] : v;
+            pm[r] = shfl64(v, (int)owner, GROUP);
+        }
+#pragma unroll
+        for (int x = 0; x < (int)kBlock; x++) {
+            const uint32_t col = b * kBlock + 1u + (uint32_t)x;
+            if (col <= n) {
+                const uint8_t ch = text[col - 1u];
+                const uint64_t eq0 = ch == 0 ? pm[0] : (ch == 1 ? pm[1] : (ch == 2 ? pm[2] : pm[3]));
+                uint64_t ph, mh, d0;
+                myers_step(eq0, (int)((k.hw >> (2 * x)) & 3u) - 1, k.pv, k.mv, ph, mh, d0);
+                if (gl == (uint32_t)x % kHold) {
+                    db[x / (int)kHold] = ~(eq0 ^ d0);           // diagonal predecessor valid
+                    ub[x / (int)kHold] = k.pv;                  // upper predecessor valid
                 }
             }
-            const int src = (int)(jc - j);
-            const uint64_t d = shfl64(db, src, GROUP), u = shfl64(ub, src, GROUP);
-            const uint32_t bit = (i - 1u) & 63u;
-            if ((d >> bit) & 1ull) {
-                op = 0;
-                i--;
-                j--;
-            } else if ((u >> bit) & 1ull) {
+        }
+    };
+    uint32_t *ops = J.ops_rev + (size_t)slot * J.ops_stride;
+    uint32_t i = m, j = best_j, n_rev = 0, cur_op = 3, cur_len = 0;
+    // Rounds: every group that is still walking recomputes its next (word, block) at the same time -- one
+    // pass through the 16 column steps for the whole wave -- and then walks until it leaves that block.  (A
+    // group refilling on its own would run those steps with the other groups masked off: 64/GROUP times the
+    // instructions.)
+    // The walk mostly runs down the diagonal, so the block it enters next is usually the one to the left in
+    // the same word: that checkpoint is requested while the current block is walked.
+    uint32_t nw = 0xFFFFFFFFu, nb = 0;
+    Checkpoint next{0, 0, 0};
+    while (__ballot(i > 0) != 0) {
+        uint32_t wc = 0, bc = 0;
+        if (i > 0 && j > 0) {
+            wc = (i - 1u) >> 6;
+            bc = (j - 1u) / kBlock;
+            refill(wc, bc, (wc == nw && bc == nb) ? next : load_checkpoint(wc, bc));
+            if (bc > 0) {
+                nw = wc;
+                nb = bc - 1u;
+                next = load_checkpoint(nw, nb);
+            }
+        }
+        while (i > 0 && (j == 0 || (((i - 1u) >> 6) == wc && (j - 1u) / kBlock == bc))) {
+            uint32_t op;
+            if (j == 0) {                                       // column 0: only the upper predecessor
                 op = 1;
                 i--;
             } else {
-                op = 2;
-                j--;
+                const uint32_t x = (j - 1u) % kBlock, held = x / kHold;
+                uint64_t md = db[0], mu = ub[0];
+#pragma unroll
+                for (int q = 1; q < kSlots; q++) {
+                    md = held == (uint32_t)q ? db[q] : md;
+                    mu = held == (uint32_t)q ? ub[q] : mu;
+                }
+                const uint64_t d = shfl64(md, (int)(x % kHold), GROUP), u = shfl64(mu, (int)(x % kHold), GROUP);
+                const uint32_t bit = (i - 1u) & 63u;
+                if ((d >> bit) & 1ull) {
+                    op = 0;
+                    i--;
+                    j--;
+                } else if ((u >> bit) & 1ull) {
+                    op = 1;
+                    i--;
+                } else {
+                    op = 2;
+                    j--;
+                }
             }
-        }
-        if (op == cur_op) {
-            cur_len++;
-        } else {
-            if (cur_len && gl == 0) ops[n_rev] = (cur_len << 4) | cur_op;
-            n_rev += cur_len ? 1u : 0u;
-            cur_op = op;
-            cur_len = 1;
+            if (op == cur_op) {
+                cur_len++;
+            } else {
+                if (cur_len && gl == 0) ops[n_rev] = (cur_len << 4) | cur_op;
+                n_rev += cur_len ? 1u : 0u;
+                cur_op = op;
+                cur_len = 1;
+            }
         }
     }
     if (cur_len) {
