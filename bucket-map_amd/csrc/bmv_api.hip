@@ -65,18 +65,23 @@ struct DevBuf {
 using align_fn = void (*)(bmv::Job);
 
 struct Shape {
-    int group, cw;
+    uint32_t group;   // lanes per alignment
+    int cw;           // 64-row words per lane
     align_fn fn;
 };
 
-// smallest shape whose GROUP * CW words hold a query of `words` 64-row words
+// A group is exactly as many lanes as the longest query has words (CW words per lane beyond 64 words); the
+// kernel variant only fixes how many of the group's lanes hold the traceback's 16 pairs of trace words.
 Shape pick_shape(uint32_t words) {
-    if (words <= 4) return {4, 1, bmv::bmv_align_kernel<4, 1>};
-    if (words <= 8) return {8, 1, bmv::bmv_align_kernel<8, 1>};
-    if (words <= 16) return {16, 1, bmv::bmv_align_kernel<16, 1>};
-    if (words <= 64) return {64, 1, bmv::bmv_align_kernel<64, 1>};
-    if (words <= 128) return {64, 2, bmv::bmv_align_kernel<64, 2>};
-    return {64, 4, bmv::bmv_align_kernel<64, 4>};
+    const int cw = words <= 64 ? 1 : (words <= 128 ? 2 : 4);
+    const uint32_t g = std::max(1u, (words + (uint32_t)cw - 1u) / (uint32_t)cw);
+    if (cw == 2) return {g, 2, bmv::bmv_align_kernel<1, 2>};
+    if (cw == 4) return {g, 4, bmv::bmv_align_kernel<1, 4>};
+    if (g >= 16) return {g, 1, bmv::bmv_align_kernel<1, 1>};
+    if (g >= 8) return {g, 1, bmv::bmv_align_kernel<2, 1>};
+    if (g >= 4) return {g, 1, bmv::bmv_align_kernel<4, 1>};
+    if (g >= 2) return {g, 1, bmv::bmv_align_kernel<8, 1>};
+    return {g, 1, bmv::bmv_align_kernel<16, 1>};
 }
 
 }  // namespace
@@ -217,8 +222,8 @@ int bmv_align(bmv_ctx *c, const uint8_t *reads, uint64_t n_read_bytes, const uin
     // kernel shape for the longest query; scratch per alignment slot
     const uint32_t words = (max_m + 63u) / 64u;
     const Shape sh = pick_shape(words ? words : 1u);
-    const uint32_t l_max = std::max(1u, (words + (uint32_t)sh.cw - 1u) / (uint32_t)sh.cw);
-    const uint32_t gpw = 64u / (uint32_t)sh.group;
+    const uint32_t l_max = sh.group;
+    const uint32_t gpw = 64u / sh.group;
     // checkpoints every 16 columns: (Pv, Mv) per word, plus one 32-bit word of horizontal deltas per word and block
     const uint32_t n_blocks = (max_n + 15u) / 16u + 1u;
     const uint64_t n_entries = (uint64_t)n_blocks * gpw * l_max * (uint32_t)sh.cw;
@@ -259,6 +264,7 @@ int bmv_align(bmv_ctx *c, const uint8_t *reads, uint64_t n_read_bytes, const uin
         j.trace_stride = trace_stride;
         j.trace_lanes = l_max;
         j.trace_blocks = n_blocks;
+        j.group = sh.group;
         j.ops_rev = c->ops_rev.p;
         j.ops_stride = ops_stride;
         j.text_lds_stride = lds_stride;

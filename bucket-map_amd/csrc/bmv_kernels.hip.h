@@ -9,9 +9,9 @@
 // column as +1/-1 vertical deltas (Pv, Mv); a column step is ~20 word operations.  A query of m bases is
 // ceil(m/64) words; they are laid over the lanes of a GROUP (CW consecutive words per lane) and the lanes
 // are skewed along the text: at step t lane l works on column t-l and takes the horizontal delta that
-// leaves lane l-1's last row (computed one step earlier) through a shuffle.  GROUP is the smallest
-// power of two that holds the query, so a wave verifies 64/GROUP candidates at once (16 for 150-bp reads,
-// 8 for 300-bp reads, 1 for 10-kbp reads).
+// leaves lane l-1's last row (computed one step earlier) through a shuffle.  A group is exactly as many lanes
+// as the longest query of the batch has words (any size, not a power of two: lanes are addressed explicitly),
+// so a wave verifies 64/G candidates at once: 21 for 150-bp reads, 12 for 300-bp reads, 1 for 10-kbp reads.
 //
 // Traceback.  Per cell two bits decide the walk: "the diagonal predecessor is valid" (match with diagonal
 // delta 0, or mismatch with diagonal delta 1: ~(Eq ^ D0)) and "the upper predecessor is valid" (vertical delta
@@ -48,6 +48,7 @@ struct Job {
     uint64_t trace_stride;          //   checkpoints (Pv, Mv) [block][group][lane][c], then horizontal deltas
     uint32_t trace_lanes;           // lanes per alignment that own words in this batch (>= every L)
     uint32_t trace_blocks;          // column blocks reserved per alignment (>= every ceil(n / 16) + 1)
+    uint32_t group;                 // lanes per alignment (1..64); 64 / group alignments per wave
     uint32_t *ops_rev;              // count x ops_stride reversed CIGAR entries
     uint32_t ops_stride;
     uint32_t text_lds_stride;       // bytes of LDS per group for the text window ...
@@ -57,9 +58,9 @@ struct Job {
     uint32_t *out_nops;             // per slot
 };
 
-__device__ __forceinline__ uint64_t shfl64(uint64_t v, int src, int width) {
-    const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)v, src, width);
-    const uint32_t hi = (uint32_t)__shfl((int)(uint32_t)(v >> 32), src, width);
+__device__ __forceinline__ uint64_t shfl64(uint64_t v, int src_lane) {
+    const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)v, src_lane, kWave);
+    const uint32_t hi = (uint32_t)__shfl((int)(uint32_t)(v >> 32), src_lane, kWave);
     return ((uint64_t)hi << 32) | lo;
 }
 
@@ -86,13 +87,15 @@ __device__ __forceinline__ int myers_step(uint64_t eq0, int hin, uint64_t &pv, u
     return hout;
 }
 
-template <int GROUP, int CW>
+// SLOTS: trace-word pairs a lane keeps during the traceback (16 / SLOTS lanes of a group hold a block's 16
+// columns; needs group >= 16 / SLOTS).  CW: 64-row words per lane.
+template <int SLOTS, int CW>
 __global__ __launch_bounds__(kWave) void bmv_align_kernel(Job J) {
     extern __shared__ uint8_t lds_text[];
-    constexpr int GPW = kWave / GROUP;                         // groups (alignments) per wave
-    const uint32_t lane = threadIdx.x, grp = lane / GROUP, gl = lane % GROUP;
+    const uint32_t GROUP = J.group, GPW = kWave / GROUP;        // lanes per alignment, alignments per wave
+    const uint32_t lane = threadIdx.x, grp = lane / GROUP, gl = lane - grp * GROUP, lane0 = grp * GROUP;
     const uint32_t slot = blockIdx.x * GPW + grp;
-    const bool have = slot < J.count;
+    const bool have = grp < GPW && slot < J.count;              // (lanes past the last whole group are spare)
     const uint32_t a = J.first + (have ? slot : 0u);
     const uint32_t n = have ? J.text_len[a] : 0u, m = have ? J.query_len[a] : 0u;
     const uint32_t W = (m + 63u) >> 6;                         // words of the query
@@ -160,7 +163,7 @@ __global__ __launch_bounds__(kWave) void bmv_align_kernel(Job J) {
     // every group of the wave runs the same number of steps (shuffles need the whole wave)
     uint32_t steps = (have && W) ? n + L - 1u : 0u;
 #pragma unroll
-    for (int o = GROUP; o < kWave; o <<= 1) {
+    for (int o = 1; o < kWave; o <<= 1) {
         const uint32_t other = (uint32_t)__shfl_xor((int)steps, o, kWave);
         steps = other > steps ? other : steps;
     }
@@ -169,7 +172,7 @@ __global__ __launch_bounds__(kWave) void bmv_align_kernel(Job J) {
 #pragma unroll
     for (int c = 0; c < CW; c++) hacc[c] = 0;
     for (uint32_t t = 1; t <= steps; t++) {
-        int hin = __shfl_up(hout_prev, 1, GROUP);
+        int hin = __shfl_up(hout_prev, 1, kWave);
         if (gl == 0) hin = 0;                                   // row 0 is all zeros: free leading text gaps
         const uint32_t j = t - gl;                              // 1-based text column of this lane
         if (gl < L && j >= 1u && j <= n && t >= gl + 1u) {
@@ -213,17 +216,18 @@ __global__ __launch_bounds__(kWave) void bmv_align_kernel(Job J) {
     __syncthreads();
     if (!have) return;
 
-    best = __shfl(best, (int)last_lane, GROUP);
-    best_j = (uint32_t)__shfl((int)best_j, (int)last_lane, GROUP);
+    best = __shfl(best, (int)(lane0 + last_lane), kWave);
+    best_j = (uint32_t)__shfl((int)best_j, (int)(lane0 + last_lane), kWave);
     if (m == 0) {                                               // H[0][j] = 0 everywhere: last column
         best = 0;
         best_j = n;
     }
 
     // traceback, the whole group in step; lane 0 of the group writes.  The trace words of the current
-    // (word, column block) live in registers: lane x % kHold keeps column x of the block in slot x / kHold.
-    constexpr uint32_t kHold = GROUP < (int)kBlock ? (uint32_t)GROUP : kBlock;
-    constexpr int kSlots = (int)(kBlock / kHold);
+    // (word, column block) live in registers: lane x % kHold of the group keeps column x of the block in slot
+    // x / kHold.
+    constexpr int kSlots = SLOTS;
+    constexpr uint32_t kHold = kBlock / SLOTS;
     uint64_t db[kSlots], ub[kSlots];
 #pragma unroll
     for (int q = 0; q < kSlots; q++) db[q] = ub[q] = 0;
@@ -251,7 +255,7 @@ __global__ __launch_bounds__(kWave) void bmv_align_kernel(Job J) {
             uint64_t v = peq[r][0];
 #pragma unroll
             for (int cc = 1; cc < CW; cc++) v = c == (uint32_t)cc ? peq[r][cc] : v;
-            pm[r] = shfl64(v, (int)owner, GROUP);
+            pm[r] = shfl64(v, (int)(lane0 + owner));
         }
 #pragma unroll
         for (int x = 0; x < (int)kBlock; x++) {
@@ -303,7 +307,7 @@ __global__ __launch_bounds__(kWave) void bmv_align_kernel(Job J) {
                     md = held == (uint32_t)q ? db[q] : md;
                     mu = held == (uint32_t)q ? ub[q] : mu;
                 }
-                const uint64_t d = shfl64(md, (int)(x % kHold), GROUP), u = shfl64(mu, (int)(x % kHold), GROUP);
+                const uint64_t d = shfl64(md, (int)(lane0 + x % kHold)), u = shfl64(mu, (int)(lane0 + x % kHold));
                 const uint32_t bit = (i - 1u) & 63u;
                 if ((d >> bit) & 1ull) {
                     op = 0;
