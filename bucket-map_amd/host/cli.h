@@ -50,7 +50,8 @@ struct cmd_arguments {
     std::vector<int> gpus{0};
     uint64_t hash_seed = 20240004;
     unsigned int host_threads = 0;
-    bool early_exit = false;   // BMF_FLAG_EARLY_EXIT (identical output, fewer index rows read)
+    bool early_exit = true;    // BMF_FLAG_EARLY_EXIT (identical output, fewer index rows read); --no-early-exit
+                               // makes the filter read every row the reference reads
     int gpu_index = -1;        // index rows built on the device (identical files): 1 = --gpu-index, 0 = --host-index,
                                // -1 = on the device where its kernels cover the seed length (3 <= -k <= 10)
 };
@@ -150,6 +151,7 @@ inline cmd_arguments parse_arguments(int argc, char **argv) {
         else if (opt == "--gpus") a.gpus = parse_gpu_list(value());
         else if (opt == "--hash-seed") a.hash_seed = as_uint(value());
         else if (opt == "--early-exit") a.early_exit = true;
+        else if (opt == "--no-early-exit") a.early_exit = false;
         else if (opt == "--gpu-index") a.gpu_index = 1;
         else if (opt == "--host-index") a.gpu_index = 0;
         else if (opt == "--threads") a.host_threads = static_cast<unsigned>(as_uint(value()));
