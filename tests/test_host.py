@@ -273,3 +273,26 @@ def test_block_readers_survive_any_block_size(tmp_path, monkeypatch):
     (tmp_path / "cut.fastq").write_text("\n".join(recs[:-1]))
     with pytest.raises(RuntimeError):
         host.fastq_stats(str(tmp_path / "cut.fastq"))
+
+
+def test_fasta_reader_edge_cases(tmp_path):
+    """The memory-mapped, multi-threaded FASTA reader: CRLF, blank lines, '>' inside a header, no final newline,
+    blanks inside a sequence line, many records (several threads), an empty record, a file without a header."""
+    p = tmp_path / "e.fa"
+    p.write_bytes(b"\n>r1 with > inside\r\nACGT\r\n\r\nacgu nn\tRY\n>r2\n>r3 empty before\nTTTT\nGG")
+    g = host.Genome.read_fasta(str(p))
+    assert g.n_records == 3
+    assert [g.record_id(i) for i in range(3)] == ["r1 with > inside", "r2", "r3 empty before"]
+    assert bytes(g.record_seq(0)) == b"ACGTACGTAAAA" and bytes(g.record_seq(1)) == b"" and bytes(g.record_seq(2)) == b"TTTTGG"
+    many = tmp_path / "many.fa"
+    rng = np.random.default_rng(3)
+    seqs = ["".join("ACGT"[i] for i in rng.integers(0, 4, int(n))) for n in rng.integers(1, 400, 500)]
+    many.write_text("".join(f">s{i}\n" + "\n".join(s[j:j + 60] for j in range(0, len(s), 60)) + "\n" for i, s in enumerate(seqs)))
+    g = host.Genome.read_fasta(str(many))
+    assert g.n_records == 500 and all(bytes(g.record_seq(i)).decode() == seqs[i] for i in range(500))
+    bad = tmp_path / "bad.fa"
+    bad.write_text("ACGT\n>late\nAC\n")
+    with pytest.raises(Exception):
+        host.Genome.read_fasta(str(bad))
+    (tmp_path / "empty.fa").write_text("")
+    assert host.Genome.read_fasta(str(tmp_path / "empty.fa")).n_records == 0
