@@ -17,9 +17,12 @@
 #include "mapper.h"
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <iostream>
 #include <map>
+#include <memory>
+#include <thread>
 #include <tuple>
 
 namespace bm {
@@ -70,8 +73,7 @@ private:
     alignment_verifier *_v = nullptr;            // non-null: the BM_ALIGN behaviour
     const Genome *genome_ = nullptr;
     std::vector<Bucket> buckets_;
-    std::vector<uint8_t> flat_;                  // the records back to back (kept for the verifier only)
-    std::vector<uint64_t> bstart_;               // bucket views into flat_
+    std::vector<uint64_t> bstart_;               // bucket views into the records laid back to back
     std::vector<uint32_t> blen_;
 
     unsigned int bucket_length, read_length, min_base_quality;
@@ -219,10 +221,21 @@ public:
         {
             std::vector<uint64_t> rec_off(genome_->seqs.size() + 1, 0);
             for (size_t r = 0; r < genome_->seqs.size(); r++) rec_off[r + 1] = rec_off[r] + genome_->seqs[r].size();
-            std::vector<uint8_t> &flat = flat_;
-            flat.assign(rec_off.back(), 0);
-            for (size_t r = 0; r < genome_->seqs.size(); r++)
-                std::copy(genome_->seqs[r].begin(), genome_->seqs[r].end(), flat.begin() + static_cast<std::ptrdiff_t>(rec_off[r]));
+            // the records back to back, for the uploads only: uninitialised storage, copied by a few threads
+            const uint64_t total = rec_off.back();
+            std::unique_ptr<uint8_t[]> flat(new uint8_t[total ? total : 1]);
+            {
+                const unsigned n_thr = std::min<unsigned>(8, std::max(1u, std::thread::hardware_concurrency()));
+                std::atomic<size_t> next{0};
+                auto copy_records = [&]() {
+                    for (size_t r = next.fetch_add(1); r < genome_->seqs.size(); r = next.fetch_add(1))
+                        std::memcpy(flat.get() + rec_off[r], genome_->seqs[r].data(), genome_->seqs[r].size());
+                };
+                std::vector<std::thread> pool;
+                for (unsigned t = 1; t < n_thr; t++) pool.emplace_back(copy_records);
+                copy_records();
+                for (auto &t : pool) t.join();
+            }
             std::vector<uint64_t> &bstart = bstart_;
             std::vector<uint32_t> &blen = blen_;
             bstart.assign(buckets_.size(), 0);
@@ -231,12 +244,8 @@ public:
                 bstart[b] = rec_off[buckets_[b].record] + buckets_[b].start;
                 blen[b] = buckets_[b].end - buckets_[b].start;
             }
-            _s->load_genome(flat.data(), flat.size(), bstart.data(), blen.data(), static_cast<uint32_t>(buckets_.size()));
-            if (_v) {
-                _v->load_genome(flat.data(), flat.size());
-            } else {
-                std::vector<uint8_t>().swap(flat_);
-            }
+            _s->load_genome(flat.get(), total, bstart.data(), blen.data(), static_cast<uint32_t>(buckets_.size()));
+            if (_v) _v->load_genome(flat.get(), total);
         }
         prepare_read_query(sequence_file);
 
