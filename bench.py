@@ -264,7 +264,7 @@ def main():
         algo_bytes_read = algo_bytes_vote + 2 * int(win_len.sum())
         achieved = algo_bytes_vote / (vote_ms * 1e-3) / 1e9
         result = {
-            "metric": "mapped reads/sec (1M x 300bp, 65536-bp-bucket index)",
+            "metric": "mapped reads/sec (1M\u00d7300bp, 65536-bucket index)",   # BASELINE.json's metric, its first clause
             "value": reads_per_s, "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u32", "data": "synthetic",
