@@ -321,3 +321,20 @@ def test_gpu_verifier_matches_golden_alignments():
     for i, c in enumerate(cases):
         assert (int(s[i]), int(b[i]), verify.cigar_string(cg[off[i]:off[i + 1]])) == (c["score"], c["begin"], c["cigar"]), c
     v.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(int(os.environ.get("BM_SWEEP_SEEDS", "8"))))   # soak: BM_SWEEP_SEEDS=500
+def test_gpu_verifier_random_sweep(seed):
+    """Random batch shapes: the longest query decides the lanes per alignment (any size 1..64) and the words per
+    lane, so sweeping max_m sweeps every group size; error rates from clean to unrelated."""
+    from bucket_map_amd import verify
+    rng = np.random.default_rng(5000 + seed)
+    max_m = int(rng.choice([1, 40, 64, 65, 130, 200, 320, 450, 600, 900, 1500, 2500, 4100, 5000]))
+    err = (float(rng.choice([0.0, 0.01, 0.05, 0.2])), float(rng.choice([0.0, 0.005, 0.03])), float(rng.choice([0.0, 0.005, 0.03])))
+    genome = rng.choice(list(b"ACGT"), max(4 * max_m, 2000)).astype(np.uint8)
+    n = int(np.clip(60000 // max_m, 3, 150))
+    v = verify.Verifier()
+    v.load_genome(genome)
+    _compare(v, genome, _random_batch(rng, genome, n, max_m, err), f"seed={seed} max_m={max_m} err={err}")
+    v.close()
