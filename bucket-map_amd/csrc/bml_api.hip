@@ -291,7 +291,7 @@ int bml_locate(bml_ctx *c, const uint32_t *sample_hash, const uint16_t *sample_p
         HIP_TRY(c->occ_a.need((size_t)cap));
         HIP_TRY(hipMemsetAsync(c->occ_count.p, 0, sizeof(unsigned long long), c->stream));
         HIP_TRY(hipEventRecord(c->ev[0], c->stream));
-        hipLaunchKernelGGL(bml::bml_scan_kernel, dim3((unsigned)chunks.size()), dim3(bml::kThreads), c->scan_lds, c->stream,
+        hipLaunchKernelGGL(bml::bml_scan_kernel, dim3((unsigned)chunks.size()), dim3(bml::kScanThreads), c->scan_lds, c->stream,
                            c->lp, c->genome.p, c->bucket_start.p, c->bucket_len.p, c->lut.p, c->chunks.p, c->sample_hash.p,
                            c->pair_window.p, c->pair_rc.p, c->occ_a.p, c->occ_count.p, cap);
         HIP_TRY(hipGetLastError());
