@@ -15,7 +15,7 @@
 
 namespace bmi {
 
-constexpr int kThreads = 256;
+constexpr int kThreads = 1024;
 
 // LDS (dynamic): bitmap[4^q / 32] u32 | lut[256] u8
 __global__ __launch_bounds__(kThreads) void bmi_presence_kernel(const uint8_t *__restrict__ genome,
@@ -29,7 +29,7 @@ __global__ __launch_bounds__(kThreads) void bmi_presence_kernel(const uint8_t *_
     uint8_t *lut = smem + (size_t)n_words * 4;
     const uint32_t tid = threadIdx.x;
     const uint32_t b = blockIdx.x;
-    lut[tid] = dna4_lut[tid];
+    if (tid < 256) lut[tid] = dna4_lut[tid];
     for (uint32_t w = tid; w < n_words; w += kThreads) bitmap[w] = 0;
     __syncthreads();
     const uint32_t len = bucket_len[b];
