@@ -303,7 +303,7 @@ def main():
             pass
 
         # ---------------- CPU baseline (oracle = port of the reference algorithm, 1 thread) + parity sample
-        if args.cpu_sample > 0:
+        if args.cpu_sample > 0 and world == 1:               # the CPU baseline is an N=1 leg only
             from oracle import oracle_c
             n_cpu = min(args.cpu_sample, reads.n)
             rows_host = index.rows() if index is not None else flt.index_download()
