@@ -295,10 +295,11 @@ def main():
         try:
             with open(os.path.join(ROOT, "profiles", "pmc_latest.json")) as f:
                 pmc = json.load(f)
-            if (pmc.get("workload") == args.workload and pmc.get("params") == args.params
-                    and pmc.get("reads") == int(reads.n) and not args.early_exit):
-                result["roofline"]["traffic"] = pmc["vote_kernel_traffic_bytes"]
-                result["roofline"]["traffic_source"] = pmc["source"]
+            for e in pmc.get("entries", [pmc]):
+                if (e.get("workload") == args.workload and e.get("params") == args.params
+                        and e.get("reads") == int(reads.n) and not args.early_exit):
+                    result["roofline"]["traffic"] = e["vote_kernel_traffic_bytes"]
+                    result["roofline"]["traffic_source"] = e["source"]
         except (OSError, ValueError, KeyError):
             pass
 

@@ -48,5 +48,14 @@ latest = {
 for k in summary:
     if "FETCH_SIZE" in summary[k] and any(n in k for n in ("bmf_pass1_kernel", "bmf_recount_kernel", "bmf_vote2_slow_kernel")):
         latest.setdefault("pruning_kernels_traffic_bytes", {})[k] = int(summary[k]["FETCH_SIZE"]["mean"] * 1024 * 2)
-json.dump(latest, open(os.path.join(root, "profiles", "pmc_latest.json"), "w"), indent=1)
+# one entry per profiled (workload, params): bench.py picks the one that matches its run
+path = os.path.join(root, "profiles", "pmc_latest.json")
+try:
+    table = json.load(open(path))
+    if "entries" not in table:
+        table = {"entries": [table]}
+except (OSError, ValueError):
+    table = {"entries": []}
+table["entries"] = [e for e in table["entries"] if (e.get("workload"), e.get("params")) != (workload, params)] + [latest]
+json.dump(table, open(path, "w"), indent=1)
 print(json.dumps(latest, indent=1))
