@@ -290,3 +290,18 @@ def test_gpu_sampling_matches_golden():
         for a, b, what in zip(want, got, ("hash", "position", "has-samples")):
             assert np.array_equal(a, b), (g["k"], g["p"], what)
         scan.close()
+
+
+@pytest.mark.gpu
+def test_gpu_sampling_errors():
+    from bucket_map_amd import locate
+    scan = locate.LocatorScan(12, 10, 4, 6, 70000)
+    bases = np.frombuffer(b"ACGT" * 10, np.uint8)
+    quals = np.full(40, ord("I"), np.uint8)
+    with pytest.raises(locate.BmlError):                       # window past the end of the buffer
+        scan.sample_windows(bases, quals, [30], [20], 0)
+    h, pos, has = scan.sample_windows(bases, quals, np.zeros(0, np.uint64), np.zeros(0, np.uint32), 0)   # empty batch
+    assert h.shape == (0, 10) and len(has) == 0
+    h, pos, has = scan.sample_windows(bases, quals, [0, 5], [40, 0], 0)                                   # empty window
+    assert has.tolist() == [1, 0] and not h[1].any()
+    scan.close()

@@ -322,3 +322,30 @@ def test_determinism_and_batch_invariance(ecoli_like):
     cp, bp = flt.map_windows(rd.bases, rd.quals, ws[perm], wl[perm])
     assert_same_candidates(c1[perm], b1[perm], cp, bp, "permutation")
     flt.close()
+
+
+def test_pass2_counts_report_the_two_pass_kernels(ecoli_like):
+    """bmf_batch_pass2_counts: zero unless the two-pass pruning kernels served the run; with them forced on,
+    recounted + slow-path items never exceed the items, and the outputs equal the default kernel's."""
+    import bucket_map_amd as bma
+    case = ecoli_like
+    rd = case.reads
+    ws, wl, _ = _windows(case)
+    plain = case.gpu_filter()
+    b = plain.batch(rd.bases, rd.quals, ws, wl)
+    b.run()
+    assert b.pass2_counts() == (0, 0)
+    want = b.download()
+    b.close(); plain.close()
+    os.environ["BMF_PASS1_ROWS"] = "1"
+    try:
+        f2 = case.gpu_filter(flags=bma.BMF_FLAG_EARLY_EXIT)
+    finally:
+        del os.environ["BMF_PASS1_ROWS"]
+    b = f2.batch(rd.bases, rd.quals, ws, wl)
+    b.run()
+    recounted, slow = b.pass2_counts()
+    assert 0 < recounted + slow <= 2 * len(ws)
+    got = b.download()
+    assert_same_candidates(want[0], want[1], got[0], got[1], "two-pass")
+    b.close(); f2.close()
