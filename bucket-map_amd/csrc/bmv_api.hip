@@ -74,14 +74,15 @@ struct Shape {
 // kernel variant only fixes how many of the group's lanes hold the traceback's 16 pairs of trace words.
 Shape pick_shape(uint32_t words) {
     const int cw = words <= 64 ? 1 : (words <= 128 ? 2 : 4);
-    const uint32_t g = std::max(1u, (words + (uint32_t)cw - 1u) / (uint32_t)cw);
-    if (cw == 2) return {g, 2, bmv::bmv_align_kernel<1, 2>};
-    if (cw == 4) return {g, 4, bmv::bmv_align_kernel<1, 4>};
-    if (g >= 16) return {g, 1, bmv::bmv_align_kernel<1, 1>};
-    if (g >= 8) return {g, 1, bmv::bmv_align_kernel<2, 1>};
-    if (g >= 4) return {g, 1, bmv::bmv_align_kernel<4, 1>};
-    if (g >= 2) return {g, 1, bmv::bmv_align_kernel<8, 1>};
-    return {g, 1, bmv::bmv_align_kernel<16, 1>};
+    // beyond 256 words the whole wave carries strips of 256 words, one after the other
+    const uint32_t g = std::min(64u, std::max(1u, (words + (uint32_t)cw - 1u) / (uint32_t)cw));
+    if (cw == 2) return {g, 2, bmv::bmv_align_kernel<1, 2, false>};
+    if (cw == 4) return {g, 4, words <= 256 ? bmv::bmv_align_kernel<1, 4, false> : bmv::bmv_align_kernel<1, 4, true>};
+    if (g >= 16) return {g, 1, bmv::bmv_align_kernel<1, 1, false>};
+    if (g >= 8) return {g, 1, bmv::bmv_align_kernel<2, 1, false>};
+    if (g >= 4) return {g, 1, bmv::bmv_align_kernel<4, 1, false>};
+    if (g >= 2) return {g, 1, bmv::bmv_align_kernel<8, 1, false>};
+    return {g, 1, bmv::bmv_align_kernel<16, 1, false>};
 }
 
 }  // namespace
@@ -113,10 +114,10 @@ const char *bmv_last_error(void) { return g_err; }
 int bmv_create(const bmv_params *params, bmv_ctx **out) {
     if (!params || !out) return fail(BMV_ERR_ARG, "bmv_create: null argument");
     *out = nullptr;
-    if (params->max_query_len == 0 || params->max_query_len > 16384)
-        return fail(BMV_ERR_UNSUPPORTED, "max_query_len must be in 1..16384 (got %u)", params->max_query_len);
-    if (params->max_text_len == 0 || params->max_text_len > 24576)
-        return fail(BMV_ERR_UNSUPPORTED, "max_text_len must be in 1..24576 (got %u)", params->max_text_len);
+    if (params->max_query_len == 0 || params->max_query_len > 65536)
+        return fail(BMV_ERR_UNSUPPORTED, "max_query_len must be in 1..65536 (got %u)", params->max_query_len);
+    if (params->max_text_len == 0 || params->max_text_len > 81920)
+        return fail(BMV_ERR_UNSUPPORTED, "max_text_len must be in 1..81920 (got %u)", params->max_text_len);
     int n_dev = 0;
     HIP_TRY(hipGetDeviceCount(&n_dev));
     if (params->device < 0 || params->device >= n_dev)
@@ -222,16 +223,17 @@ int bmv_align(bmv_ctx *c, const uint8_t *reads, uint64_t n_read_bytes, const uin
     // kernel shape for the longest query; scratch per alignment slot
     const uint32_t words = (max_m + 63u) / 64u;
     const Shape sh = pick_shape(words ? words : 1u);
-    const uint32_t l_max = sh.group;
+    const uint32_t trace_words = std::max(words, 1u);           // >= sh.group * sh.cw only when strips are needed
     const uint32_t gpw = 64u / sh.group;
     // checkpoints every 16 columns: (Pv, Mv) per word, plus one 32-bit word of horizontal deltas per word and block
     const uint32_t n_blocks = (max_n + 15u) / 16u + 1u;
-    const uint64_t n_entries = (uint64_t)n_blocks * gpw * l_max * (uint32_t)sh.cw;
+    const uint64_t n_entries = (uint64_t)n_blocks * gpw * std::max(trace_words, sh.group * (uint32_t)sh.cw);
     const uint64_t trace_stride = n_entries * 2u + (n_entries + 1u) / 2u;   // 64-bit words per wave
     const uint32_t ops_stride = max_m + max_n + 1u;
-    const uint32_t lds_stride = (max_n + 15u) & ~15u, qry_stride = std::max(64u, (max_m + 63u) & ~63u);
+    const uint32_t lds_stride = (max_n + 15u) & ~15u;
+    const uint32_t qry_stride = std::max(64u, std::min((max_m + 63u) & ~63u, sh.group * (uint32_t)sh.cw * 64u));   // one strip
     const size_t lds = 256 + (size_t)gpw * (lds_stride + qry_stride);
-    if (lds > 64 * 1024) return fail(BMV_ERR_UNSUPPORTED, "text windows of %u bases need %zu B of LDS", max_n, lds);
+    if (lds > 160 * 1024) return fail(BMV_ERR_UNSUPPORTED, "text windows of %u bases need %zu B of LDS", max_n, lds);
     if (lds > 48 * 1024)
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(sh.fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const uint64_t per_slot = trace_stride / gpw * 8u + (uint64_t)ops_stride * 4u;
@@ -262,7 +264,7 @@ int bmv_align(bmv_ctx *c, const uint8_t *reads, uint64_t n_read_bytes, const uin
         j.count = count;
         j.trace = c->trace.p;
         j.trace_stride = trace_stride;
-        j.trace_lanes = l_max;
+        j.trace_words = std::max(trace_words, sh.group * (uint32_t)sh.cw);
         j.trace_blocks = n_blocks;
         j.group = sh.group;
         j.ops_rev = c->ops_rev.p;

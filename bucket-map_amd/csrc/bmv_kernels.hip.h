@@ -12,6 +12,9 @@
 // leaves lane l-1's last row (computed one step earlier) through a shuffle.  A group is exactly as many lanes
 // as the longest query of the batch has words (any size, not a power of two: lanes are addressed explicitly),
 // so a wave verifies 64/G candidates at once: 21 for 150-bp reads, 12 for 300-bp reads, 1 for 10-kbp reads.
+// A query of more than 64 * CW words (16 384 bases at CW = 4) is processed in STRIPS of that many words, one
+// after the other over the whole text: the horizontal deltas entering a strip's first word are the stored
+// ones that left the last word of the strip above.
 //
 // Traceback.  Per cell two bits decide the walk: "the diagonal predecessor is valid" (match with diagonal
 // delta 0, or mismatch with diagonal delta 1: ~(Eq ^ D0)) and "the upper predecessor is valid" (vertical delta
@@ -46,7 +49,7 @@ struct Job {
     uint32_t first, count;          // this launch handles alignments [first, first + count); slot = a - first
     uint64_t *trace;                // one region of trace_stride words per wave (64/GROUP alignments):
     uint64_t trace_stride;          //   checkpoints (Pv, Mv) [block][group][lane][c], then horizontal deltas
-    uint32_t trace_lanes;           // lanes per alignment that own words in this batch (>= every L)
+    uint32_t trace_words;           // words reserved per alignment and block in this batch (>= every W)
     uint32_t trace_blocks;          // column blocks reserved per alignment (>= every ceil(n / 16) + 1)
     uint32_t group;                 // lanes per alignment (1..64); 64 / group alignments per wave
     uint32_t *ops_rev;              // count x ops_stride reversed CIGAR entries
@@ -88,8 +91,9 @@ __device__ __forceinline__ int myers_step(uint64_t eq0, int hin, uint64_t &pv, u
 }
 
 // SLOTS: trace-word pairs a lane keeps during the traceback (16 / SLOTS lanes of a group hold a block's 16
-// columns; needs group >= 16 / SLOTS).  CW: 64-row words per lane.
-template <int SLOTS, int CW>
+// columns; needs group >= 16 / SLOTS).  CW: 64-row words per lane.  STRIPS: queries of more than 64 * CW
+// words are allowed (the group is then the whole wave).
+template <int SLOTS, int CW, bool STRIPS>
 __global__ __launch_bounds__(kWave) void bmv_align_kernel(Job J) {
     extern __shared__ uint8_t lds_text[];
     const uint32_t GROUP = J.group, GPW = kWave / GROUP;        // lanes per alignment, alignments per wave
@@ -99,8 +103,9 @@ __global__ __launch_bounds__(kWave) void bmv_align_kernel(Job J) {
     const uint32_t a = J.first + (have ? slot : 0u);
     const uint32_t n = have ? J.text_len[a] : 0u, m = have ? J.query_len[a] : 0u;
     const uint32_t W = (m + 63u) >> 6;                         // words of the query
-    const uint32_t L = (W + CW - 1u) / CW;                     // lanes of the group that hold query rows
-    // LDS: the dna4 folding table, then per group the text window and the query, both as ranks
+    const uint32_t strip_words = GROUP * CW;                    // words one pass over the text carries
+    const uint32_t n_strips = (STRIPS && W) ? (W + strip_words - 1u) / strip_words : 1u;
+    // LDS: the dna4 folding table, then per group the text window and (one strip of) the query, both as ranks
     uint8_t *lut = lds_text;
     uint8_t *text = lds_text + 256 + (size_t)grp * (J.text_lds_stride + J.query_lds_stride);
     uint8_t *qry = text + J.text_lds_stride;
@@ -115,104 +120,126 @@ __global__ __launch_bounds__(kWave) void bmv_align_kernel(Job J) {
             const uint8_t r = lut[rc ? src[n - 1u - j] : src[j]];
             text[j] = rc ? (uint8_t)(3u - r) : r;
         }
-        const uint8_t *q = J.reads + J.query_start[a];
-        const uint32_t padded = W * 64u;             // rows past the query match nothing
-#pragma unroll 4
-        for (uint32_t i = gl; i < padded; i += GROUP) qry[i] = i < m ? lut[q[i]] : (uint8_t)0xFF;
     }
-    __syncthreads();
-    // match masks of this lane's words, one per base
-    uint64_t peq[4][CW];
-#pragma unroll
-    for (int c = 0; c < CW; c++) {
-        peq[0][c] = peq[1][c] = peq[2][c] = peq[3][c] = 0;
-        const uint32_t w = gl * CW + c;
-        if (have && w < W) {
-            const uint64_t *q8 = reinterpret_cast<const uint64_t *>(qry + (size_t)w * 64u);
-#pragma unroll
-            for (int k = 0; k < 8; k++) {
-                const uint64_t v = q8[k];
-#pragma unroll
-                for (int t = 0; t < 8; t++) {
-                    const uint32_t r = (uint32_t)(v >> (8 * t)) & 0xFFu;
-                    const uint64_t bit = 1ull << (8 * k + t);
-                    peq[0][c] |= r == 0 ? bit : 0;
-                    peq[1][c] |= r == 1 ? bit : 0;
-                    peq[2][c] |= r == 2 ? bit : 0;
-                    peq[3][c] |= r == 3 ? bit : 0;
-                }
-            }
-        }
-    }
+    // checkpoint entry of (block b, this group, word w of the query): (b * GPW + grp) * TW + w
+    const uint32_t TW = J.trace_words;
+    uint64_t *ckpt = J.trace + (size_t)blockIdx.x * J.trace_stride;
+    uint32_t *hbuf = reinterpret_cast<uint32_t *>(ckpt + (size_t)J.trace_blocks * GPW * TW * 2u);
+    auto entry = [&](uint32_t b, uint32_t w) { return ((size_t)b * GPW + grp) * TW + w; };
 
-    uint64_t pv[CW], mv[CW];
-#pragma unroll
-    for (int c = 0; c < CW; c++) {
-        pv[c] = ~0ull;                                          // column 0: H[i][0] = i
-        mv[c] = 0;
-    }
+    uint64_t peq[4][CW];
     int32_t score = (int32_t)m, best = (int32_t)m;              // tracked by the lane that holds row m
     uint32_t best_j = 0;
-    const uint32_t last_lane = W ? (W - 1u) / CW : 0u, last_c = W ? (W - 1u) % CW : 0u, last_bit = (m - 1u) & 63u;
-    // checkpoint entry of (block b, this group, lane l, word c of the lane): ((b * GPW + grp) * TL + l) * CW + c
-    const uint32_t TL = J.trace_lanes;
-    uint64_t *ckpt = J.trace + (size_t)blockIdx.x * J.trace_stride;
-    uint32_t *hbuf = reinterpret_cast<uint32_t *>(ckpt + (size_t)J.trace_blocks * GPW * TL * CW * 2u);
-    auto entry = [&](uint32_t b, uint32_t l, uint32_t c) { return (((size_t)b * GPW + grp) * TL + l) * CW + c; };
-
-    // every group of the wave runs the same number of steps (shuffles need the whole wave)
-    uint32_t steps = (have && W) ? n + L - 1u : 0u;
+    const uint32_t last_word = W ? W - 1u : 0u, last_bit = (m - 1u) & 63u;
+    const uint32_t last_lane = (last_word % strip_words) / CW;
+    // the wave's groups run the same number of strips and steps (shuffles and barriers need the whole wave)
+    uint32_t wave_strips = n_strips;
+    if (STRIPS) {
 #pragma unroll
-    for (int o = 1; o < kWave; o <<= 1) {
-        const uint32_t other = (uint32_t)__shfl_xor((int)steps, o, kWave);
-        steps = other > steps ? other : steps;
+        for (int o = 1; o < kWave; o <<= 1) {
+            const uint32_t other = (uint32_t)__shfl_xor((int)wave_strips, o, kWave);
+            wave_strips = other > wave_strips ? other : wave_strips;
+        }
     }
-    int hout_prev = 0;
-    uint32_t hacc[CW];                                          // horizontal deltas of the current block, 2 bits each
+    for (uint32_t strip = 0; strip < wave_strips; strip++) {
+        const uint32_t w0 = strip * strip_words;                // first word of the strip
+        const bool live = have && strip < n_strips;
+        const uint32_t Ws = live ? (W - w0 < strip_words ? W - w0 : strip_words) : 0u;   // words in this strip
+        const uint32_t L = (Ws + CW - 1u) / CW;                 // lanes of the group that hold rows of it
+        __syncthreads();                                        // the previous strip's query rows are no longer read
+        if (live) {
+            const uint8_t *q = J.reads + J.query_start[a] + (size_t)w0 * 64u;
+            const uint32_t rows = m - w0 * 64u, padded = Ws * 64u;      // rows past the query match nothing
+#pragma unroll 4
+            for (uint32_t i = gl; i < padded; i += GROUP) qry[i] = i < rows ? lut[q[i]] : (uint8_t)0xFF;
+        }
+        __syncthreads();
+        // match masks of this lane's words, one per base
 #pragma unroll
-    for (int c = 0; c < CW; c++) hacc[c] = 0;
-    for (uint32_t t = 1; t <= steps; t++) {
-        int hin = __shfl_up(hout_prev, 1, kWave);
-        if (gl == 0) hin = 0;                                   // row 0 is all zeros: free leading text gaps
-        const uint32_t j = t - gl;                              // 1-based text column of this lane
-        if (gl < L && j >= 1u && j <= n && t >= gl + 1u) {
-            const uint8_t ch = text[j - 1u];
-            const uint32_t x = (j - 1u) % kBlock;
-            const bool block_end = x == kBlock - 1u || j == n;
+        for (int c = 0; c < CW; c++) {
+            peq[0][c] = peq[1][c] = peq[2][c] = peq[3][c] = 0;
+            const uint32_t w = gl * CW + c;
+            if (live && w < Ws) {
+                const uint64_t *q8 = reinterpret_cast<const uint64_t *>(qry + (size_t)w * 64u);
 #pragma unroll
-            for (int c = 0; c < CW; c++) {
-                const uint32_t w = gl * CW + c;
-                if (w < W) {
-                    const uint64_t eq0 = ch == 0 ? peq[0][c] : (ch == 1 ? peq[1][c] : (ch == 2 ? peq[2][c] : peq[3][c]));
-                    uint64_t ph, mh, d0;
-                    const int hout = myers_step(eq0, hin, pv[c], mv[c], ph, mh, d0);
-                    if (gl == last_lane && c == (int)last_c) {
-                        score += (int32_t)((ph >> last_bit) & 1ull) - (int32_t)((mh >> last_bit) & 1ull);
-                        if (score <= best) {                    // the LAST minimum of the bottom row
-                            best = score;
-                            best_j = j;
-                        }
-                    }
-                    hin = hout;
-                    hacc[c] |= (uint32_t)(hout + 1) << (2u * x);
-                    if (block_end) {
-                        hbuf[entry((j - 1u) / kBlock, gl, c)] = hacc[c];
-                        hacc[c] = 0;
-                        if (j < n) {                            // state the next block starts from
-                            uint64_t *ck = ckpt + entry(j / kBlock, gl, c) * 2u;
-                            ck[0] = pv[c];
-                            ck[1] = mv[c];
-                        }
+                for (int k = 0; k < 8; k++) {
+                    const uint64_t v = q8[k];
+#pragma unroll
+                    for (int t = 0; t < 8; t++) {
+                        const uint32_t r = (uint32_t)(v >> (8 * t)) & 0xFFu;
+                        const uint64_t bit = 1ull << (8 * k + t);
+                        peq[0][c] |= r == 0 ? bit : 0;
+                        peq[1][c] |= r == 1 ? bit : 0;
+                        peq[2][c] |= r == 2 ? bit : 0;
+                        peq[3][c] |= r == 3 ? bit : 0;
                     }
                 }
             }
-            hout_prev = hin;
         }
+        uint64_t pv[CW], mv[CW];
+        uint32_t hacc[CW];                                      // horizontal deltas of the current block, 2 bits each
+#pragma unroll
+        for (int c = 0; c < CW; c++) {
+            pv[c] = ~0ull;                                      // column 0: H[i][0] = i
+            mv[c] = 0;
+            hacc[c] = 0;
+        }
+        uint32_t steps = (live && Ws) ? n + L - 1u : 0u;
+#pragma unroll
+        for (int o = 1; o < kWave; o <<= 1) {
+            const uint32_t other = (uint32_t)__shfl_xor((int)steps, o, kWave);
+            steps = other > steps ? other : steps;
+        }
+        int hout_prev = 0;
+        uint32_t habove = 0x55555555u;                          // deltas leaving the strip above, 16 columns at a time
+        for (uint32_t t = 1; t <= steps; t++) {
+            int hin = __shfl_up(hout_prev, 1, kWave);
+            const uint32_t j = t - gl;                          // 1-based text column of this lane
+            if (gl < L && j >= 1u && j <= n && t >= gl + 1u) {
+                const uint8_t ch = text[j - 1u];
+                const uint32_t x = (j - 1u) % kBlock;
+                const bool block_end = x == kBlock - 1u || j == n;
+                if (gl == 0) {
+                    // row 0 is all zeros (free leading text gaps); below the first strip the deltas come from
+                    // the last word of the strip above
+                    if (STRIPS && strip && x == 0) habove = hbuf[entry((j - 1u) / kBlock, w0 - 1u)];
+                    hin = (STRIPS && strip) ? (int)((habove >> (2u * x)) & 3u) - 1 : 0;
+                }
+#pragma unroll
+                for (int c = 0; c < CW; c++) {
+                    const uint32_t w = gl * CW + c;
+                    if (w < Ws) {
+                        const uint64_t eq0 = ch == 0 ? peq[0][c] : (ch == 1 ? peq[1][c] : (ch == 2 ? peq[2][c] : peq[3][c]));
+                        uint64_t ph, mh, d0;
+                        const int hout = myers_step(eq0, hin, pv[c], mv[c], ph, mh, d0);
+                        if (w0 + w == last_word) {
+                            score += (int32_t)((ph >> last_bit) & 1ull) - (int32_t)((mh >> last_bit) & 1ull);
+                            if (score <= best) {                // the LAST minimum of the bottom row
+                                best = score;
+                                best_j = j;
+                            }
+                        }
+                        hin = hout;
+                        hacc[c] |= (uint32_t)(hout + 1) << (2u * x);
+                        if (block_end) {
+                            hbuf[entry((j - 1u) / kBlock, w0 + w)] = hacc[c];
+                            hacc[c] = 0;
+                            if (j < n) {                        // state the next block starts from
+                                uint64_t *ck = ckpt + entry(j / kBlock, w0 + w) * 2u;
+                                ck[0] = pv[c];
+                                ck[1] = mv[c];
+                            }
+                        }
+                    }
+                }
+                hout_prev = hin;
+            }
+        }
+        // the next strip (and the traceback) read what other lanes of this wave wrote: same wave, same L1,
+        // lines never read before, so completing the stores (workgroup scope) is all the ordering needed --
+        // a device-wide fence here cost 3.7 ms per million alignments
+        __threadfence_block();
     }
-    // the traceback reads checkpoints other lanes of this wave wrote: same wave, same L1, lines never read
-    // before, so completing the stores (workgroup scope) is all the ordering that is needed -- a device-wide
-    // fence here cost 3.7 ms per million alignments
-    __threadfence_block();
     __syncthreads();
     if (!have) return;
 
@@ -240,22 +267,30 @@ __global__ __launch_bounds__(kWave) void bmv_align_kernel(Job J) {
     auto load_checkpoint = [&](uint32_t w, uint32_t b) {
         Checkpoint k{~0ull, 0ull, 0x55555555u};                 // block 0 starts from column 0: H[i][0] = i
         if (b) {
-            const uint64_t *ck = ckpt + entry(b, w / CW, w % CW) * 2u;
+            const uint64_t *ck = ckpt + entry(b, w) * 2u;
             k.pv = ck[0];
             k.mv = ck[1];
         }
-        if (w) k.hw = hbuf[entry(b, (w - 1u) / CW, (w - 1u) % CW)];
+        if (w) k.hw = hbuf[entry(b, w - 1u)];
         return k;
     };
     auto refill = [&](uint32_t w, uint32_t b, Checkpoint k) {
-        const uint32_t owner = w / CW, c = w % CW;
-        uint64_t pm[4];                                         // the word's match masks, from the lane that owns it
+        uint64_t pm[4];                                         // the word's match masks
+        if (!STRIPS || n_strips == 1) {                         // ... from the lane that owns the word
+            const uint32_t owner = w / CW, c = w % CW;
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
-            uint64_t v = peq[r][0];
+            for (int r = 0; r < 4; r++) {
+                uint64_t v = peq[r][0];
 #pragma unroll
-            for (int cc = 1; cc < CW; cc++) v = c == (uint32_t)cc ? peq[r][cc] : v;
-            pm[r] = shfl64(v, (int)(lane0 + owner));
+                for (int cc = 1; cc < CW; cc++) v = c == (uint32_t)cc ? peq[r][cc] : v;
+                pm[r] = shfl64(v, (int)(lane0 + owner));
+            }
+        } else {                                                // ... rebuilt: the registers hold the last strip only.
+            // Several strips mean the group is the whole wave: lane l looks at query row 64 w + l
+            const uint32_t row = w * 64u + lane;
+            const uint32_t rk = row < m ? lut[J.reads[J.query_start[a] + row]] : 0xFFu;
+#pragma unroll
+            for (int r = 0; r < 4; r++) pm[r] = __ballot(rk == (uint32_t)r);
         }
 #pragma unroll
         for (int x = 0; x < (int)kBlock; x++) {

@@ -15,8 +15,8 @@ class gpu_alignment_verifier : public alignment_verifier {
 public:
     explicit gpu_alignment_verifier(int device = 0) {
         bmv_params p{};
-        p.max_query_len = 16384;   // the ABI's limits: reads are not known yet
-        p.max_text_len = 24576;
+        p.max_query_len = 65536;   // the ABI's limits: reads are not known yet
+        p.max_text_len = 81920;
         p.device = device;
         if (bmv_create(&p, &ctx_) != BMV_OK)
             throw std::runtime_error(std::string("cannot create the GPU alignment verifier: ") + bmv_last_error());

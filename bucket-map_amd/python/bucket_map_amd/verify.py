@@ -61,7 +61,7 @@ def cigar_string(packed) -> str:
 class Verifier:
     """align_pairwise of the BM_ALIGN branch (bucket_locator.h:520-528,569-576) for batches, on one GPU."""
 
-    def __init__(self, max_query_len: int = 16384, max_text_len: int = 24576, device: int = 0):
+    def __init__(self, max_query_len: int = 65536, max_text_len: int = 81920, device: int = 0):
         h = C.c_void_p()
         prm = _Params(max_query_len, max_text_len, device)
         _check(lib().bmv_create(C.byref(prm), C.byref(h)))

@@ -18,8 +18,8 @@
  * MAPQ = 60 + score rule and its threshold (:570-573), SAM output.
  *
  * Semi-global edit distance (the whole query against the best substring of the text, unit costs) by
- * Myers' bit-vector recurrence, 64 query rows per lane, lanes skewed along the text; the traceback runs
- * on the device too.  The score is unique; between equally good alignments SeqAn3's own choice is not
+ * Myers' bit-vector recurrence, 64 query rows per lane, lanes skewed along the text (queries beyond 16 384
+ * bases in strips of that many rows); the traceback runs on the device too.  The score is unique; between equally good alignments SeqAn3's own choice is not
  * pinned by anything in the reference (no test, no fixture, SeqAn3 itself absent), so the rules are stated
  * here and a maintainer with SeqAn3 at hand can correct them in one place:
  *   (1) the alignment ends at the LAST text column whose bottom-row score is the minimum;
@@ -44,8 +44,8 @@ enum { BMV_OK = 0, BMV_ERR_ARG = 1, BMV_ERR_HIP = 2, BMV_ERR_STATE = 3, BMV_ERR_
 enum { BMV_OP_M = 0, BMV_OP_I = 1, BMV_OP_D = 2 };
 
 typedef struct bmv_params {
-    uint32_t max_query_len;   /* longest read handed to bmv_align (<= 16384)                        */
-    uint32_t max_text_len;    /* longest text window: max_query_len + 1 + indel allowance (<= 24576) */
+    uint32_t max_query_len;   /* longest read handed to bmv_align (<= 65536)                        */
+    uint32_t max_text_len;    /* longest text window: max_query_len + 1 + indel allowance (<= 81920) */
     int32_t  device;
 } bmv_params;
 

@@ -186,7 +186,8 @@ def test_gpu_verifier_matches_oracle(max_m, n, err):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("m,n_align", [(6000, 3), (10000, 2), (16384, 1)])     # 2 and 4 words per lane
+@pytest.mark.parametrize("m,n_align", [(6000, 3), (10000, 2), (16384, 1), (16385, 1), (20000, 2), (33000, 1)])
+# 2 and 4 words per lane; beyond 16 384 bases the query is processed in strips (2, 2 and 3 of them)
 def test_gpu_verifier_long_reads(m, n_align):
     from bucket_map_amd import verify
     rng = np.random.default_rng(m)
@@ -248,7 +249,7 @@ def test_gpu_verifier_errors():
     assert len(s) == 0 and o.tolist() == [0]
     v.close()
     with pytest.raises(verify.BmvError):
-        verify.Verifier(max_query_len=20000)
+        verify.Verifier(max_query_len=70000)
 
 
 def _run(exe, args, cwd, env=None):
