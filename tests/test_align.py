@@ -260,7 +260,7 @@ def _run(exe, args, cwd, env=None):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("profile", ["short", "long"])
+@pytest.mark.parametrize("profile", ["short", "long", "ultralong"])
 def test_bucketmap_align_sam_identical_to_oracle_backed_run(tmp_path, profile):
     """`bucketmap_align` end to end: GPU filter + GPU locator scan + GPU verifier against the same tool with the
     three CPU oracles behind the same interfaces.  Also: CIGARs consume the reads, MAPQ = 60 - edits."""
@@ -271,9 +271,10 @@ def test_bucketmap_align_sam_identical_to_oracle_backed_run(tmp_path, profile):
         g = host.Genome.synth(31, [300_000, 120_000])
         rd = host.Reads(g, 8192, 150, 150, 2000, sub=0.01, ins=0.002, dele=0.002, seed=9)
         flags = ["-i", "idx", "--genome", "g.fa", "--bucket-len", "8192", "-r", "150", "-f", "1", "-q", "reads.fastq"]
-    else:   # benchmark/long_read/benchmark_map.sh:25
+    else:   # benchmark/long_read/benchmark_map.sh:25 ("ultralong": reads beyond 16 384 bases, verified in strips)
         g = host.Genome.synth(32, [1_500_000])
-        rd = host.Reads(g, 262144, 300, 4000, 60, sub=0.03, ins=0.025, dele=0.025, seed=10)
+        rd = (host.Reads(g, 262144, 300, 4000, 60, sub=0.03, ins=0.025, dele=0.025, seed=10) if profile == "long" else
+              host.Reads(g, 262144, 300, 18000, 4, sub=0.03, ins=0.025, dele=0.025, seed=12))
         flags = ["-i", "idx", "--genome", "g.fa", "--bucket-len", "262144", "-f", "1", "-s", "30", "-e", "0.9", "-n", "0.1",
                  "-l", "12", "-p", "20", "-u", "5", "-q", "reads.fastq"]
     g.write_fasta(str(tmp_path / "g.fa"))
@@ -286,12 +287,14 @@ def test_bucketmap_align_sam_identical_to_oracle_backed_run(tmp_path, profile):
     import re
     records = [l.split(b"\t") for l in gpu_sam.split(b"\n") if l and not l.startswith(b"@")]
     assert len({r[0] for r in records}) > (0.9 if profile == "short" else 0.5) * rd.n
+    if profile == "ultralong":
+        assert max(len(r[9]) for r in records) > 16384
     for r in records[:500]:
         ops = re.findall(rb"(\d+)([MID])", r[5])
         assert sum(int(n) for n, o in ops if o in b"MI") == len(r[9])
         # 60u + score wraps for more than 60 edits and is written through an 8-bit field (bucket_locator.h:570):
         # a 4-kbp read at 8 % errors has ~300 edits, so only the short profile stays within 0..60
-        assert profile == "long" or int(r[4]) <= 60
+        assert profile != "short" or int(r[4]) <= 60
 
 
 # ------------------------------------------------------------------------------------------------ golden
