@@ -240,8 +240,11 @@ int bmv_align(bmv_ctx *c, const uint8_t *reads, uint64_t n_read_bytes, const uin
     uint64_t chunk = std::max<uint64_t>(gpw, c->scratch_bytes / per_slot);
     chunk = std::min<uint64_t>(chunk / gpw * gpw, (uint64_t)n);
     if (chunk == 0) chunk = n;
-    HIP_TRY(c->trace.need((size_t)((chunk + gpw - 1u) / gpw * trace_stride)));
-    HIP_TRY(c->ops_rev.need((size_t)(chunk * ops_stride)));
+    // Grow these with headroom: the longest read differs a little from call to call, and reallocating tens of
+    // gigabytes every time it grows costs seconds.
+    auto with_headroom = [](size_t need, size_t have) { return need <= have ? have : need + need / 4; };
+    HIP_TRY(c->trace.need(with_headroom((size_t)((chunk + gpw - 1u) / gpw * trace_stride), c->trace.cap)));
+    HIP_TRY(c->ops_rev.need(with_headroom((size_t)(chunk * ops_stride), c->ops_rev.cap)));
     HIP_TRY(c->nops.need((size_t)chunk));
     HIP_TRY(c->offsets.need((size_t)chunk));
     size_t tmp_bytes = 0;
@@ -285,7 +288,7 @@ int bmv_align(bmv_ctx *c, const uint8_t *reads, uint64_t n_read_bytes, const uin
         HIP_TRY(hipMemcpyAsync(&last_n, c->nops.p + (count - 1u), 4, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
         const uint32_t total = last_off + last_n;
-        HIP_TRY(c->packed.need(total));
+        HIP_TRY(c->packed.need(with_headroom(total, c->packed.cap)));
         hipLaunchKernelGGL(bmv::bmv_gather_kernel, dim3((count + 31u) / 32u), dim3(256), 0, c->stream, c->ops_rev.p, ops_stride,
                            c->nops.p, c->offsets.p, count, c->packed.p);
         HIP_TRY(hipGetLastError());
