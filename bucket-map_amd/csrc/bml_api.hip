@@ -51,8 +51,9 @@ struct DevBuf {
         if (p) (void)hipFree(p);
         p = nullptr;
         cap = 0;
-        hipError_t e = hipMalloc(reinterpret_cast<void **>(&p), (n ? n : 1) * sizeof(T));
-        if (e == hipSuccess) cap = n;
+        const size_t want = (n ? n : 1) + n / 8;   // headroom: batches of a file differ a little in size
+        hipError_t e = hipMalloc(reinterpret_cast<void **>(&p), want * sizeof(T));
+        if (e == hipSuccess) cap = want;
         return e;
     }
     void release() {
