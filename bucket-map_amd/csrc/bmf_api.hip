@@ -378,9 +378,9 @@ static void free_index(bmf_ctx *c) {
 
 // BMF_FLAG_EARLY_EXIT: which exact-pruning kernel serves this index.  The two-pass kernel streams r rows
 // per sample at full width, then recounts the chunks that survive; a bucket unrelated to the read survives
-// a sample with probability about d^r (d = density of the rows a read meets, weighted by density because a
-// q-gram is met in proportion to how often it occurs), so the expected number of survivors is
-// NB * P[Bin(S, d^r) >= S-F+1].  Costs are in row bytes; the single-pass PRUNE kernel reads F*G whole rows
+// a sample with probability about h^r, h = 1 - f + f*d (d = density of the rows a read meets, weighted by density
+// because a q-gram is met in proportion to how often it occurs; f = fraction of q-grams FracMinHash kept -- the
+// others AND as the identity), so the expected number of survivors is NB * P[Bin(S, h^r) >= S-F+1].  Costs are in row bytes; the single-pass PRUNE kernel reads F*G whole rows
 // before it can narrow.  BMF_PASS1_ROWS=r forces r (0: never two-pass) for experiments.
 static int select_pruned_variant(bmf_ctx *c) {
     const bmf::DevParams &d = c->dp;
@@ -397,12 +397,23 @@ static int select_pruned_variant(bmf_ctx *c) {
         s2 += di * di;
     }
     const double dens = s1 > 0.0 ? s2 / s1 : 0.0;
+    // a q-gram FracMinHash did not keep ANDs as the identity: a row of a sample tells nothing with probability 1 - f
+    const double kept = d.n_kmers ? (double)c->n_rows / (double)d.n_kmers : 1.0;
+    const double hit1 = 1.0 - kept + kept * dens;   // P[one row of a sample leaves an unrelated bucket's bit set]
+    // With most q-grams not indexed (the reference's default -f 0.25) three rows in four are the cache-resident
+    // all-ones row: the plain kernel then runs at 50+ M reads/s and the pruning kernels' bookkeeping costs more
+    // than the few real rows they skip (measured: 53.6 M plain, 32.0 M single-pass pruning on the Egu -f 0.25
+    // index).  The flag promises identical outputs from no more work, so the plain kernel serves such an index.
+    if (kept < 0.6 && !getenv("BMF_PASS1_ROWS")) {
+        c->vote = pick_vote(c->cpl, c->planes, false);
+        return BMF_OK;
+    }
     const double row_bytes = (double)d.n_chunks * 16.0, sector = 64.0;
     const double prune_cost = (double)d.F * d.G * row_bytes;
     uint32_t best_r = 0;
     double best = 0.95 * prune_cost;
     for (uint32_t r = 1; r < d.G; r++) {
-        const double live = (double)d.nb * binom_tail(d.S, pow(dens, (double)r), d.S - d.F + 1u);
+        const double live = (double)d.nb * binom_tail(d.S, pow(hit1, (double)r), d.S - d.F + 1u);
         if (live > 20.0) continue;   // more than kMaxLive live chunks send an item down the slow path
         const double cost = (double)d.S * r * row_bytes + live * d.S * sector + 1.3 * d.S * d.G * sector;
         if (cost < best) {
