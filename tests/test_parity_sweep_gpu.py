@@ -40,6 +40,16 @@ def random_case(rng, *, nb, q, k, S, F, max_cand, kmer_frac, density, read_len, 
     c_e, b_e = fe.map_windows(bases, quals, ws, wl)
     flt.close(); fe.close()
     out = [c_ref, b_ref, c_got, b_got, c_e, b_e]
+    # the single-pass pruning kernel, forced (the library keeps the plain kernel for short rows and sparse indexes)
+    os.environ["BMF_PASS1_ROWS"] = "0"
+    try:
+        f1 = bma.Filter(bma.Params(num_buckets=nb, flags=bma.BMF_FLAG_EARLY_EXIT, **kw))
+        f1.load_index(rows, k2i)
+    finally:
+        del os.environ["BMF_PASS1_ROWS"]
+    c_1, b_1 = f1.map_windows(bases, quals, ws, wl)
+    f1.close()
+    assert_same_candidates(c_ref, b_ref, c_1, b_1, "single-pass pruning forced")
     if k > q:
         # the two-pass pruning kernel, forced (the library only picks it for sparse indexes), r rows in pass 1
         os.environ["BMF_PASS1_ROWS"] = str(int(rng.integers(1, k - q + 1)))
