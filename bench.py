@@ -76,6 +76,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="egu", choices=sorted(WORKLOADS))
     ap.add_argument("--reads", type=int, default=0, help="reads per GPU (default: the workload's)")
+    ap.add_argument("--total-bp", type=int, default=0, help="override the workload's genome size (other NB geometries)")
     ap.add_argument("--params", default="default", choices=["default", "bench"],
                     help="default = CLI defaults (k12 q9 S15 F6); bench = benchmark_map.sh (-s 20 -e 0.6 -l 14 -b 10)")
     ap.add_argument("--cpu-sample", type=int, default=200000, help="reads timed on the CPU oracle (0 = skip)")
@@ -124,6 +125,8 @@ def main():
     total_bp, bucket_len, read_len, n_reads = WORKLOADS[args.workload]
     if args.reads:
         n_reads = args.reads
+    if args.total_bp:
+        total_bp = args.total_bp
     threads = args.host_threads or max(1, usable_cores() // world)
     if args.params == "bench":
         cli = dict(index_seed=9, query_seed=14, read_len=read_len, mapper_samples=20, max_error_rate=0.6,

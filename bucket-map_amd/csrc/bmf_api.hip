@@ -404,9 +404,10 @@ static int select_pruned_variant(bmf_ctx *c) {
     // all-ones row: the plain kernel then runs at 50+ M reads/s and the pruning kernels' bookkeeping costs more
     // than the few real rows they skip (measured: 53.6 M plain, 32.0 M single-pass pruning on the Egu -f 0.25
     // index).  The flag promises identical outputs from no more work, so the plain kernel serves such an index.
-    // The same holds for rows of at most 1 KiB (NB <= 8 192): the step is latency-bound and the plain kernel is the
-    // fastest (E. coli-sized index: 177 M reads/s plain, 160 M with single-pass pruning).
-    if ((kept < 0.6 || d.n_chunks <= 64u) && !getenv("BMF_PASS1_ROWS")) {
+    // The same holds for very short rows (NB <= 2 048): the step is latency-bound and the plain kernel is the
+    // fastest (E. coli-sized index: 177 M reads/s plain, 160 M with single-pass pruning; from NB ~ 3 800 on,
+    // pruning wins again: 102 M plain, 129 M single-pass).
+    if ((kept < 0.6 || d.n_chunks <= 16u) && !getenv("BMF_PASS1_ROWS")) {
         c->vote = pick_vote(c->cpl, c->planes, false);
         return BMF_OK;
     }
