@@ -24,6 +24,7 @@ ap.add_argument("--dir", default="/tmp/bm_e2e")
 ap.add_argument("--out", default="")
 ap.add_argument("--extra", default="", help="extra CLI flags, e.g. '--early-exit'")
 ap.add_argument("--align", action="store_true", help="run bucketmap_align (alignment verification + CIGAR)")
+ap.add_argument("--kmer-frac", default="1", help="-f of the index (the reference's default is 0.25)")
 ap.add_argument("--long", action="store_true",
                 help="the reference's long-read profile (benchmark/long_read/benchmark_map.sh:25): 10-kbp ONT-like reads "
                      "(sub 0.03, ins = del 0.025), -s 30 -e 0.9 -n 0.1 -l 12 -p 20 -u 5; the workload's 65536-bp buckets "
@@ -54,7 +55,7 @@ rd = host.Reads(g, bucket_len, read_len, sim_len, args.reads, seed=20240003, **e
 rd.write_fastq(os.path.join(args.dir, "reads"))
 say(f"[e2e] inputs written in {time.perf_counter() - t:.1f} s ({g.total_length()} bp, {rd.n} reads)")
 exe = os.path.join(ROOT, "bucket-map_amd", "bucketmap")
-common = ["-i", "idx", "--genome", "g.fa", "--bucket-len", str(bucket_len), "-r", str(read_len), "-f", "1", *profile]
+common = ["-i", "idx", "--genome", "g.fa", "--bucket-len", str(bucket_len), "-r", str(read_len), "-f", args.kmer_frac, *profile]
 for f in ("idx.qgram", "idx.kmers_index", "idx.bucket_id", "out.sam"):
     p = os.path.join(args.dir, f)
     if os.path.exists(p):
