@@ -159,3 +159,18 @@ def test_full_size_properties():
     ca, ba = flt.map_windows(reads.bases, reads.quals, ws[:h], wl[:h])
     assert_same_candidates(c[:h], b[:h], ca, ba, "batch split")
     flt.close()
+
+
+def test_sam_identical_with_fracminhash_index(tmp_path):
+    # the reference's default -f 0.25: three q-grams in four are not indexed (seeded selection: both tools keep the same rows)
+    from bucket_map_amd import host
+    g = host.Genome.synth(26, [500_000, 60_000])
+    g.write_fasta(str(tmp_path / "g.fa"))
+    rd = host.Reads(g, 8192, 150, 150, 2500, sub=0.005, seed=12)
+    rd.write_fastq(str(tmp_path / "reads"))
+    common = ["-i", "idx", "--genome", "g.fa", "--bucket-len", "8192", "-r", "150", "-f", "0.25", "--hash-seed", "7", "-q", "reads.fastq"]
+    _run(GPU_CLI, [*common, "-o", "gpu.sam"], tmp_path)
+    _run(ORACLE_CLI, [*common, "-o", "cpu.sam"], tmp_path)
+    gpu_sam = (tmp_path / "gpu.sam").read_bytes()
+    assert gpu_sam == (tmp_path / "cpu.sam").read_bytes()
+    assert gpu_sam.count(b"\n") > 0.8 * rd.n
