@@ -418,7 +418,7 @@ static int select_pruned_variant(bmf_ctx *c) {
     for (uint32_t r = 1; r < d.G; r++) {
         const double live = (double)d.nb * binom_tail(d.S, pow(hit1, (double)r), d.S - d.F + 1u);
         if (live > 20.0) continue;   // more than kMaxLive live chunks send an item down the slow path
-        const double cost = (double)d.S * r * row_bytes + live * d.S * sector + 1.3 * d.S * d.G * sector;
+        const double cost = (double)d.S * r * row_bytes + live * d.S * sector + 1.0 * d.S * d.G * sector;
         if (cost < best) {
             best = cost;
             best_r = r;
