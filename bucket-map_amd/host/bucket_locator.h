@@ -20,8 +20,8 @@
 #include <atomic>
 #include <chrono>
 #include <iostream>
-#include <map>
 #include <memory>
+#include <string_view>
 #include <thread>
 #include <tuple>
 
@@ -148,40 +148,54 @@ private:
         first_window.push_back(static_cast<uint32_t>(window_start.size()));
     }
 
-    // _filter_best_locations (:350-405)
+    // _filter_best_locations (:350-405).  The reference keeps a std::map keyed (bucket, offset, strand); here the
+    // proposals of a read live in one flat vector kept in that key order (a read has a handful of them):
+    //   * an incoming location adds its votes to EVERY proposal of its bucket and strand whose offset lies in
+    //     [offset - len * n, offset + len * n] -- float32 arithmetic, truncated towards zero (:365-366);
+    //   * only when none took the votes does it become a proposal itself, with its own votes (:380);
+    //   * all proposals holding the maximum come out, in key order (:390-402).
+    // Pinned by tests/golden/sam_small.json (an independent plain-Python statement of the whole tool).
+    struct proposal {
+        unsigned int bucket;
+        int offset;
+        bool as_is;
+        unsigned int votes;
+        bool before(unsigned int b, int o, bool s) const {
+            return std::tie(bucket, offset, as_is) < std::tie(b, o, s);
+        }
+    };
     std::vector<locate_t> filter_best_locations(const std::vector<locate_t> &mapped_locations, unsigned int read_len) const {
-        std::map<std::tuple<unsigned int, int, bool>, unsigned int> loc_votes;
-        for (auto &[bucket_id, bucket_offset, segment_offset, votes, is_orig] : mapped_locations) {
-            (void)segment_offset;
-            if (loc_votes.empty()) {
-                loc_votes[{bucket_id, bucket_offset, is_orig}] = votes;
-            } else {
-                bool found_close_loc = false;
-                // int = int -/+ float product, truncated (:365-366)
-                const int lower_bound = static_cast<int>(bucket_offset - read_len * allowed_indel_rate);
-                const int upper_bound = static_cast<int>(bucket_offset + read_len * allowed_indel_rate);
-                for (auto it = loc_votes.begin(); it != loc_votes.end(); ++it) {
-                    const int proposed = std::get<1>(it->first);
-                    if (bucket_id == std::get<0>(it->first) && proposed <= upper_bound && proposed >= lower_bound &&
-                        std::get<2>(it->first) == is_orig) {
-                        it->second += votes;
-                        found_close_loc = true;
-                    }
+        std::vector<proposal> props;
+        const float reach = read_len * allowed_indel_rate;
+        for (const locate_t &loc : mapped_locations) {
+            const unsigned int bucket = std::get<0>(loc), votes = std::get<3>(loc);
+            const int offset = std::get<1>(loc);
+            const bool as_is = std::get<4>(loc);
+            const int lo = static_cast<int>(offset - reach), hi = static_cast<int>(offset + reach);
+            bool taken = false;
+            for (proposal &p : props)
+                if (p.bucket == bucket && p.as_is == as_is && p.offset >= lo && p.offset <= hi) {
+                    p.votes += votes;
+                    taken = true;
                 }
-                if (!found_close_loc) loc_votes[{bucket_id, bucket_offset, is_orig}] = votes;
-            }
+            if (taken) continue;
+            auto at = std::find_if(props.begin(), props.end(), [&](const proposal &p) { return !p.before(bucket, offset, as_is); });
+            props.insert(at, proposal{bucket, offset, as_is, votes});
         }
-        std::vector<locate_t> res;
-        unsigned int max_votes = 0;
-        for (auto &kv : loc_votes) {
-            if (kv.second > max_votes) {
-                res.clear();
-                max_votes = kv.second;
-            }
-            if (kv.second == max_votes)
-                res.push_back(std::make_tuple(std::get<0>(kv.first), std::get<1>(kv.first), 0u, kv.second, std::get<2>(kv.first)));
-        }
-        return res;
+        unsigned int top = 0;
+        for (const proposal &p : props) top = std::max(top, p.votes);
+        std::vector<locate_t> best;
+        for (const proposal &p : props)
+            if (p.votes == top) best.emplace_back(p.bucket, p.offset, 0u, p.votes, p.as_is);
+        return best;
+    }
+
+    // SEQ as seqan3 writes a dna4 vector: the reads were folded to A/C/G/T when they were parsed
+    // (_phred94_traits, utils.h:192-204), so N / IUPAC / lower case never reach the SAM file.
+    static void append_dna4(std::string &out, std::string_view seq) {
+        const size_t at = out.size();
+        out.resize(at + seq.size());
+        for (size_t i = 0; i < seq.size(); i++) out[at + i] = dna4_char(dna4_rank(static_cast<uint8_t>(seq[i])));
     }
 
 public:
@@ -302,7 +316,10 @@ public:
         return res;
     }
 
-    // .bucket_id -> @SQ lines and per-bucket offsets (:473-503)
+    // .bucket_id -> @SQ lines and per-bucket offsets (:473-503).  One line per kept bucket; the reference name of
+    // a bucket is its line up to the first blank, consecutive buckets of one name form one @SQ entry whose
+    // length is the upper bound #buckets * bucket_len (:491,502) -- two FASTA records whose headers agree up to
+    // the first blank therefore share an entry and the second one's offsets carry on from the first's.
     struct sam_header {
         std::vector<std::string> bucket_name, ref_ids;
         std::vector<unsigned int> bucket_offsets;
@@ -310,27 +327,20 @@ public:
     };
     sam_header read_bucket_ids(std::filesystem::path const &index_file) const {
         sam_header h;
-        std::ifstream bucket_info(index_file);
-        std::string name, last_bucket_name;
-        unsigned int bucket_index = 0;
-        for (size_t i = 0; i < buckets_.size(); i++) {
-            std::getline(bucket_info, name);
-            name = name.substr(0, name.find(' '));
-            if (name != last_bucket_name) {
-                if (bucket_index != 0) {
-                    h.ref_ids.push_back(last_bucket_name);
-                    h.ref_lengths.push_back(static_cast<size_t>(bucket_index) * bucket_length);
-                }
-                last_bucket_name = name;
-                bucket_index = 0;
-            }
-            h.bucket_name.push_back(name);
-            h.bucket_offsets.push_back(bucket_index * bucket_length);
-            bucket_index++;
+        std::ifstream in(index_file);
+        std::string line;
+        for (size_t b = 0; b < buckets_.size(); b++) {
+            line.clear();
+            std::getline(in, line);
+            line.resize(std::min(line.size(), line.find(' ')));
+            h.bucket_name.push_back(line);
         }
-        if (bucket_index != 0) {
-            h.ref_ids.push_back(last_bucket_name);
-            h.ref_lengths.push_back(static_cast<size_t>(bucket_index) * bucket_length);
+        // runs of equal consecutive names: one entry per run, offsets counted from the run's first bucket
+        for (size_t b = 0, e = 0; b < h.bucket_name.size(); b = e) {
+            for (e = b; e < h.bucket_name.size() && h.bucket_name[e] == h.bucket_name[b]; e++)
+                h.bucket_offsets.push_back(static_cast<unsigned int>(e - b) * bucket_length);
+            h.ref_ids.push_back(h.bucket_name[b]);
+            h.ref_lengths.push_back((e - b) * static_cast<size_t>(bucket_length));
         }
         return h;
     }
@@ -353,14 +363,19 @@ public:
         if (_v) {
             mapped_locations = write_verified(sequence_file, locate_res, h, sam, quality_threshold, read_id);
         } else {
+            std::string seq;
             for_each_fastq(sequence_file, [&](const FastqRecord &rec) {
                 auto best = filter_best_locations(locate_res[read_id], static_cast<unsigned int>(rec.seq.size()));   // :540
+                if (!best.empty()) {
+                    seq.clear();
+                    append_dna4(seq, rec.seq);
+                }
                 for (auto &[bucket_id, offset, segment_offset, votes, is_original] : best) {
                     (void)segment_offset;
                     const unsigned int map_qual = std::min(60u, 6 * votes);                      // :591
                     const size_t ref_offset = static_cast<size_t>(h.bucket_offsets[bucket_id]) + offset;  // :592, 0-based
                     sam << rec.id << '\t' << (is_original ? 0 : 16) << '\t' << h.bucket_name[bucket_id] << '\t'
-                        << ref_offset + 1 << '\t' << map_qual << "\t*\t*\t0\t0\t" << rec.seq << '\t' << rec.qual << '\n';
+                        << ref_offset + 1 << '\t' << map_qual << "\t*\t*\t0\t0\t" << seq << '\t' << rec.qual << '\n';
                     mapped_locations++;
                 }
                 read_id++;
@@ -429,7 +444,8 @@ private:
         };
         for_each_fastq(sequence_file, [&](const FastqRecord &rec) {
             const size_t len = rec.seq.size();
-            block.push_back({std::string(rec.id), std::string(rec.seq), std::string(rec.qual), bases.size()});
+            block.push_back({std::string(rec.id), std::string(), std::string(rec.qual), bases.size()});
+            append_dna4(block.back().seq, rec.seq);
             bases.insert(bases.end(), rec.seq.begin(), rec.seq.end());
             for (auto &[bucket_id, offset, segment_offset, votes, is_original] : locate_res[read_id]) {
                 (void)segment_offset; (void)votes;

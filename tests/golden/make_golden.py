@@ -9,7 +9,7 @@ align_small.json and sampling_small.json pin the two "next" paths (alignment ver
 k-mer sampling) the same way: expected values from plain-Python restatements written here -- lists and
 loops, sharing nothing with oracle/*.c or the kernels.
 
-    python tests/golden/make_golden.py        # rewrites the four fixtures
+    python tests/golden/make_golden.py        # rewrites the five fixtures (or only those named)
 """
 import json
 import os
@@ -199,9 +199,105 @@ def sampling_small():
     return {"groups": groups}
 
 
+SAM_SMALL_FLAGS = dict(bucket_len=256, read_len=60, q=5, k=7, S=8, e=0.5, d=0.5, b=20, n=0.05, p=8, u=40)
+
+
+def sam_small():
+    """A tiny genome and 60-odd reads pushed through tests/golden/py_bucketmap.py (the whole tool in plain
+    Python): expected @SQ lines and SAM records of `bucketmap` and of `bucketmap_align`.  Built to hit the
+    order-sensitive host code: records whose names share the text before the first blank (one @SQ, offsets
+    carried across), a record whose tail bucket is dropped (NB > kept buckets), a duplicated stretch (vote ties:
+    two records for one read), hits on both strands, hits at bucket offset 0 (dropped, :674/:686) and at the
+    overlap of two buckets, 5-window long reads whose proposals merge, N / lower-case bases (SEQ is written
+    folded to ACGT), low and noisy qualities, reads shorter than k and reads from nowhere."""
+    import py_bucketmap as pb
+    rng = np.random.default_rng(20240014)
+    alpha = "ACGT"
+
+    def rnd(n):
+        return "".join(alpha[i] for i in rng.integers(0, 4, n))
+
+    def rc(s):
+        return "".join("TGCA"["ACGT".index(c)] for c in reversed(s))
+
+    chr_b = rnd(1000)
+    chr_c = rnd(552)
+    chr_c = chr_c[:150] + chr_b[400:530] + chr_c[280:]          # 130 bases of chrB again inside chrC
+    records = [("chrA part1 of two", rnd(1500)), ("chrA part2", rnd(700)), ("chrB", chr_b), ("chrC tail dropped", chr_c)]
+    reads = []
+
+    def add(name, seq, qual=None, flip=False):
+        seq = rc(seq) if flip else seq
+        reads.append((name, seq, qual if qual is not None else "E" * len(seq)))
+
+    def damaged(s, subs=0, dele=None, ins=None):
+        s = list(s)
+        for _ in range(subs):
+            at = int(rng.integers(0, len(s)))
+            s[at] = alpha[(alpha.index(s[at]) + int(rng.integers(1, 4))) % 4]
+        if dele is not None:
+            del s[dele]
+        if ins is not None:
+            s.insert(ins, "G")
+        return "".join(s)
+
+    for i in range(14):                                         # plain short reads, both strands, 0-3 substitutions
+        r = int(rng.integers(0, 4))
+        at = int(rng.integers(1, len(records[r][1]) - 61))
+        add(f"plain{i}", damaged(records[r][1][at:at + 60], subs=i % 4), flip=bool(i % 2))
+    add("record_start", records[0][1][0:60])                    # offset 0 of bucket 0: never reported
+    add("record_start_rc", records[2][1][0:60], flip=True)
+    add("bucket_edge", records[0][1][256:316])                  # offset 0 of bucket 1 = offset 256 of bucket 0
+    add("bucket_edge_rc", records[0][1][512:572], flip=True)
+    add("overlap", records[0][1][280:340])                      # lies in buckets 0 and 1
+    add("part2", records[1][1][300:360])                        # RNAME chrA, POS continues after part1's buckets
+    add("part2_rc", records[1][1][520:580], flip=True)
+    add("dup", chr_b[430:490])                                  # also in chrC: two best locations
+    add("dup_rc", chr_b[440:500], flip=True)
+    add("dup_partial", chr_b[380:440])                          # only 40 of its 60 bases are in chrC
+    add("tail_bucket", records[3][1][470:530])                  # lives in chrC's last kept bucket only
+    add("with_N", records[2][1][100:110] + "NNNN" + records[2][1][114:160])
+    add("lower_case", records[2][1][700:760].lower())
+    add("iupac", records[0][1][900:920] + "RYKM" + records[0][1][924:960])
+    add("low_quality", records[0][1][1000:1060], qual="#" * 60)
+    add("noisy_quality", records[0][1][1100:1160], qual="".join(chr(int(x)) for x in rng.integers(40, 75, 60)))
+    add("half_bad_quality", records[1][1][100:160], qual="#" * 30 + "I" * 30)
+    add("deletion", damaged(records[2][1][200:261], dele=30))
+    add("insertion_rc", damaged(records[2][1][300:359], ins=25), flip=True)
+    add("len61", records[0][1][600:661])
+    add("len100_rc", records[0][1][700:800], flip=True)
+    add("len120", records[1][1][50:170])
+    add("len121", records[2][1][500:621])                       # > 2 * read_len: five windows
+    add("long200", damaged(records[0][1][100:300], subs=3))
+    add("long300_rc", damaged(records[0][1][900:1200], subs=5, dele=150), flip=True)
+    add("long250_two_records", records[1][1][500:700] + records[2][1][0:50])   # chimeric
+    add("long400", damaged(records[2][1][350:750], subs=6, ins=200))
+    add("short5", "ACGTA")
+    add("len8", records[0][1][40:48])                           # two k-mers (one would hit the Sampler's ub == 0 quirk)
+    add("len20", records[0][1][40:60])
+    for i in range(4):
+        add(f"junk{i}", rnd(60 + 40 * i))
+    for i in range(10):                                         # noisier reads: 4-8 substitutions, some indels
+        r = int(rng.integers(0, 4))
+        at = int(rng.integers(1, len(records[r][1]) - 62))
+        add(f"noisy{i}", damaged(records[r][1][at:at + 61], subs=4 + i % 5, dele=20 if i % 3 == 0 else None),
+            flip=bool(i % 2))
+    out = {"flags": SAM_SMALL_FLAGS, "records": [list(r) for r in records], "reads": [list(r) for r in reads]}
+    for key, align in (("bucketmap", False), ("bucketmap_align", True)):
+        tool = pb.Tool(records, align=align, **SAM_SMALL_FLAGS)
+        refs, sam = tool.run(reads)
+        out[key] = {"num_buckets": tool.NB, "kept_buckets": len(tool.buckets), "sq": [list(r) for r in refs],
+                    "sam": [list(r) for r in sam]}
+    return out
+
+
 if __name__ == "__main__":
+    sys.path.insert(0, HERE)
     for name, fn in (("tiny_index.json", tiny_index), ("reads_small.json", reads_small),
-                     ("align_small.json", align_small), ("sampling_small.json", sampling_small)):
+                     ("align_small.json", align_small), ("sampling_small.json", sampling_small),
+                     ("sam_small.json", sam_small)):
+        if len(sys.argv) > 1 and name not in sys.argv[1:]:
+            continue
         with open(os.path.join(HERE, name), "w") as f:
             json.dump(fn(), f, separators=(",", ":"))
         print("wrote", name, os.path.getsize(os.path.join(HERE, name)), "bytes")
