@@ -216,8 +216,23 @@ struct bmf_ctx {
     bool profiling = false;
     uint32_t prof_max = 0, prof_n = 0;
     std::vector<hipEvent_t> ev;      // 3 per run: before sample, between, after vote
-    // buffers reused by bmf_map_windows from call to call
-    bmf_batch *scratch = nullptr;
+    // bmf_map_windows: a batch is cut into pieces; while piece i runs on `stream`, piece i+1 is uploaded on `h2d`
+    // and the results of piece i-1 come back on `d2h`.  Two slots of device + pinned staging buffers.
+    struct MapSlot {
+        bmf_batch dev;
+        DevBuf<uint32_t> pack;           // [total | ids of all lists back to back]
+        uint8_t *h_views = nullptr;      // pinned: rebased win_start (u64 x n) then win_len (u32 x n)
+        size_t h_views_cap = 0;
+        uint32_t *h_out = nullptr;       // pinned: counts (2n) then the head of `pack`
+        size_t h_out_cap = 0;
+        hipEvent_t uploaded = nullptr, ran = nullptr, landed = nullptr;
+        // the piece in flight
+        uint32_t first = 0, n = 0;
+        size_t ids_copied = 0;
+    };
+    MapSlot *slot[2] = {nullptr, nullptr};
+    hipStream_t h2d = nullptr, d2h = nullptr;
+    DevBuf<uint8_t> whole_bases, whole_quals;   // windows in no particular order: the read buffer is uploaded once
 };
 
 extern "C" {
@@ -435,12 +450,39 @@ static int select_pruned_variant(bmf_ctx *c) {
     return BMF_OK;
 }
 
+static void release_batch(bmf_batch *b) {
+    b->bases.release(); b->quals.release(); b->scan_tmp.release(); b->win_start.release(); b->win_len.release();
+    b->lists.release(); b->list_n.release(); b->rows_anded.release(); b->counts.release(); b->buckets.release();
+    b->offsets.release(); b->compact.release();
+    b->slice_min.release(); b->slice_cnt.release(); b->slice_ids.release();
+    b->q_counters.release(); b->q_slow.release(); b->q_live_n.release(); b->q_live_chunks.release();
+}
+
+static void free_map_slots(bmf_ctx *c) {
+    for (auto *&sl : c->slot) {
+        if (!sl) continue;
+        release_batch(&sl->dev);
+        sl->pack.release();
+        if (sl->h_views) (void)hipHostFree(sl->h_views);
+        if (sl->h_out) (void)hipHostFree(sl->h_out);
+        for (hipEvent_t e : {sl->uploaded, sl->ran, sl->landed})
+            if (e) (void)hipEventDestroy(e);
+        delete sl;
+        sl = nullptr;
+    }
+    c->whole_bases.release();
+    c->whole_quals.release();
+    if (c->h2d) (void)hipStreamDestroy(c->h2d);
+    if (c->d2h) (void)hipStreamDestroy(c->d2h);
+    c->h2d = c->d2h = nullptr;
+}
+
 void bmf_destroy(bmf_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->p.device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
-    if (c->scratch) bmf_batch_destroy(nullptr, c->scratch);
+    free_map_slots(c);
     free_index(c);
     (void)hipFree(c->d_lut);
     (void)hipFree(c->d_pos_table);
@@ -564,6 +606,11 @@ int bmf_build_index(bmf_ctx *c, const uint8_t *genome, uint64_t n_bases, const u
     HIP_TRY(hipSetDevice(c->p.device));
     const uint32_t pitch = c->dp.pitch;
     const uint64_t n_words = ((1ull << (2 * q)) + 31) / 32;
+    // launch geometry of the transpose: one wave per (64 buckets, 64 q-grams), 16 waves per workgroup
+    const uint64_t n_tr_waves = (uint64_t)((n_buckets + 63u) / 64u) * (n_words / 2);
+    const uint64_t n_tr_blocks = (n_tr_waves * 64 + bmi::kThreads - 1) / bmi::kThreads;
+    if (n_tr_blocks > 0x7FFFFFFFull || n_buckets > 0x7FFFFFFFu)
+        return fail(BMF_ERR_UNSUPPORTED, "the GPU index build cannot cover %u buckets at q = %u in one launch", n_buckets, q);
     uint8_t *d_genome = nullptr, *d_lut = c->d_lut;
     uint64_t *d_bstart = nullptr;
     uint32_t *d_blen = nullptr, *d_presence = nullptr;
@@ -592,9 +639,7 @@ int bmf_build_index(bmf_ctx *c, const uint8_t *genome, uint64_t n_bases, const u
     if (e == hipSuccess && n_buckets) {
         hipLaunchKernelGGL(bmi::bmi_presence_kernel, dim3(n_buckets), dim3(bmi::kThreads), lds, c->stream, d_genome, d_bstart,
                            d_blen, d_lut, q, d_presence);
-        const uint64_t n_waves = (uint64_t)((n_buckets + 63u) / 64u) * (n_words / 2);
-        hipLaunchKernelGGL(bmi::bmi_transpose_kernel, dim3((unsigned)((n_waves * 64 + bmi::kThreads - 1) / bmi::kThreads)),
-                           dim3(bmi::kThreads), 0, c->stream, reinterpret_cast<const uint64_t *>(d_presence), n_buckets, q,
+        hipLaunchKernelGGL(bmi::bmi_transpose_kernel, dim3((unsigned)n_tr_blocks), dim3(bmi::kThreads), 0, c->stream, reinterpret_cast<const uint64_t *>(d_presence), n_buckets, q,
                            c->d_k2i, c->d_rows, pitch);
         ok(hipGetLastError());
     }
@@ -745,17 +790,12 @@ void bmf_batch_destroy(bmf_ctx *c, bmf_batch *b) {
         (void)hipSetDevice(c->p.device);
         (void)hipStreamSynchronize(c->stream);
     }
-    b->bases.release(); b->quals.release(); b->scan_tmp.release(); b->win_start.release(); b->win_len.release();
-    b->lists.release(); b->list_n.release(); b->rows_anded.release(); b->counts.release(); b->buckets.release();
-    b->offsets.release(); b->compact.release();
-    b->slice_min.release(); b->slice_cnt.release(); b->slice_ids.release();
-    b->q_counters.release(); b->q_slow.release(); b->q_live_n.release(); b->q_live_chunks.release();
+    release_batch(b);
     delete b;
 }
 
-// Validates the windows, (re)sizes the batch's device buffers and uploads reads + window views.
-static int batch_fill(bmf_ctx *c, bmf_batch *b, const uint8_t *bases, const uint8_t *quals, uint64_t n_bytes,
-                      const uint64_t *win_start, const uint32_t *win_len, uint32_t n_windows) {
+static int check_windows(const bmf_ctx *c, const uint8_t *bases, const uint8_t *quals, uint64_t n_bytes,
+                         const uint64_t *win_start, const uint32_t *win_len, uint32_t n_windows) {
     if (n_windows && (!win_start || !win_len)) return fail(BMF_ERR_ARG, "win_start/win_len is null");
     if (n_windows > 0x3FFFFFFFu) return fail(BMF_ERR_ARG, "too many windows");
     if (n_bytes && (!bases || !quals)) return fail(BMF_ERR_ARG, "bases/quals is null");
@@ -766,15 +806,17 @@ static int batch_fill(bmf_ctx *c, bmf_batch *b, const uint8_t *bases, const uint
             return fail(BMF_ERR_ARG, "window %u [%llu, +%u) lies outside the %llu-byte read buffer", w,
                         (unsigned long long)win_start[w], win_len[w], (unsigned long long)n_bytes);
     }
-    HIP_TRY(hipSetDevice(c->p.device));
-    HIP_TRY(hipStreamSynchronize(c->stream));   // the buffers may still be in use by an earlier run
-    b->n_windows = n_windows;
-    b->n_bytes = n_bytes;
-    const size_t n = n_windows;
+    return BMF_OK;
+}
+
+// (Re)sizes the device buffers of a batch of n windows over n_bytes of reads (0: the reads live elsewhere).
+static hipError_t batch_reserve(bmf_ctx *c, bmf_batch *b, size_t n, size_t n_bytes) {
     hipError_t e = hipSuccess;
     auto ok = [&](hipError_t r) { if (e == hipSuccess) e = r; };
-    ok(b->bases.need((size_t)n_bytes));
-    ok(b->quals.need((size_t)n_bytes));
+    if (n_bytes) {
+        ok(b->bases.need(n_bytes));
+        ok(b->quals.need(n_bytes));
+    }
     ok(b->win_start.need(n));
     ok(b->win_len.need(n));
     ok(b->lists.need(2 * n * c->dp.list_len));
@@ -787,6 +829,27 @@ static int batch_fill(bmf_ctx *c, bmf_batch *b, const uint8_t *bases, const uint
         ok(b->slice_cnt.need(2 * n * c->n_slices));
         ok(b->slice_ids.need(2 * n * c->n_slices * c->p.max_candidates));
     }
+    if (c->dp.pass1_rows) {
+        ok(b->q_counters.need(2));
+        ok(b->q_slow.need(2 * n));
+        ok(b->q_live_n.need(2 * n));
+        ok(b->q_live_chunks.need(2 * n * bmf::kMaxLive));
+    }
+    return e;
+}
+
+// Validates the windows, (re)sizes the batch's device buffers and uploads reads + window views.
+static int batch_fill(bmf_ctx *c, bmf_batch *b, const uint8_t *bases, const uint8_t *quals, uint64_t n_bytes,
+                      const uint64_t *win_start, const uint32_t *win_len, uint32_t n_windows) {
+    const int rc = check_windows(c, bases, quals, n_bytes, win_start, win_len, n_windows);
+    if (rc != BMF_OK) return rc;
+    HIP_TRY(hipSetDevice(c->p.device));
+    HIP_TRY(hipStreamSynchronize(c->stream));   // the buffers may still be in use by an earlier run
+    b->n_windows = n_windows;
+    b->n_bytes = n_bytes;
+    const size_t n = n_windows;
+    hipError_t e = batch_reserve(c, b, n, (size_t)n_bytes);
+    auto ok = [&](hipError_t r) { if (e == hipSuccess) e = r; };
     if (e == hipSuccess && n_bytes) {
         ok(hipMemcpy(b->bases.p, bases, (size_t)n_bytes, hipMemcpyHostToDevice));
         ok(hipMemcpy(b->quals.p, quals, (size_t)n_bytes, hipMemcpyHostToDevice));
@@ -813,19 +876,13 @@ int bmf_batch_create(bmf_ctx *c, const uint8_t *bases, const uint8_t *quals, uin
     return BMF_OK;
 }
 
-int bmf_batch_run(bmf_ctx *c, bmf_batch *b) {
-    if (!c || !b) return fail(BMF_ERR_ARG, "bmf_batch_run: null argument");
-    // q_gram_mapper.h:389-393: "The q-gram index is empty. Cannot accept query."
-    if (!c->loaded) return fail(BMF_ERR_STATE, "the q-gram index is empty; cannot accept query");
-    if (b->n_windows == 0) return BMF_OK;
-    HIP_TRY(hipSetDevice(c->p.device));
-    const bool prof = c->profiling && c->prof_n < c->prof_max;
-    hipEvent_t *ev = prof ? &c->ev[(size_t)3 * c->prof_n] : nullptr;
-    if (prof) HIP_TRY(hipEventRecord(ev[0], c->stream));
+// The filter's kernels for the n_windows windows of `b`, reads at d_bases / d_quals, on the context's stream.
+static int launch_filter(bmf_ctx *c, bmf_batch *b, const uint8_t *d_bases, const uint8_t *d_quals, hipEvent_t *ev) {
+    if (ev) HIP_TRY(hipEventRecord(ev[0], c->stream));
     hipLaunchKernelGGL(bmf::bmf_sample_kernel, dim3(b->n_windows), dim3(bmf::kWave), c->sample_lds, c->stream, c->dp,
-                       b->bases.p, b->quals.p, b->win_start.p, b->win_len.p, c->d_lut, c->d_qgram_ok, c->d_k2i, c->d_pos_table,
+                       d_bases, d_quals, b->win_start.p, b->win_len.p, c->d_lut, c->d_qgram_ok, c->d_k2i, c->d_pos_table,
                        b->lists.p, b->list_n.p, b->rows_anded.p);
-    if (prof) HIP_TRY(hipEventRecord(ev[1], c->stream));
+    if (ev) HIP_TRY(hipEventRecord(ev[1], c->stream));
     if (c->dp.pass1_rows) {
         // two-pass pruning: full-width lower-bound pass, then the queued items' exact recount (bmf_vote2.hip.h)
         const size_t n_items = 2 * (size_t)b->n_windows;
@@ -856,12 +913,21 @@ int bmf_batch_run(bmf_ctx *c, bmf_batch *b) {
                            2 * b->n_windows, c->n_slices, b->slice_min.p, b->slice_cnt.p, b->slice_ids.p, b->counts.p,
                            b->buckets.p);
     }
-    if (prof) {
-        HIP_TRY(hipEventRecord(ev[2], c->stream));
-        c->prof_n++;
-    }
+    if (ev) HIP_TRY(hipEventRecord(ev[2], c->stream));
     HIP_TRY(hipGetLastError());
     return BMF_OK;
+}
+
+int bmf_batch_run(bmf_ctx *c, bmf_batch *b) {
+    if (!c || !b) return fail(BMF_ERR_ARG, "bmf_batch_run: null argument");
+    // q_gram_mapper.h:389-393: "The q-gram index is empty. Cannot accept query."
+    if (!c->loaded) return fail(BMF_ERR_STATE, "the q-gram index is empty; cannot accept query");
+    if (b->n_windows == 0) return BMF_OK;
+    HIP_TRY(hipSetDevice(c->p.device));
+    const bool prof = c->profiling && c->prof_n < c->prof_max;
+    const int rc = launch_filter(c, b, b->bases.p, b->quals.p, prof ? &c->ev[(size_t)3 * c->prof_n] : nullptr);
+    if (rc == BMF_OK && prof) c->prof_n++;
+    return rc;
 }
 
 int bmf_sync(bmf_ctx *c) {
@@ -923,6 +989,136 @@ int bmf_batch_rows_anded(bmf_ctx *c, bmf_batch *b, uint64_t *out) {
     return BMF_OK;
 }
 
+// ---- bmf_map_windows: host buffers in, host buffers out, copies hidden under the kernels -----------------
+//
+// The batch is cut into pieces of consecutive windows.  Per piece: the byte span of the read buffer its
+// windows cover (not the whole buffer: with several devices each context is handed its own window range of a
+// shared buffer) and the rebased window views go up on the h2d stream; sample + vote + exclusive scan +
+// compaction run on the context's stream; counts and the compacted ids come back on the d2h stream.  The host
+// issues piece i+1 before it waits for piece i, so uploads, kernels and downloads of neighbouring pieces overlap
+// (they do when `bases` / `quals` are page-locked -- bmf_pinned_alloc; pageable memory still works, its
+// copies just block the issuing thread).
+
+static uint32_t piece_windows_of(uint32_t n_windows) {
+    if (const char *e = getenv("BMF_PIECE_WINDOWS")) {
+        const long v = strtol(e, nullptr, 10);
+        if (v > 0) return (uint32_t)std::min<long>(v, 0x3FFFFFFF);
+    }
+    // at least four pieces where the batch allows it, pieces of 8 Ki ... 64 Ki windows
+    return std::min<uint32_t>(65536u, std::max<uint32_t>(8192u, (n_windows + 3u) / 4u));
+}
+
+static int map_slots_init(bmf_ctx *c) {
+    if (c->slot[0]) return BMF_OK;
+    HIP_TRY(hipStreamCreateWithFlags(&c->h2d, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&c->d2h, hipStreamNonBlocking));
+    for (auto *&sl : c->slot) {
+        sl = new bmf_ctx::MapSlot();
+        HIP_TRY(hipEventCreateWithFlags(&sl->uploaded, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&sl->ran, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&sl->landed, hipEventDisableTiming));
+    }
+    return BMF_OK;
+}
+
+static hipError_t pinned_need(void **p, size_t *cap, size_t bytes) {
+    if (bytes <= *cap && *p) return hipSuccess;
+    if (*p) (void)hipHostFree(*p);
+    *p = nullptr;
+    *cap = 0;
+    const size_t want = bytes + bytes / 8 + 64;
+    const hipError_t e = hipHostMalloc(p, want, hipHostMallocDefault);
+    if (e == hipSuccess) *cap = want;
+    return e;
+}
+
+// ids copied back with the counts, per (window, orientation): lists hold < 1 id on average; the rare piece with
+// more fetches the rest in a second copy
+constexpr size_t kIdsPerItemCopied = 2;
+
+// Uploads piece [first, first + n) and queues its kernels and its downloads.  `whole`: the read buffer is
+// already in HBM as a whole (c->whole_*), window starts stay absolute.
+static int map_piece_issue(bmf_ctx *c, bmf_ctx::MapSlot *sl, const uint8_t *bases, const uint8_t *quals,
+                           const uint64_t *win_start, const uint32_t *win_len, uint32_t first, uint32_t n, bool whole) {
+    sl->first = first;
+    sl->n = n;
+    uint64_t lo = ~0ull, hi = 0;
+    for (uint32_t w = first; w < first + n; w++) {
+        lo = std::min(lo, win_start[w]);
+        hi = std::max(hi, win_start[w] + win_len[w]);
+    }
+    if (whole) lo = 0;
+    const size_t span = whole ? 0 : (size_t)(hi - lo);
+    bmf_batch *b = &sl->dev;
+    b->n_windows = n;
+    b->n_bytes = span;
+    HIP_TRY(batch_reserve(c, b, n, span));
+    const size_t n_items = 2 * (size_t)n, mc = c->p.max_candidates;
+    HIP_TRY(b->offsets.need(n_items));
+    HIP_TRY(sl->pack.need(1 + n_items * mc));
+    HIP_TRY(pinned_need(reinterpret_cast<void **>(&sl->h_views), &sl->h_views_cap, (size_t)n * 12));
+    sl->ids_copied = kIdsPerItemCopied * n_items;
+    HIP_TRY(pinned_need(reinterpret_cast<void **>(&sl->h_out), &sl->h_out_cap, (n_items + 1 + sl->ids_copied) * sizeof(uint32_t)));
+    uint64_t *hs = reinterpret_cast<uint64_t *>(sl->h_views);
+    uint32_t *hl = reinterpret_cast<uint32_t *>(sl->h_views + (size_t)n * 8);
+    for (uint32_t w = 0; w < n; w++) hs[w] = win_start[first + w] - lo;
+    memcpy(hl, win_len + first, (size_t)n * sizeof(uint32_t));
+    if (span) {
+        HIP_TRY(hipMemcpyAsync(b->bases.p, bases + lo, span, hipMemcpyHostToDevice, c->h2d));
+        HIP_TRY(hipMemcpyAsync(b->quals.p, quals + lo, span, hipMemcpyHostToDevice, c->h2d));
+    }
+    HIP_TRY(hipMemcpyAsync(b->win_start.p, hs, (size_t)n * 8, hipMemcpyHostToDevice, c->h2d));
+    HIP_TRY(hipMemcpyAsync(b->win_len.p, hl, (size_t)n * 4, hipMemcpyHostToDevice, c->h2d));
+    HIP_TRY(hipEventRecord(sl->uploaded, c->h2d));
+    HIP_TRY(hipStreamWaitEvent(c->stream, sl->uploaded, 0));
+    const int rc = launch_filter(c, b, whole ? c->whole_bases.p : b->bases.p, whole ? c->whole_quals.p : b->quals.p, nullptr);
+    if (rc != BMF_OK) return rc;
+    // The dense result buffer (max_candidates slots per list) holds < 1 id per list on average: exclusive-scan
+    // the counts, gather the defined ids behind their total, copy only counts + the head of that.
+    size_t tmp_bytes = 0;
+    HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, b->counts.p, b->offsets.p, (int)n_items, c->stream));
+    HIP_TRY(b->scan_tmp.need(tmp_bytes));
+    HIP_TRY(hipcub::DeviceScan::ExclusiveSum(b->scan_tmp.p, tmp_bytes, b->counts.p, b->offsets.p, (int)n_items, c->stream));
+    hipLaunchKernelGGL(bmf::bmf_compact_total_kernel, dim3((unsigned)((n_items + 255) / 256)), dim3(256), 0, c->stream,
+                       b->counts.p, b->offsets.p, b->buckets.p, (uint32_t)mc, (uint32_t)n_items, sl->pack.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(sl->ran, c->stream));
+    HIP_TRY(hipStreamWaitEvent(c->d2h, sl->ran, 0));
+    HIP_TRY(hipMemcpyAsync(sl->h_out, b->counts.p, n_items * sizeof(uint32_t), hipMemcpyDeviceToHost, c->d2h));
+    const size_t head = std::min(1 + sl->ids_copied, 1 + n_items * mc);
+    HIP_TRY(hipMemcpyAsync(sl->h_out + n_items, sl->pack.p, head * sizeof(uint32_t), hipMemcpyDeviceToHost, c->d2h));
+    HIP_TRY(hipEventRecord(sl->landed, c->d2h));
+    return BMF_OK;
+}
+
+// Waits for the piece in the slot and scatters its results into the caller's arrays.
+static int map_piece_finish(bmf_ctx *c, bmf_ctx::MapSlot *sl, uint32_t *out_counts, uint32_t *out_buckets) {
+    HIP_TRY(hipEventSynchronize(sl->landed));
+    const size_t n_items = 2 * (size_t)sl->n, mc = c->p.max_candidates;
+    const uint32_t *counts = sl->h_out, *ids = sl->h_out + n_items + 1;
+    const size_t total = sl->h_out[n_items];
+    uint64_t sum = 0;
+    for (size_t i = 0; i < n_items; i++) {
+        if (counts[i] > mc) return fail(BMF_ERR_HIP, "device returned count %u > max_candidates", counts[i]);
+        sum += counts[i];
+    }
+    if (sum != total) return fail(BMF_ERR_HIP, "device returned %zu ids for counts that sum to %llu", total, (unsigned long long)sum);
+    std::vector<uint32_t> rest;
+    if (total > sl->ids_copied) {   // rare: more ids than came back with the counts
+        rest.resize(total);
+        HIP_TRY(hipMemcpy(rest.data(), sl->pack.p + 1, total * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        ids = rest.data();
+    }
+    uint32_t *oc = out_counts + 2 * (size_t)sl->first, *ob = out_buckets + 2 * (size_t)sl->first * mc;
+    memcpy(oc, counts, n_items * sizeof(uint32_t));
+    size_t at = 0;
+    for (size_t i = 0; i < n_items; i++) {
+        for (uint32_t t = 0; t < counts[i]; t++) ob[i * mc + t] = ids[at + t];
+        at += counts[i];
+    }
+    return BMF_OK;
+}
+
 int bmf_map_windows(bmf_ctx *c, const uint8_t *bases, const uint8_t *quals, uint64_t n_bytes,
                     const uint64_t *win_start, const uint32_t *win_len, uint32_t n_windows,
                     uint32_t *out_counts, uint32_t *out_buckets) {
@@ -930,10 +1126,44 @@ int bmf_map_windows(bmf_ctx *c, const uint8_t *bases, const uint8_t *quals, uint
     if (!c->loaded) return fail(BMF_ERR_STATE, "the q-gram index is empty; cannot accept query");
     if (n_windows == 0) return BMF_OK;
     if (!out_counts || !out_buckets) return fail(BMF_ERR_ARG, "bmf_map_windows: null output");
-    if (!c->scratch) c->scratch = new bmf_batch();   // device buffers are kept from call to call
-    int rc = batch_fill(c, c->scratch, bases, quals, n_bytes, win_start, win_len, n_windows);
-    if (rc == BMF_OK) rc = bmf_batch_run(c, c->scratch);
-    if (rc == BMF_OK) rc = bmf_batch_download(c, c->scratch, out_counts, out_buckets);
+    int rc = check_windows(c, bases, quals, n_bytes, win_start, win_len, n_windows);
+    if (rc != BMF_OK) return rc;
+    HIP_TRY(hipSetDevice(c->p.device));
+    rc = map_slots_init(c);
+    if (rc != BMF_OK) return rc;
+    const uint32_t piece = piece_windows_of(n_windows);
+    const uint32_t n_pieces = (n_windows + piece - 1) / piece;
+    // Bytes the pieces' spans add up to: windows in read order cover the buffer once; windows in no particular
+    // order (a permuted batch) would upload most of the buffer per piece -- then it goes up once, as a whole.
+    uint64_t span_sum = 0;
+    for (uint32_t p = 0; p < n_pieces; p++) {
+        uint64_t lo = ~0ull, hi = 0;
+        for (uint32_t w = p * piece; w < std::min(n_windows, (p + 1) * piece); w++) {
+            lo = std::min(lo, win_start[w]);
+            hi = std::max(hi, win_start[w] + win_len[w]);
+        }
+        span_sum += hi - lo;
+    }
+    const bool whole = n_pieces > 1 && span_sum > n_bytes + n_bytes / 2;
+    if (whole) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        HIP_TRY(c->whole_bases.need((size_t)n_bytes));
+        HIP_TRY(c->whole_quals.need((size_t)n_bytes));
+        HIP_TRY(hipMemcpyAsync(c->whole_bases.p, bases, (size_t)n_bytes, hipMemcpyHostToDevice, c->h2d));
+        HIP_TRY(hipMemcpyAsync(c->whole_quals.p, quals, (size_t)n_bytes, hipMemcpyHostToDevice, c->h2d));
+    }
+    // issue piece p, then finish piece p-1: its slot is free again before piece p+1 needs it
+    for (uint32_t p = 0; p <= n_pieces && rc == BMF_OK; p++) {
+        if (p < n_pieces)
+            rc = map_piece_issue(c, c->slot[p & 1], bases, quals, win_start, win_len, p * piece,
+                                 std::min(piece, n_windows - p * piece), whole);
+        if (rc == BMF_OK && p > 0) rc = map_piece_finish(c, c->slot[(p - 1) & 1], out_counts, out_buckets);
+    }
+    if (rc != BMF_OK) {   // leave nothing in flight that still reads the caller's buffers
+        (void)hipStreamSynchronize(c->h2d);
+        (void)hipStreamSynchronize(c->stream);
+        (void)hipStreamSynchronize(c->d2h);
+    }
     return rc;
 }
 

@@ -235,6 +235,17 @@ __global__ void bmf_compact_kernel(const uint32_t *__restrict__ counts, const ui
     for (uint32_t i = 0; i < n; i++) compact[o + i] = buckets[(size_t)item * max_cand + i];
 }
 
+// Same for bmf_map_windows' pieces: pack[0] = number of ids, pack[1 + offsets[item] ...] = the item's ids.
+__global__ void bmf_compact_total_kernel(const uint32_t *__restrict__ counts, const uint32_t *__restrict__ offsets,
+                                         const uint32_t *__restrict__ buckets, uint32_t max_cand, uint32_t n_items,
+                                         uint32_t *__restrict__ pack) {
+    const uint32_t item = blockIdx.x * blockDim.x + threadIdx.x;
+    if (item >= n_items) return;
+    const uint32_t n = counts[item], o = offsets[item];
+    for (uint32_t i = 0; i < n; i++) pack[1 + o + i] = buckets[(size_t)item * max_cand + i];
+    if (item == n_items - 1) pack[0] = o + n;
+}
+
 // --------------------------------------------------------------------------------------------------
 // vote kernel
 // --------------------------------------------------------------------------------------------------

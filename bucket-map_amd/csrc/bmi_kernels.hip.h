@@ -59,11 +59,12 @@ __global__ __launch_bounds__(kThreads) void bmi_transpose_kernel(const uint64_t 
                                                                 uint32_t q, const int32_t *__restrict__ k2i,
                                                                 uint8_t *__restrict__ rows, uint32_t pitch) {
     const uint32_t n_w64 = (1u << (2 * q)) >> 6;           // 64-bit words per bucket
-    const uint32_t wave = (blockIdx.x * kThreads + threadIdx.x) >> 6;
+    // 64-bit: (groups of 64 buckets) x (q-gram words) passes 2^32 / 64 waves from ~1 M buckets on at q = 9
+    const uint64_t wave = (uint64_t)blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6);
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t n_groups = (n_buckets + 63u) / 64u;
+    const uint64_t n_groups = (n_buckets + 63u) / 64u;
     if (wave >= n_groups * n_w64) return;
-    const uint32_t group = wave / n_w64, w64 = wave % n_w64;  // consecutive waves walk the q-gram words of one group
+    const uint32_t group = (uint32_t)(wave / n_w64), w64 = (uint32_t)(wave % n_w64);  // consecutive waves walk the q-gram words of one group
     const uint32_t b = group * 64u + lane;
     const uint64_t v = b < n_buckets ? presence[(size_t)b * n_w64 + w64] : 0ull;
     uint64_t mine = 0;

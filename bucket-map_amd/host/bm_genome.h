@@ -21,6 +21,7 @@
 #include <functional>
 #include <stdexcept>
 #include <mutex>
+#include <memory>
 #include <string>
 #include <thread>
 #include <vector>
@@ -176,15 +177,14 @@ struct FastqRecord {
 // and lines are found with memchr (the mapper, the locator's sampling pass and the SAM pass each walk
 // the whole FASTQ, as the reference does, so this loop is the host-side bottleneck of the tool).
 inline void for_each_fastq(const std::string &path, const std::function<void(const FastqRecord &)> &op) {
-    FILE *f = std::fopen(path.c_str(), "rb");
-    if (!f) throw std::runtime_error("cannot open FASTQ file " + path);
+    // closed on every way out, the callback's exceptions included
+    std::unique_ptr<FILE, int (*)(FILE *)> file(std::fopen(path.c_str(), "rb"), &std::fclose);
+    if (!file) throw std::runtime_error("cannot open FASTQ file " + path);
+    FILE *f = file.get();
     std::vector<char> buf(io_block_bytes());
     size_t have = 0;
     bool eof = false;
-    auto fail = [&](const std::string &what) {
-        std::fclose(f);
-        throw std::runtime_error(what + " in " + path);
-    };
+    auto fail = [&](const std::string &what) { throw std::runtime_error(what + " in " + path); };
     for (;;) {
         if (!eof) {
             const size_t got = std::fread(buf.data() + have, 1, buf.size() - have, f);
@@ -232,7 +232,6 @@ inline void for_each_fastq(const std::string &path, const std::function<void(con
         have -= pos;
         if (have == buf.size()) buf.resize(buf.size() * 2);
     }
-    std::fclose(f);
 }
 
 // One kept bucket of iterate_through_buckets (utils.h:72-97).

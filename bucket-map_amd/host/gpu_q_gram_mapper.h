@@ -57,8 +57,11 @@ private:
         // first allocation: room for a whole batch of reads of the nominal length (one page-locking call)
         size_t cap = s.cap ? s.cap : std::max<size_t>(1u << 20, batch_reads_ * static_cast<size_t>(read_length_ + 8));
         while (cap < need) cap *= 2;
-        uint8_t *b = host_alloc(cap), *q = host_alloc(cap);
-        if (!b || !q) throw std::runtime_error("out of host memory for the read staging buffers");
+        uint8_t *b = host_alloc(cap), *q = b ? host_alloc(cap) : nullptr;
+        if (!b || !q) {
+            if (b) host_free(b);
+            throw std::runtime_error("out of host memory for the read staging buffers");
+        }
         if (s.n_bytes) {
             std::memcpy(b, s.bases, s.n_bytes);
             std::memcpy(q, s.quals, s.n_bytes);
@@ -90,18 +93,25 @@ public:
         std::vector<uint8_t> read_mapped;
 
         // runs on the worker thread: query_sequence for every window of the slot
+        // (an exception must not leave a std::thread: it is turned into a failed batch, reported by scatter)
         auto run = [&](Slot &s) {
-            const uint32_t n = static_cast<uint32_t>(s.win_start.size());
-            s.counts.assign(2 * static_cast<size_t>(n), 0);
-            s.buckets.assign(2 * static_cast<size_t>(n) * max_candidates_, 0);
-            s.ok = true;
-            if (n == 0) return;
-            if (!index_loaded()) {
-                // q_gram_mapper.h:389-393 (printed once per query in the reference; once per batch here)
-                std::cerr << "[ERROR]\t\tThe q-gram index is empty. Cannot accept query.\n";
-            } else {
-                s.ok = query_windows(s.bases, s.quals, s.n_bytes, s.win_start.data(), s.win_len.data(), n, s.counts.data(),
-                                     s.buckets.data());
+            s.ok = false;
+            try {
+                const uint32_t n = static_cast<uint32_t>(s.win_start.size());
+                s.counts.assign(2 * static_cast<size_t>(n), 0);
+                s.buckets.assign(2 * static_cast<size_t>(n) * max_candidates_, 0);
+                s.ok = true;
+                if (n == 0) return;
+                if (!index_loaded()) {
+                    // q_gram_mapper.h:389-393 (printed once per query in the reference; once per batch here)
+                    std::cerr << "[ERROR]\t\tThe q-gram index is empty. Cannot accept query.\n";
+                } else {
+                    s.ok = query_windows(s.bases, s.quals, s.n_bytes, s.win_start.data(), s.win_len.data(), n, s.counts.data(),
+                                         s.buckets.data());
+                }
+            } catch (const std::exception &e) {
+                std::cerr << "[ERROR]\t\t" << e.what() << "\n";
+                s.ok = false;
             }
         };
         // q_gram_mapper.h:526-538: scatter (read, window start) into the per-bucket lists, in batch order
@@ -208,6 +218,8 @@ protected:
         const size_t D = ctx_.size();
         std::vector<int> rc(D, BMF_OK);
         std::vector<std::string> msg(D);
+        // every context is handed the shared buffers and ITS window range: bmf_map_windows uploads only the byte
+        // span those windows cover
         auto work = [&](size_t d) {
             const uint32_t w0 = static_cast<uint32_t>(static_cast<uint64_t>(n) * d / D);
             const uint32_t w1 = static_cast<uint32_t>(static_cast<uint64_t>(n) * (d + 1) / D);

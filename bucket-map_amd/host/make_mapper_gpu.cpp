@@ -39,17 +39,25 @@ bool bm_gpu_index(const bm::cmd_arguments &args, const bm::Genome &genome, unsig
     bmf_params p{};
     p.num_buckets = num_buckets;
     p.q = args.index_seed_length;
-    p.k = std::max<uint32_t>(args.query_seed_length, args.index_seed_length);
+    // the index rows depend on q and the buckets only: the mapper's own limits (read_len, k - q + 1 ...) must not
+    // decide whether an index can be BUILT, so the build context asks for the smallest mapper there is
+    p.k = args.index_seed_length;
     p.num_samples = 1;
     p.num_fault = 1;
     p.max_candidates = 1;
-    p.read_len = std::max<uint32_t>(args.max_read_length, p.k);
+    p.read_len = args.index_seed_length;
     p.num_segment_samples = 5;
     p.device = args.gpus.front();
     bmf_ctx *c = nullptr;
-    if (bmf_create(&p, &c) != BMF_OK) throw std::runtime_error(std::string("--gpu-index: ") + bmf_last_error());
-    int rc = bmf_build_index(c, flat.data(), flat.size(), bstart.data(), blen.data(), static_cast<uint32_t>(buckets.size()),
-                             ix.kmer_to_index.data(), ix.kmer_to_index.size());
+    int rc = bmf_create(&p, &c);
+    if (rc == BMF_ERR_UNSUPPORTED || rc == BMF_ERR_ARG) return false;   // not a geometry the device build covers: host indexer
+    if (rc != BMF_OK) throw std::runtime_error(std::string("--gpu-index: ") + bmf_last_error());
+    rc = bmf_build_index(c, flat.data(), flat.size(), bstart.data(), blen.data(), static_cast<uint32_t>(buckets.size()),
+                         ix.kmer_to_index.data(), ix.kmer_to_index.size());
+    if (rc == BMF_ERR_UNSUPPORTED) {
+        bmf_destroy(c);
+        return false;
+    }
     if (rc == BMF_OK) {
         ix.rows.assign(static_cast<size_t>(ix.num_rows) * ix.row_bytes, 0);
         rc = bmf_index_download(c, ix.rows.data(), nullptr);
@@ -63,9 +71,9 @@ bool bm_gpu_index(const bm::cmd_arguments &args, const bm::Genome &genome, unsig
 std::unique_ptr<bm::offset_scanner> bm_make_scanner(const bm::cmd_arguments &args, int allowed_mismatch, int allowed_indel) {
     return std::make_unique<bm::gpu_offset_scanner>(args.query_seed_length, static_cast<uint32_t>(args.locator_sample_size),
                                                     allowed_mismatch, allowed_indel,
-                                                    args.bucket_len + args.max_read_length, args.gpus.front());
+                                                    args.bucket_len + args.max_read_length, args.gpus);
 }
 
 std::unique_ptr<bm::alignment_verifier> bm_make_verifier(const bm::cmd_arguments &args) {
-    return std::make_unique<bm::gpu_alignment_verifier>(args.gpus.front());
+    return std::make_unique<bm::gpu_alignment_verifier>(args.gpus);
 }

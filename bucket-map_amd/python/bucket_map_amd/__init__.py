@@ -263,7 +263,9 @@ class Filter:
     # mapper::load, from <dir>/<indicator>.{kmers_index,qgram}
     def load_index_files(self, index_dir: str, indicator: str) -> None:
         _check(lib().bmf_load_index_files(self._h, os.fsencode(index_dir), indicator.encode()))
-        self._n_rows = -1
+        n = C.c_uint64()
+        _check(lib().bmf_index_download(self._h, None, C.byref(n)))
+        self._n_rows = int(n.value)
 
     # mapper::reset
     def reset(self) -> None:

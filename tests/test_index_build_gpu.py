@@ -60,3 +60,42 @@ def test_build_errors():
     with pytest.raises(bma.BmfError):                     # already loaded
         flt.build_index(flat, bs, bl, host.select_qgrams(7))
     flt.close()
+
+
+def test_transpose_beyond_2_pow_32_lanes():
+    """q = 10 with 300 000 tiny buckets: (groups of 64 buckets) x (4^q / 64 q-gram words) x 64 lanes = 4.9e9 > 2^32.
+    A 32-bit wave index aliases there and leaves rows unwritten (all-zero rows = false-negative buckets).  The rows
+    (39 GB) stay in HBM; their popcounts -- zeros[row] = NB - #buckets holding the q-gram -- are checked for ALL
+    4^q rows against a numpy count over the same buckets."""
+    import bucket_map_amd as bma
+    from bucket_map_amd import host
+    q, bucket_len, read_len, nb = 10, 16, 12, 300_000
+    g = host.Genome.synth(77, [nb * bucket_len + 5])
+    flat, _ = g.flat()
+    bstart, blen = g.bucket_views(bucket_len, read_len)
+    assert len(bstart) == nb and g.awk_bucket_num(bucket_len) == nb + 1
+    k2i = host.select_qgrams(q)
+    flt = bma.Filter(bma.Params.from_cli(nb + 1, read_len=read_len, index_seed=q, query_seed=q))
+    flt.build_index(flat, bstart, blen, k2i)
+    zeros = flt.zeros()
+    flt.close()
+    # numpy: hash of every q-gram start, then per bucket the distinct hashes it holds
+    codes = np.zeros(256, np.uint8)
+    for c, r in zip(b"ACGT", range(4)):
+        codes[c] = r
+    r = codes[flat].astype(np.uint32)
+    n = len(r) - q + 1
+    h = np.zeros(n, np.uint32)
+    for t in range(q):
+        h = h * 4 + r[t:t + n]
+    per = int(blen.max()) - q + 1
+    pos = bstart.astype(np.int64)[:, None] + np.arange(per)[None, :]
+    ok = np.arange(per)[None, :] < (blen.astype(np.int64) - q + 1)[:, None]
+    hb = np.where(ok, h[np.minimum(pos, n - 1)], np.uint32(0xFFFFFFFF))
+    hb.sort(axis=1)
+    first = np.ones_like(hb, bool)
+    first[:, 1:] = hb[:, 1:] != hb[:, :-1]
+    keep = first & (hb != 0xFFFFFFFF)
+    counts = np.bincount(hb[keep].astype(np.int64), minlength=4 ** q)
+    assert counts.max() > 0 and (counts > 0).mean() > 0.9
+    assert np.array_equal(zeros, (nb + 1 - counts).astype(np.uint32))
