@@ -9,8 +9,10 @@ A "step" is one pass of the hot path (sample kernel + vote kernel) over one batc
 already resident in HBM.  Workload at N=1 = BASELINE.json configs[1]: Egu-like 1.70 Gbp synthetic
 genome cut into 65 536-bp buckets, `-f 1` index, 1 M x 300 bp simulated reads (sub 0.002,
 ins = del 0.00025), CLI-default parameters (k=12 q=9 S=15 e=0.4 -> F=6).  With N GPUs the index is
-replicated, every rank maps its own 1 M-read shard, and there is no collective on the data path
-(weak scaling); torch.distributed only provides the barrier and the max-over-ranks of the time.
+replicated and there is no collective on the data path; torch.distributed only provides the barrier and
+the max-over-ranks of the time.  N > 1 defaults to BASELINE.json configs[2] -- the SAME 1 M reads cut into
+N contiguous shards, one per rank (`--scaling strong`, "scaling": "strong"); `--scaling weak` gives every
+rank its own 1 M reads instead, and the strong run reports that leg too, as `weak_scaling`.
 
 Rank 0 prints ONE JSON line.  `roofline` prices the vote kernel: algorithmic bytes = (index rows the
 reference ANDs, both orientations) x ceil(NB/8)   / mean kernel time from HIP events on
@@ -69,6 +71,90 @@ def egu_like_record_lengths(total):
     return big + [int(x) for x in small]
 
 
+def live_pmc_traffic(args, log):
+    """Runs this file again as `--pmc-child` under rocprofv3 --pmc FETCH_SIZE and returns the roofline fields
+    {traffic, traffic_source, traffic_dispatches, traffic_over_algorithmic}, or None when the profiler is not usable."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None
+    out = tempfile.mkdtemp(prefix="bm_pmc_", dir="/tmp")
+    cmd = [exe, "--pmc", "FETCH_SIZE", "--output-format", "csv", "-d", out, "--", sys.executable, os.path.abspath(__file__),
+           "--pmc-child", "--workload", args.workload, "--params", args.params, "--kmer-frac", str(args.kmer_frac),
+           "--reads", str(args.reads), "--total-bp", str(args.total_bp), "--host-threads", str(args.host_threads)]
+    t0 = time.perf_counter()
+    try:
+        r = subprocess.run(cmd, cwd="/tmp", env={**os.environ, "TMPDIR": "/tmp"}, capture_output=True, text=True, timeout=600)
+        files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
+        if r.returncode != 0 or not files:
+            log(f"pmc child failed (rc {r.returncode}): {r.stderr[-400:]}")
+            return None
+        child = json.loads(r.stdout.strip().splitlines()[-1])
+        vals = []
+        for row in csv.DictReader(open(max(files, key=os.path.getmtime))):
+            k = row["Kernel_Name"]
+            if row["Counter_Name"] == "FETCH_SIZE" and "bmf_vote_kernel" in k:
+                vals.append(float(row["Counter_Value"]))
+        if not vals:
+            return None
+        traffic = sum(vals) / len(vals) * 1024 * 2
+        log(f"pmc child: {len(vals)} vote dispatches, FETCH_SIZE mean {sum(vals) / len(vals):.0f} KiB ({time.perf_counter() - t0:.0f}s)")
+        return {"traffic": int(traffic), "traffic_dispatches_KiB": vals,
+                "traffic_over_algorithmic": traffic / child["algorithmic_bytes_per_launch"],
+                "traffic_source": "live: rocprofv3 --pmc FETCH_SIZE child run of this bench (same workload, vote kernel, "
+                                  f"mean of {len(vals)} dispatches) x1024 (KiB) x2 (gfx950 wide streaming reads)"}
+    except (OSError, ValueError, KeyError, subprocess.SubprocessError) as e:
+        log(f"pmc child failed: {e}")
+        return None
+    finally:
+        shutil.rmtree(out, ignore_errors=True)
+
+
+def pmc_child(args):
+    """The profiled child of live_pmc_traffic: same synthetic workload, three launches of the hot path, nothing else
+    (no torch, no CPU leg).  Prints the algorithmic bytes of one vote launch."""
+    import numpy as np
+    import bucket_map_amd as bma
+    from bucket_map_amd import host
+    total_bp, bucket_len, read_len, n_reads = WORKLOADS[args.workload]
+    n_reads = args.reads or n_reads
+    total_bp = args.total_bp or total_bp
+    threads = args.host_threads or usable_cores()
+    cli = (dict(index_seed=9, query_seed=14, read_len=read_len, mapper_samples=20, max_error_rate=0.6, distinguishability=0.5,
+                average_base_quality=10) if args.params == "bench" else
+           dict(index_seed=9, query_seed=12, read_len=read_len, mapper_samples=15, max_error_rate=0.4, distinguishability=0.5,
+                average_base_quality=25))
+    genome = host.Genome.synth(20240001, workload_record_lengths(args.workload, total_bp), threads)
+    nb = genome.awk_bucket_num(bucket_len)
+    reads = host.Reads(genome, bucket_len, read_len, read_len, n_reads, sub=0.002, ins=0.00025, dele=0.00025, seed=20240003,
+                       threads=threads)
+    flt = bma.Filter(bma.Params.from_cli(nb, device=0, **cli))
+    flat, _ = genome.flat()
+    bstart, blen = genome.bucket_views(bucket_len, read_len)
+    flt.build_index(flat, bstart, blen, host.select_qgrams(cli["index_seed"], args.kmer_frac))
+    del flat
+    ws, wl, _, _ = bma.windows_for_reads(reads.offsets, read_len)
+    batch = flt.batch(reads.bases, reads.quals, ws, wl)
+    for _ in range(3):
+        batch.run()
+    flt.sync()
+    print(json.dumps({"algorithmic_bytes_per_launch": int(batch.rows_anded()) * ((nb + 7) >> 3)}), flush=True)
+    batch.close()
+    flt.close()
+
+
+def workload_record_lengths(workload, total_bp):
+    if workload == "ecoli":
+        return [total_bp]
+    if workload == "grch38":
+        return [int(total_bp * m / sum(GRCH38_MBP)) for m in GRCH38_MBP]
+    return egu_like_record_lengths(total_bp)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -94,7 +180,15 @@ def main():
                     help="torch.distributed backend for the barrier / max-over-ranks (nccl = RCCL)")
     ap.add_argument("--device-override", type=int, default=-1,
                     help="rehearsal only: put every rank on this device (use with --backend gloo)")
+    ap.add_argument("--scaling", default="auto", choices=["auto", "strong", "weak"],
+                    help="N > 1: strong = the workload's reads cut into N contiguous shards (BASELINE configs[2], the "
+                         "default); weak = every rank maps its own full batch")
+    ap.add_argument("--no-pmc", action="store_true",
+                    help="do not spawn the rocprofv3 --pmc FETCH_SIZE child that measures roofline.traffic live")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.pmc_child:
+        return pmc_child(args)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -141,12 +235,7 @@ def main():
 
     # ---------------- synthetic inputs, identical on every rank except the reads
     t0 = time.perf_counter()
-    if args.workload == "ecoli":
-        lens = [total_bp]
-    elif args.workload == "grch38":
-        lens = [int(total_bp * m / sum(GRCH38_MBP)) for m in GRCH38_MBP]
-    else:
-        lens = egu_like_record_lengths(total_bp)
+    lens = workload_record_lengths(args.workload, total_bp)
     genome = host.Genome.synth(20240001, lens, threads)
     nb = genome.awk_bucket_num(bucket_len)
     log(f"genome: {len(lens)} records, {genome.total_length()} bp, NB={nb} ({time.perf_counter() - t0:.1f}s)")
@@ -157,9 +246,13 @@ def main():
         index = host.Index(genome, nb, bucket_len, read_len, q=cli["index_seed"], kmer_frac=args.kmer_frac, threads=threads)
         log(f"index (host indexer): {index.num_rows} rows x {row_bytes} B ({time.perf_counter() - t0:.1f}s)")
     t0 = time.perf_counter()
+    scaling = args.scaling if args.scaling != "auto" else ("strong" if world > 1 else "weak")
+    if world == 1:
+        scaling = "weak"          # one GPU: the two coincide; the contract's default label
+    # strong: every rank simulates the same batch (same seed) and keeps the windows of its contiguous shard
     reads = host.Reads(genome, bucket_len, read_len, read_len, n_reads, sub=0.002, ins=0.00025, dele=0.00025,
-                       seed=20240003 + 7919 * rank, threads=threads)
-    log(f"reads: {reads.n} x {read_len} bp ({time.perf_counter() - t0:.1f}s)")
+                       seed=20240003 + (7919 * rank if scaling == "weak" else 0), threads=threads)
+    log(f"reads: {reads.n} x {read_len} bp ({time.perf_counter() - t0:.1f}s), scaling {scaling}")
 
     # ---------------- GPU side
     params = bma.Params.from_cli(nb, device=device, flags=bma.BMF_FLAG_EARLY_EXIT if args.early_exit else 0, **cli)
@@ -179,7 +272,15 @@ def main():
         f"({time.perf_counter() - t0:.1f}s), kernel variant {flt.info()}")
     # mapper::map's windowing: one window [0, min(read_len, len)) per short read
     win_start, win_len, _, _ = bma.windows_for_reads(reads.offsets, read_len)
-    batch = flt.batch(reads.bases, reads.quals, win_start, win_len)
+    shard = slice(0, reads.n)
+    if scaling == "strong" and world > 1:
+        shard = slice(reads.n * rank // world, reads.n * (rank + 1) // world)
+        lo, hi = int(reads.offsets[shard.start]), int(reads.offsets[shard.stop])
+        batch = flt.batch(reads.bases[lo:hi], reads.quals[lo:hi], win_start[shard] - np.uint64(lo), win_len[shard])
+    else:
+        batch = flt.batch(reads.bases, reads.quals, win_start, win_len)
+    n_mine = shard.stop - shard.start
+    reads_per_step = reads.n if scaling == "strong" else world * reads.n
 
     def barrier():
         if world > 1:
@@ -207,12 +308,39 @@ def main():
     rows_anded = batch.rows_anded()
     counts, buckets = batch.download()
 
+    # the other scaling mode, beside the headline (strong runs only): every rank maps the whole batch
+    weak_leg = None
+    if scaling == "strong" and world > 1:
+        wb = flt.batch(reads.bases, reads.quals, win_start, win_len)
+        wb.run()
+        barrier()
+        t_w = time.perf_counter()
+        for _ in range(args.steps):
+            wb.run()
+        flt.sync()
+        weak_s = time.perf_counter() - t_w
+        tw = torch.tensor([weak_s], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
+        dist.all_reduce(tw, op=dist.ReduceOp.MAX)
+        weak_s = float(tw.item())
+        wb.close()
+        weak_leg = {"value": world * reads.n * args.steps / weak_s, "unit": "reads/s", "ms_per_step": weak_s / args.steps * 1e3,
+                    "what": f"every rank maps its own copy of the {reads.n}-read batch (per-GPU work fixed)"}
+
     # PCIe-inclusive rate of the host-buffer entry point (bmf_map_windows: H2D of the reads, both kernels,
-    # compacted D2H of the results).  Reported for DESIGN.md only; it is never `value`.
-    flt.map_windows(reads.bases, reads.quals, win_start, win_len)          # first call allocates
-    t_h = time.perf_counter()
-    flt.map_windows(reads.bases, reads.quals, win_start, win_len)
-    host_buffer_s = time.perf_counter() - t_h
+    # compacted D2H of the results; the batch goes through in pieces so that the copies of one piece run under
+    # the kernels of its neighbours).  From page-locked buffers, as the `bucketmap` tool stages its reads, and
+    # from ordinary pageable memory.  Reported for DESIGN.md only; it is never `value`.
+    def time_map_windows(f, b, q):
+        f.map_windows(b, q, win_start, win_len)          # first call allocates
+        best = 1e9
+        for _ in range(3):
+            t_h = time.perf_counter()
+            f.map_windows(b, q, win_start, win_len)
+            best = min(best, time.perf_counter() - t_h)
+        return best
+    pinned_b, pinned_q = bma.pinned_copy(reads.bases), bma.pinned_copy(reads.quals)
+    host_pinned_s = time_map_windows(flt, pinned_b.array, pinned_q.array)
+    host_buffer_s = time_map_windows(flt, reads.bases, reads.quals)
 
     # Second leg, reported beside the headline, never instead of it: the same batch with BMF_FLAG_EARLY_EXIT
     # (identical outputs from fewer row bytes: waves stop, and lanes stop loading, once no bucket they hold can
@@ -228,7 +356,11 @@ def main():
             bstart, blen = genome.bucket_views(bucket_len, read_len)
             fp.build_index(flat, bstart, blen, k2i)
             del flat
-        bp = fp.batch(reads.bases, reads.quals, win_start, win_len)
+        if shard.stop - shard.start != reads.n:
+            lo, hi = int(reads.offsets[shard.start]), int(reads.offsets[shard.stop])
+            bp = fp.batch(reads.bases[lo:hi], reads.quals[lo:hi], win_start[shard] - np.uint64(lo), win_len[shard])
+        else:
+            bp = fp.batch(reads.bases, reads.quals, win_start, win_len)
         bp.run()
         fp.sync()
         if world > 1:
@@ -246,68 +378,90 @@ def main():
         same = bool(np.array_equal(cp, counts))
         maskp = np.arange(bkp.shape[-1])[None, None, :] < counts[:, :, None]
         same = same and bool(np.array_equal(bkp[maskp], buckets[maskp]))
-        pruned = {"value": world * reads.n * args.steps / pruned_s, "unit": "reads/s", "ms_per_step": pruned_s / args.steps * 1e3,
+        pruned = {"value": reads_per_step * args.steps / pruned_s, "unit": "reads/s", "ms_per_step": pruned_s / args.steps * 1e3,
                   "outputs_identical_to_headline_run": same, "flag": "BMF_FLAG_EARLY_EXIT",
                   "pass1_rows": fp.info()["pass1_rows"]}
         if pruned["pass1_rows"]:
             pruned["items_recounted"], pruned["items_slow_path"] = bp.pass2_counts()
         bp.close()
+        if world == 1:
+            pruned["pcie_inclusive_ms_pinned"] = time_map_windows(fp, pinned_b.array, pinned_q.array) * 1e3
         fp.close()
 
     # ---------------- correctness properties at full size (size-independent)
-    strand = reads.truth_rc.astype(np.int64)
-    idx = np.arange(reads.n)
+    strand = reads.truth_rc.astype(np.int64)[shard]
+    idx = np.arange(n_mine)
     own = buckets[idx, strand]                                   # candidate list on the true strand
     valid = np.arange(own.shape[1])[None, :] < counts[idx, strand][:, None]
-    recovered = float(((own == reads.truth_bucket[:, None]) & valid).any(axis=1).mean())
+    recovered = float(((own == reads.truth_bucket[shard][:, None]) & valid).any(axis=1).mean())
     mapped = float((counts.sum(axis=1) > 0).mean())
 
     result = None
     if rank == 0:
-        reads_per_s = world * reads.n * args.steps / elapsed
+        reads_per_s = reads_per_step * args.steps / elapsed
         vote_ms = float(np.mean(ms_vote))
         algo_bytes_vote = rows_anded * row_bytes                 # rows ANDed x ceil(NB/8)
-        algo_bytes_read = algo_bytes_vote + 2 * int(win_len.sum())
+        algo_bytes_read = algo_bytes_vote + 2 * int(win_len[shard].sum())
         achieved = algo_bytes_vote / (vote_ms * 1e-3) / 1e9
+        # What the HBM devices themselves see: FETCH_SIZE (and the algorithmic count) include reads the 256 MiB
+        # Infinity Cache serves.  A uniformly gathered table of T bytes keeps about 256 MiB / T of itself there
+        # (MI355X_MICROARCH.md, Infinity Cache), so the HBM side moves roughly (1 - share) of the bytes.
+        index_bytes = (n_rows + 1) * flt.info()["row_pitch_bytes"]
+        ic_share = min(1.0, (256 << 20) / index_bytes)
         result = {
             "metric": "mapped reads/sec (1M\u00d7300bp, 65536-bucket index)",   # BASELINE.json's metric, its first clause
             "value": reads_per_s, "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": scaling,
             "vs_baseline": None, "dtype": "u32", "data": "synthetic",
             "config": {
                 "workload": f"{args.workload}-like synthetic genome {genome.total_length()} bp, bucket_len {bucket_len}, "
-                            f"NB={nb}, -f {args.kmer_frac:g} index ({n_rows} rows x {row_bytes} B), {reads.n} x {read_len} bp "
-                            f"simulated reads per GPU (sub 0.002, ins=del 0.00025), params {args.params} "
+                            f"NB={nb}, -f {args.kmer_frac:g} index ({n_rows} rows x {row_bytes} B), {reads_per_step} x {read_len} bp "
+                            f"simulated reads per step (sub 0.002, ins=del 0.00025), params {args.params} "
                             f"(k={params.k} q={params.q} S={params.num_samples} F={params.num_fault})",
-                "reads_per_gpu": int(reads.n), "global_reads_per_step": int(world * reads.n),
-                "parallelism": f"reads sharded over {world} GPU(s), index replicated, no collective",
+                "reads_per_gpu": int(n_mine), "global_reads_per_step": int(reads_per_step),
+                "parallelism": f"reads sharded over {world} GPU(s) in contiguous ranges, index replicated, no collective",
                 "early_exit": bool(args.early_exit),
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS, "traffic": None, "traffic_source": None,
                 "kernel": "bmf_vote_kernel", "kernel_ms": vote_ms, "algorithmic_bytes_per_launch": int(algo_bytes_vote),
-                "bytes_per_read": algo_bytes_read / reads.n, "sample_kernel_ms": float(np.mean(ms_sample)),
+                "bytes_per_read": algo_bytes_read / n_mine, "sample_kernel_ms": float(np.mean(ms_sample)),
+                "index_bytes_in_hbm": int(index_bytes), "infinity_cache_share": ic_share,
+                "hbm_side_estimate_GBps": achieved * (1.0 - ic_share),
+                "note": "achieved = algorithmic row bytes / kernel time: it counts reads the 256 MiB Infinity Cache serves; "
+                        "hbm_side_estimate_GBps = achieved x (1 - infinity_cache_share) is what the HBM stacks move",
             },
             "checks": {"reads_with_candidates": mapped, "source_bucket_recovered": recovered},
             "pruned": pruned,
-            "pcie_inclusive": {"reads_per_s_per_gpu": reads.n / host_buffer_s, "ms": host_buffer_s * 1e3,
-                               "what": "bmf_map_windows on pageable host buffers: H2D reads + kernels + compact D2H"},
+            "weak_scaling": weak_leg,
+            "pcie_inclusive": {"reads_per_s_per_gpu": reads.n / host_pinned_s, "ms": host_pinned_s * 1e3,
+                               "ms_pageable": host_buffer_s * 1e3, "reads": int(reads.n),
+                               "what": "bmf_map_windows, host buffers in and out: H2D of the reads, kernels and compacted D2H "
+                                       "pipelined in pieces; page-locked source (ms) and pageable source (ms_pageable)"},
         }
 
-        # HBM-side traffic of the vote kernel: PMC counters cannot be read in-process, so the value comes
-        # from the committed rocprofv3 --pmc FETCH_SIZE pass of the SAME workload (tools/profile.sh),
-        # corrected as MI355X_MICROARCH.md prescribes (KiB -> bytes, x2 on gfx950); null if none matches.
-        try:
-            with open(os.path.join(ROOT, "profiles", "pmc_latest.json")) as f:
-                pmc = json.load(f)
-            for e in pmc.get("entries", [pmc]):
-                if (e.get("workload") == args.workload and e.get("params") == args.params
-                        and e.get("reads") == int(reads.n) and not args.early_exit and args.kmer_frac == 1.0):
-                    result["roofline"]["traffic"] = e["vote_kernel_traffic_bytes"]
-                    result["roofline"]["traffic_source"] = e["source"]
-        except (OSError, ValueError, KeyError):
-            pass
+        # HBM-side traffic of the vote kernel, measured NOW: PMC counters cannot be read in-process, so a child
+        # runs the same workload's vote kernel under `rocprofv3 --pmc FETCH_SIZE` (its own pass, no tracing) and the
+        # per-dispatch values are corrected as MI355X_MICROARCH.md prescribes (KiB -> bytes, x2 on gfx950 for wide
+        # streaming reads).  If the profiler cannot run here the committed pass of the same workload is quoted,
+        # and traffic_source says so.
+        if world == 1 and not args.no_pmc and not args.early_exit:
+            live = live_pmc_traffic(args, log)
+            if live:
+                result["roofline"].update(live)
+        if result["roofline"]["traffic"] is None:
+            try:
+                with open(os.path.join(ROOT, "profiles", "pmc_latest.json")) as f:
+                    pmc = json.load(f)
+                for e in pmc.get("entries", [pmc]):
+                    if (e.get("workload") == args.workload and e.get("params") == args.params
+                            and e.get("reads") == int(n_mine) and not args.early_exit and args.kmer_frac == 1.0
+                            and not args.total_bp):
+                        result["roofline"]["traffic"] = e["vote_kernel_traffic_bytes"]
+                        result["roofline"]["traffic_source"] = "NOT measured in this run; committed pass " + e["source"]
+            except (OSError, ValueError, KeyError):
+                pass
 
         # ---------------- CPU baseline (oracle = port of the reference algorithm, 1 thread) + parity sample
         if args.cpu_sample > 0 and world == 1:               # the CPU baseline is an N=1 leg only

@@ -166,6 +166,35 @@ def windows_for_reads(offsets, read_len: int, n_seg: int = 5):
     return (np.array(ws, np.uint64), np.array(wl, np.uint32), np.array(rid, np.uint32), np.array(sir, np.uint32))
 
 
+class PinnedArray:
+    """A uint8 numpy array in page-locked host memory (bmf_pinned_alloc): `.array` is valid until close()."""
+
+    def __init__(self, n: int):
+        self._p = C.c_void_p()
+        _check(lib().bmf_pinned_alloc(max(1, n), C.byref(self._p)))
+        self.array = np.ctypeslib.as_array(C.cast(self._p, _u8p), shape=(n,))
+
+    def close(self) -> None:
+        if self._p:
+            self.array = None
+            lib().bmf_pinned_free(self._p)
+            self._p = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def pinned_copy(a) -> PinnedArray:
+    """Copy of a byte array in page-locked memory: the source bmf_map_windows can overlap with its kernels."""
+    a = np.ascontiguousarray(a, dtype=np.uint8)
+    out = PinnedArray(a.size)
+    out.array[:] = a
+    return out
+
+
 class Batch:
     """Device-resident batch of windows (bmf_batch)."""
 

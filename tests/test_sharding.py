@@ -65,6 +65,59 @@ def test_two_rank_sharding_matches_single_process(tmp_path):
     assert n == 5 * 90 and nonempty > 200
 
 
+def _locator_worker(rank, world, port, out_path):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "bucket-map_amd", "python"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch.distributed as dist
+    from bucket_map_amd import shard
+    from oracle import oracle_c as oc
+    from test_locator import make_case
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    # every rank holds the genome and all sampled k-mers (replicated) and scans ITS contiguous range of the candidates,
+    # which arrive grouped by bucket: a bucket whose run straddles the cut is scanned by both ranks
+    case = make_case(np.random.default_rng(5), n_buckets=7, bucket_len=2048, read_len=150, n_reads=150)
+    n = len(case["pb"])
+    lo, hi = shard.shard_range(n, rank, world)
+    off, votes = oc.locate(case["k"], case["p"], 4, 6, case["genome"], case["bstart"], case["blen"], case["sh"], case["sp"],
+                           case["sl"], case["pb"][lo:hi], case["pw"][lo:hi], case["pr"][lo:hi])
+    # the verifier's split: alignments of the located candidates, cut by summed cell count
+    keep = np.nonzero(off > 0)[0]
+    ts = (case["bstart"][case["pb"][lo:hi][keep]] + off[keep].astype(np.uint64)).astype(np.uint64)
+    tl = np.full(len(keep), 150 + 1 + 3, np.uint32)
+    reads = np.concatenate([case["genome"][int(s):int(s) + 150] for s in ts]) if len(keep) else np.zeros(0, np.uint8)
+    qs = (np.arange(len(keep)) * 150).astype(np.uint64)
+    ql = np.full(len(keep), 150, np.uint32)
+    sc, bg, co, cg = oc.align_batch(case["genome"], reads, ts, tl, np.zeros(len(keep), np.uint8), qs, ql)
+    gathered = [None] * world if rank == 0 else None
+    dist.gather_object((off, votes, sc, bg), gathered, dst=0)
+    if rank == 0:
+        off_all = np.concatenate([g[0] for g in gathered])
+        votes_all = np.concatenate([g[1] for g in gathered])
+        o1, v1 = oc.locate(case["k"], case["p"], 4, 6, case["genome"], case["bstart"], case["blen"], case["sh"], case["sp"],
+                           case["sl"], case["pb"], case["pw"], case["pr"])
+        ok = np.array_equal(off_all, o1) and np.array_equal(votes_all, v1)
+        straddles = int(case["pb"][shard.shard_range(n, 1, world)[0] - 1] == case["pb"][shard.shard_range(n, 1, world)[0]])
+        perfect = all((g[2] == 0).all() and (g[3] == 0).all() for g in gathered)   # a read cut from the text aligns at 0, score 0
+        with open(out_path, "w") as f:
+            f.write(f"{int(ok)} {straddles} {int((o1 > 0).sum())} {int(perfect)}")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_locator_scan_matches_single_process(tmp_path):
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "result.txt")
+    mp.spawn(_locator_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    ok, straddles, located, perfect = (int(x) for x in open(out).read().split())
+    assert ok == 1, "candidate ranges scanned by two ranks differ from the single-process scan"
+    assert straddles == 1, "the cut was meant to fall inside one bucket's run of candidates"
+    assert located > 100 and perfect == 1
+
+
 def test_shard_ranges_partition():
     sys.path.insert(0, os.path.join(ROOT, "bucket-map_amd", "python"))
     from bucket_map_amd import shard
