@@ -330,12 +330,14 @@ def main():
     # compacted D2H of the results; the batch goes through in pieces so that the copies of one piece run under
     # the kernels of its neighbours).  From page-locked buffers, as the `bucketmap` tool stages its reads, and
     # from ordinary pageable memory.  Reported for DESIGN.md only; it is never `value`.
+    out_arrays = (np.zeros((len(win_start), 2), np.uint32), np.zeros((len(win_start), 2, params.max_candidates), np.uint32))
+
     def time_map_windows(f, b, q):
-        f.map_windows(b, q, win_start, win_len)          # first call allocates
+        f.map_windows(b, q, win_start, win_len, out=out_arrays)          # first call allocates
         best = 1e9
         for _ in range(3):
             t_h = time.perf_counter()
-            f.map_windows(b, q, win_start, win_len)
+            f.map_windows(b, q, win_start, win_len, out=out_arrays)
             best = min(best, time.perf_counter() - t_h)
         return best
     pinned_b, pinned_q = bma.pinned_copy(reads.bases), bma.pinned_copy(reads.quals)

@@ -543,8 +543,8 @@ static int upload_finish(bmf_ctx *c) {
     if (n_rows) {
         hipLaunchKernelGGL(bmf::bmf_sanitize_rows_kernel, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, c->stream,
                            c->d_rows, n_rows, pitch, c->p.num_buckets);
-        hipLaunchKernelGGL(bmf::bmf_zeros_kernel, dim3((unsigned)n_rows), dim3(bmf::kWave), 0, c->stream, c->d_rows,
-                           n_rows, pitch, c->p.num_buckets, c->d_zeros);
+        hipLaunchKernelGGL(bmf::bmf_zeros_kernel, dim3((unsigned)std::min<uint64_t>(n_rows, 1u << 22)), dim3(bmf::kWave), 0,
+                           c->stream, c->d_rows, n_rows, pitch, c->p.num_buckets, c->d_zeros);
     }
     hipLaunchKernelGGL(bmf::bmf_qgram_ok_kernel, dim3((unsigned)((n_words + 255) / 256)), dim3(256), 0, c->stream,
                        c->d_k2i, n_kmers, c->d_zeros, c->p.threshold, c->d_qgram_ok, n_words);
@@ -606,11 +606,13 @@ int bmf_build_index(bmf_ctx *c, const uint8_t *genome, uint64_t n_bases, const u
     HIP_TRY(hipSetDevice(c->p.device));
     const uint32_t pitch = c->dp.pitch;
     const uint64_t n_words = ((1ull << (2 * q)) + 31) / 32;
-    // launch geometry of the transpose: one wave per (64 buckets, 64 q-grams), 16 waves per workgroup
-    const uint64_t n_tr_waves = (uint64_t)((n_buckets + 63u) / 64u) * (n_words / 2);
-    const uint64_t n_tr_blocks = (n_tr_waves * 64 + bmi::kThreads - 1) / bmi::kThreads;
-    if (n_tr_blocks > 0x7FFFFFFFull || n_buckets > 0x7FFFFFFFu)
-        return fail(BMF_ERR_UNSUPPORTED, "the GPU index build cannot cover %u buckets at q = %u in one launch", n_buckets, q);
+    // Launch geometries.  A HIP grid dimension times its block dimension is a 32-bit thread count (larger grids
+    // wrap silently and run a fraction of their workgroups), so the presence kernel goes out in slices of 2 Mi
+    // buckets and the transpose walks the bucket groups with a strided y dimension.
+    const uint32_t n_groups = (n_buckets + 63u) / 64u;
+    const uint32_t tr_blocks_x = (uint32_t)((n_words / 2 + bmi::kThreads / 64 - 1) / (bmi::kThreads / 64));
+    const uint32_t tr_blocks_y = std::max(1u, std::min(n_groups, 32768u));
+    constexpr uint32_t kPresenceSlice = 1u << 21;
     uint8_t *d_genome = nullptr, *d_lut = c->d_lut;
     uint64_t *d_bstart = nullptr;
     uint32_t *d_blen = nullptr, *d_presence = nullptr;
@@ -637,9 +639,10 @@ int bmf_build_index(bmf_ctx *c, const uint8_t *genome, uint64_t n_bases, const u
         ok(hipFuncSetAttribute(reinterpret_cast<const void *>(bmi::bmi_presence_kernel),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     if (e == hipSuccess && n_buckets) {
-        hipLaunchKernelGGL(bmi::bmi_presence_kernel, dim3(n_buckets), dim3(bmi::kThreads), lds, c->stream, d_genome, d_bstart,
-                           d_blen, d_lut, q, d_presence);
-        hipLaunchKernelGGL(bmi::bmi_transpose_kernel, dim3((unsigned)n_tr_blocks), dim3(bmi::kThreads), 0, c->stream, reinterpret_cast<const uint64_t *>(d_presence), n_buckets, q,
+        for (uint32_t b0 = 0; b0 < n_buckets; b0 += kPresenceSlice)
+            hipLaunchKernelGGL(bmi::bmi_presence_kernel, dim3(std::min(kPresenceSlice, n_buckets - b0)), dim3(bmi::kThreads), lds,
+                               c->stream, d_genome, d_bstart + b0, d_blen + b0, d_lut, q, d_presence + (size_t)b0 * n_words);
+        hipLaunchKernelGGL(bmi::bmi_transpose_kernel, dim3(tr_blocks_x, tr_blocks_y), dim3(bmi::kThreads), 0, c->stream, reinterpret_cast<const uint64_t *>(d_presence), n_buckets, q,
                            c->d_k2i, c->d_rows, pitch);
         ok(hipGetLastError());
     }
@@ -648,8 +651,8 @@ int bmf_build_index(bmf_ctx *c, const uint8_t *genome, uint64_t n_bases, const u
     c->dp.n_kmers = (uint32_t)n_kmers;
     if (e == hipSuccess) {
         if (n_rows)
-            hipLaunchKernelGGL(bmf::bmf_zeros_kernel, dim3((unsigned)n_rows), dim3(bmf::kWave), 0, c->stream, c->d_rows,
-                               (uint64_t)n_rows, pitch, c->p.num_buckets, c->d_zeros);
+            hipLaunchKernelGGL(bmf::bmf_zeros_kernel, dim3((unsigned)std::min<int64_t>(n_rows, 1 << 22)), dim3(bmf::kWave), 0,
+                               c->stream, c->d_rows, (uint64_t)n_rows, pitch, c->p.num_buckets, c->d_zeros);
         hipLaunchKernelGGL(bmf::bmf_qgram_ok_kernel, dim3((unsigned)((n_words + 255) / 256)), dim3(256), 0, c->stream,
                            c->d_k2i, n_kmers, c->d_zeros, c->p.threshold, c->d_qgram_ok, n_words);
         ok(hipGetLastError());
@@ -797,7 +800,8 @@ void bmf_batch_destroy(bmf_ctx *c, bmf_batch *b) {
 static int check_windows(const bmf_ctx *c, const uint8_t *bases, const uint8_t *quals, uint64_t n_bytes,
                          const uint64_t *win_start, const uint32_t *win_len, uint32_t n_windows) {
     if (n_windows && (!win_start || !win_len)) return fail(BMF_ERR_ARG, "win_start/win_len is null");
-    if (n_windows > 0x3FFFFFFFu) return fail(BMF_ERR_ARG, "too many windows");
+    // one wave per (window, orientation): 2 * n * 64 threads must stay below 2^32 (HIP's grid limit)
+    if (n_windows >= (1u << 25)) return fail(BMF_ERR_ARG, "too many windows in one batch (%u, limit %u)", n_windows, (1u << 25) - 1u);
     if (n_bytes && (!bases || !quals)) return fail(BMF_ERR_ARG, "bases/quals is null");
     for (uint32_t w = 0; w < n_windows; w++) {
         if (win_len[w] > c->p.read_len)

@@ -102,13 +102,13 @@ __global__ void bmf_sanitize_rows_kernel(uint8_t *rows, uint64_t n_rows, uint32_
 // One wave per row, coalesced dword reads.
 __global__ __launch_bounds__(kWave) void bmf_zeros_kernel(const uint8_t *rows, uint64_t n_rows, uint32_t pitch,
                                                          uint32_t nb, uint32_t *zeros) {
-    uint64_t r = blockIdx.x;
-    if (r >= n_rows) return;
-    const uint32_t *row = reinterpret_cast<const uint32_t *>(rows + r * pitch);
-    uint32_t n_dw = pitch >> 2, ones = 0;
-    for (uint32_t i = threadIdx.x; i < n_dw; i += kWave) ones += __popc(row[i]);
-    ones = wave_sum(ones);
-    if (threadIdx.x == 0) zeros[r] = nb - ones;   // ones == 0 -> NB, as the reference's special case
+    for (uint64_t r = blockIdx.x; r < n_rows; r += gridDim.x) {
+        const uint32_t *row = reinterpret_cast<const uint32_t *>(rows + r * pitch);
+        uint32_t n_dw = pitch >> 2, ones = 0;
+        for (uint32_t i = threadIdx.x; i < n_dw; i += kWave) ones += __popc(row[i]);
+        ones = wave_sum(ones);
+        if (threadIdx.x == 0) zeros[r] = nb - ones;   // ones == 0 -> NB, as the reference's special case
+    }
 }
 
 // Bitmap over all 4^q q-grams: bit g set iff the q-gram is indexed and its row has

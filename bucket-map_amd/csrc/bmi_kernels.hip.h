@@ -55,26 +55,28 @@ __global__ __launch_bounds__(kThreads) void bmi_presence_kernel(const uint8_t *_
 }
 
 // One wave per (group of 64 buckets, 64 consecutive q-grams).  presence is read as u64 words.
+// Grid: x = 16-wave workgroups over the q-gram words of one group, y = groups of 64 buckets (strided: a HIP grid
+// dimension times its block dimension must stay below 2^32 threads, and y below 65 536 workgroups).
 __global__ __launch_bounds__(kThreads) void bmi_transpose_kernel(const uint64_t *__restrict__ presence, uint32_t n_buckets,
                                                                 uint32_t q, const int32_t *__restrict__ k2i,
                                                                 uint8_t *__restrict__ rows, uint32_t pitch) {
     const uint32_t n_w64 = (1u << (2 * q)) >> 6;           // 64-bit words per bucket
-    // 64-bit: (groups of 64 buckets) x (q-gram words) passes 2^32 / 64 waves from ~1 M buckets on at q = 9
-    const uint64_t wave = (uint64_t)blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6);
+    const uint32_t w64 = blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6);
     const uint32_t lane = threadIdx.x & 63u;
-    const uint64_t n_groups = (n_buckets + 63u) / 64u;
-    if (wave >= n_groups * n_w64) return;
-    const uint32_t group = (uint32_t)(wave / n_w64), w64 = (uint32_t)(wave % n_w64);  // consecutive waves walk the q-gram words of one group
-    const uint32_t b = group * 64u + lane;
-    const uint64_t v = b < n_buckets ? presence[(size_t)b * n_w64 + w64] : 0ull;
-    uint64_t mine = 0;
-#pragma unroll 8
-    for (uint32_t t = 0; t < 64; t++) {
-        const uint64_t m = __ballot((v >> t) & 1ull);      // bit i = bucket group*64+i holds q-gram w64*64+t
-        if (lane == t) mine = m;
-    }
+    const uint32_t n_groups = (n_buckets + 63u) / 64u;
+    if (w64 >= n_w64) return;
     const int32_t row = k2i[w64 * 64u + lane];             // FracMinHash: -1 = q-gram not kept
-    if (row >= 0) *reinterpret_cast<uint64_t *>(rows + (size_t)row * pitch + (size_t)group * 8u) = mine;
+    for (uint32_t group = blockIdx.y; group < n_groups; group += gridDim.y) {
+        const uint32_t b = group * 64u + lane;
+        const uint64_t v = b < n_buckets ? presence[(size_t)b * n_w64 + w64] : 0ull;
+        uint64_t mine = 0;
+#pragma unroll 8
+        for (uint32_t t = 0; t < 64; t++) {
+            const uint64_t m = __ballot((v >> t) & 1ull);  // bit i = bucket group*64+i holds q-gram w64*64+t
+            if (lane == t) mine = m;
+        }
+        if (row >= 0) *reinterpret_cast<uint64_t *>(rows + (size_t)row * pitch + (size_t)group * 8u) = mine;
+    }
 }
 
 }  // namespace bmi

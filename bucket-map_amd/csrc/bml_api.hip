@@ -162,6 +162,7 @@ int bml_sample_windows(bml_ctx *c, const uint8_t *bases, const uint8_t *quals, u
     if (n_windows == 0) return BML_OK;
     if (!win_start || !win_len || !out_hash || !out_pos || !out_has || (n_bytes && (!bases || !quals)))
         return fail(BML_ERR_ARG, "bml_sample_windows: null argument");
+    if (n_windows >= (1u << 26)) return fail(BML_ERR_UNSUPPORTED, "too many windows in one call (%u)", n_windows);   // 64 threads each, < 2^32
     uint32_t max_len = 1;
     for (uint32_t w = 0; w < n_windows; w++) {
         if (win_start[w] > n_bytes || win_len[w] > n_bytes - win_start[w])
@@ -263,6 +264,7 @@ int bml_locate(bml_ctx *c, const uint32_t *sample_hash, const uint16_t *sample_p
             chunks.push_back(bml::Chunk{b, s, (j - s < c->max_pairs_per_chunk) ? j - s : c->max_pairs_per_chunk});
         i = j;
     }
+    if (chunks.size() >= (1u << 22)) return fail(BML_ERR_UNSUPPORTED, "too many candidate chunks in one call (%zu)", chunks.size());   // 1 024 threads each, < 2^32
     for (uint32_t i = 0; i < n_pairs; i++) {
         if (pair_window[i] >= n_windows) return fail(BML_ERR_ARG, "candidate %u names window %u of %u", i, pair_window[i], n_windows);
         // :242 `length - k - index` must not wrap for reverse-complement candidates

@@ -238,6 +238,7 @@ int bmv_align(bmv_ctx *c, const uint8_t *reads, uint64_t n_read_bytes, const uin
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(sh.fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const uint64_t per_slot = trace_stride / gpw * 8u + (uint64_t)ops_stride * 4u;
     uint64_t chunk = std::max<uint64_t>(gpw, c->scratch_bytes / per_slot);
+    chunk = std::min<uint64_t>(chunk, (uint64_t)gpw << 25);   // one wave per gpw alignments: waves * 64 threads < 2^32
     chunk = std::min<uint64_t>(chunk / gpw * gpw, (uint64_t)n);
     if (chunk == 0) chunk = n;
     // Grow these with headroom: the longest read differs a little from call to call, and reallocating tens of

@@ -98,8 +98,10 @@ public:
             s.ok = false;
             try {
                 const uint32_t n = static_cast<uint32_t>(s.win_start.size());
-                s.counts.assign(2 * static_cast<size_t>(n), 0);
-                s.buckets.assign(2 * static_cast<size_t>(n) * max_candidates_, 0);
+                // only entries below a list's count are ever read back: no need to clear 240 bytes per window per batch
+                s.counts.resize(2 * static_cast<size_t>(n));
+                s.buckets.resize(2 * static_cast<size_t>(n) * max_candidates_);
+                if (!index_loaded()) std::fill(s.counts.begin(), s.counts.end(), 0u);
                 s.ok = true;
                 if (n == 0) return;
                 if (!index_loaded()) {

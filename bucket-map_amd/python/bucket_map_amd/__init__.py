@@ -307,8 +307,9 @@ class Filter:
         _check(lib().bmf_index_zeros(self._h, _ptr(out, _u32p)))
         return out
 
-    def map_windows(self, bases, quals, win_start, win_len):
-        """query_sequence for every window; returns (counts[n,2], buckets[n,2,max_candidates])."""
+    def map_windows(self, bases, quals, win_start, win_len, out=None):
+        """query_sequence for every window; returns (counts[n,2], buckets[n,2,max_candidates]).  `out` = a pair of
+        arrays of those shapes to write into (entries past a list's count are left as they are)."""
         bases = np.ascontiguousarray(bases, dtype=np.uint8)
         quals = np.ascontiguousarray(quals, dtype=np.uint8)
         win_start = np.ascontiguousarray(win_start, dtype=np.uint64)
@@ -316,8 +317,13 @@ class Filter:
         n = len(win_start)
         assert len(win_len) == n and len(quals) == len(bases)
         mc = self.params.max_candidates
-        counts = np.zeros((n, 2), dtype=np.uint32)
-        buckets = np.zeros((n, 2, mc), dtype=np.uint32)
+        if out is None:
+            counts = np.zeros((n, 2), dtype=np.uint32)
+            buckets = np.zeros((n, 2, mc), dtype=np.uint32)
+        else:
+            counts, buckets = out
+            assert counts.shape == (n, 2) and buckets.shape == (n, 2, mc) and counts.dtype == buckets.dtype == np.uint32
+            assert counts.flags.c_contiguous and buckets.flags.c_contiguous
         _check(lib().bmf_map_windows(self._h, _ptr(bases, _u8p), _ptr(quals, _u8p), len(bases),
                                      _ptr(win_start, _u64p), _ptr(win_len, _u32p), n,
                                      _ptr(counts, _u32p), _ptr(buckets, _u32p)))

@@ -72,6 +72,21 @@ class Case:
         return f
 
 
+def oracle_map_windows(ix, bases, quals, win_start, win_len, threads=None):
+    """ix.map_windows over `threads` host threads (the oracle is re-entrant, ctypes releases the GIL): the way the
+    CPU restatement reaches 100 k-read samples inside a GPU test.  Returns (counts, buckets, rows ANDed)."""
+    from concurrent.futures import ThreadPoolExecutor
+    n = len(win_start)
+    threads = threads or max(1, min(len(os.sched_getaffinity(0)), 32))
+    if n < 4 * threads:
+        return ix.map_windows(bases, quals, win_start, win_len)
+    cuts = [n * t // threads for t in range(threads + 1)]
+    with ThreadPoolExecutor(threads) as pool:
+        parts = list(pool.map(lambda t: ix.map_windows(bases, quals, win_start[cuts[t]:cuts[t + 1]], win_len[cuts[t]:cuts[t + 1]]),
+                              range(threads)))
+    return (np.concatenate([p[0] for p in parts]), np.concatenate([p[1] for p in parts]), sum(int(p[2]) for p in parts))
+
+
 def assert_same_candidates(c_ref, b_ref, c_got, b_got, what=""):
     """Bit-exact comparison of candidate lists: counts, then ids (values AND order)."""
     c_ref, c_got = np.asarray(c_ref), np.asarray(c_got)

@@ -9,7 +9,7 @@ import subprocess
 import numpy as np
 import pytest
 
-from conftest import Case, assert_same_candidates
+from conftest import Case, assert_same_candidates, oracle_map_windows
 
 pytestmark = pytest.mark.gpu
 
@@ -130,12 +130,19 @@ def test_full_size_properties():
     fb.close()
     ws, wl, _, _ = bma.windows_for_reads(reads.offsets, 300)
     c, b = flt.map_windows(reads.bases, reads.quals, ws, wl)
-    # (a) parity with the oracle on a sample
-    n = 1500
+    # (a) parity with the oracle on 100 000 reads (SURVEY 7 step 4's gate; the CPU restatement on all host cores)
+    n = 100_000
     ora = oracle_c.Index(oracle_c.params_from_cli(nb, **cli), rows_ptr=index.rows_ptr, n_rows=index.num_rows,
                          k2i_ptr=index.k2i_ptr, n_kmers=index.num_kmers)
-    c_ref, b_ref, _ = ora.map_windows(reads.bases, reads.quals, ws[:n], wl[:n])
+    c_ref, b_ref, _ = oracle_map_windows(ora, reads.bases, reads.quals, ws[:n], wl[:n])
     assert_same_candidates(c_ref, b_ref, c[:n], b[:n], "full-size sample")
+    # ... the same 100 000 through the pruning kernels the tools use by default
+    fp = bma.Filter(bma.Params.from_cli(nb, flags=bma.BMF_FLAG_EARLY_EXIT, **cli))
+    fp.load_index_ptr(index.rows_ptr, index.num_rows, index.k2i_ptr, index.num_kmers)
+    assert fp.info()["pass1_rows"] >= 1
+    c_p, b_p = fp.map_windows(reads.bases, reads.quals, ws[:n], wl[:n])
+    assert_same_candidates(c_ref, b_ref, c_p, b_p, "full-size sample, two-pass pruning")
+    fp.close()
     # (b) reads recover their source bucket on their strand, as the reference's logs report (95-99 %)
     s = reads.truth_rc.astype(np.int64)
     i = np.arange(reads.n)

@@ -1,0 +1,226 @@
+"""BASELINE.json's configurations at their TRUE geometry, on the GPU (configs[1] lives in test_cli_gpu.py):
+
+  configs[0]  E. coli-sized: one 4 641 652-bp record, bucket_len 65 536, NB = 71, 10 000 x 150 bp -- every read
+              GPU == oracle, and the `bucketmap` tool == the oracle-backed tool;
+  configs[3]  GRCh38-like: 3.1 Gbp in 24 records with the chromosomes' length ratios, bucket_len 65 536 (NB ~ 47 k),
+              full `-f 1` index built on the device, 100 000 x 150 bp reads, all of them against the oracle, with the
+              default, the pruned and the forced two-pass kernels, plus size-independent properties;
+  configs[4]  the same genome at bucket_len 262 144 with the reference's long-read flags
+              (benchmark/long_read/benchmark_map.sh:25: -s 30 -e 0.9 -n 0.1 -l 12 -p 20 -u 5), 10-kbp ONT-profile reads
+              through `bucketmap_align`: == the oracle-backed tool on a handful (the CPU verifier fills a 440 MB matrix per
+              alignment), properties and the --gpus split on 1 500.
+
+Synthetic data as SURVEY.md 8d prescribes (real genomes are not available offline).
+"""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import assert_same_candidates, oracle_map_windows
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+sys.path.insert(0, ROOT)
+TOOL = {"gpu": os.path.join(ROOT, "bucket-map_amd", "bucketmap"), "oracle": os.path.join(ROOT, "tests", "cpp", "bucketmap_oracle"),
+        "gpu_align": os.path.join(ROOT, "bucket-map_amd", "bucketmap_align"),
+        "oracle_align": os.path.join(ROOT, "tests", "cpp", "bucketmap_align_oracle")}
+
+
+def run(exe, args, cwd, env=None):
+    r = subprocess.run([TOOL[exe], *args], cwd=str(cwd), capture_output=True, text=True,
+                       env=None if env is None else {**os.environ, **env})
+    assert r.returncode == 0, r.stderr[-2000:]
+    return r.stderr
+
+
+def three_kernels(nb, cli, load):
+    """The filter three ways: as the reference reads its rows, with exact pruning as the library picks it, and with
+    the two-pass pruning kernels forced."""
+    import bucket_map_amd as bma
+    out = []
+    for flags, env in ((0, None), (bma.BMF_FLAG_EARLY_EXIT, None), (bma.BMF_FLAG_EARLY_EXIT, "1")):
+        if env is not None:
+            os.environ["BMF_PASS1_ROWS"] = env
+        try:
+            f = bma.Filter(bma.Params.from_cli(nb, flags=flags, **cli))
+            load(f)
+        finally:
+            os.environ.pop("BMF_PASS1_ROWS", None)
+        out.append(f)
+    assert out[2].info()["pass1_rows"] == 1
+    return out
+
+
+# ---------------------------------------------------------------------------------------------- configs[0]
+
+def test_config0_ecoli_true_size(tmp_path):
+    import bucket_map_amd as bma
+    from bucket_map_amd import host
+    from oracle import oracle_c
+    genome = host.Genome.synth(20240001, [4_641_652])
+    nb = genome.awk_bucket_num(65536)
+    assert nb == 71
+    index = host.Index(genome, nb, 65536, 150, q=9)
+    cli = dict(read_len=150)
+    ora = oracle_c.Index(oracle_c.params_from_cli(nb, **cli), rows_ptr=index.rows_ptr, n_rows=index.num_rows,
+                         k2i_ptr=index.k2i_ptr, n_kmers=index.num_kmers)
+    filters = three_kernels(nb, cli, lambda f: f.load_index_ptr(index.rows_ptr, index.num_rows, index.k2i_ptr, index.num_kmers))
+    # the config's 10 000 reads, then SURVEY 7 step 4's 100 000 at NB = 71 (another seed, noisy qualities)
+    for n_reads, seed, noisy in ((10_000, 20240003, False), (100_000, 20240005, True)):
+        reads = host.Reads(genome, 65536, 150, 150, n_reads, seed=seed, noisy_quals=noisy)
+        ws, wl, _, _ = bma.windows_for_reads(reads.offsets, 150)
+        c_ref, b_ref, _ = oracle_map_windows(ora, reads.bases, reads.quals, ws, wl)
+        for f, what in zip(filters, ("default", "pruned", "two-pass")):
+            c, b = f.map_windows(reads.bases, reads.quals, ws, wl)
+            assert_same_candidates(c_ref, b_ref, c, b, f"NB=71, {n_reads} reads, {what}")
+        if not noisy:
+            s = reads.truth_rc.astype(np.int64)
+            i = np.arange(reads.n)
+            own, valid = b_ref[i, s], np.arange(b_ref.shape[2])[None, :] < c_ref[i, s][:, None]
+            assert ((own == reads.truth_bucket[:, None]) & valid).any(axis=1).mean() > 0.97
+    for f in filters:
+        f.close()
+    # the tool: GPU build == oracle-backed build, byte for byte, on the config's 10 000 reads
+    genome.write_fasta(str(tmp_path / "ecoli.fa"))
+    host.Reads(genome, 65536, 150, 150, 10_000, seed=20240003).write_fastq(str(tmp_path / "reads"))
+    common = ["-i", "ecoli", "--genome", "ecoli.fa", "-r", "150", "-f", "1", "-q", "reads.fastq"]
+    err = run("gpu", [*common, "-o", "gpu.sam"], tmp_path)
+    assert "number of buckets: 71." in err
+    run("oracle", [*common, "-o", "cpu.sam"], tmp_path)
+    sam = (tmp_path / "gpu.sam").read_bytes()
+    assert sam == (tmp_path / "cpu.sam").read_bytes()
+    assert sam.count(b"\n") > 9_500
+
+
+# ------------------------------------------------------------------------------------- configs[3] and [4]
+
+@pytest.fixture(scope="module")
+def grch38_like():
+    """3.1 Gbp, 24 records with the human chromosomes' length ratios (bench.py's `grch38` workload)."""
+    import bench
+    from bucket_map_amd import host
+    return host.Genome.synth(20240001, bench.workload_record_lengths("grch38", 3_100_000_000), 16)
+
+
+def test_config3_grch38_like_full_index(grch38_like):
+    import bucket_map_amd as bma
+    from bucket_map_amd import host
+    from oracle import oracle_c
+    genome = grch38_like
+    nb = genome.awk_bucket_num(65536)
+    assert 47_000 < nb < 47_700
+    cli = dict(read_len=150)
+    k2i = host.select_qgrams(9)
+    flat, _ = genome.flat()
+    bstart, blen = genome.bucket_views(65536, 150)
+    filters = three_kernels(nb, cli, lambda f: f.build_index(flat, bstart, blen, k2i))
+    del flat
+    rows = filters[0].index_download()                                   # 262 144 x 5 9xx bytes
+    assert rows.shape == (4 ** 9, (nb + 7) >> 3)
+    # the device-built rows are the host indexer's on a sample of buckets (the full-size byte comparison is
+    # test_cli_gpu.py's, on the 1.7 Gbp genome): bit b of row g == bucket b holds q-gram g
+    rng = np.random.default_rng(9)
+    for b in rng.integers(0, len(bstart), 6):
+        rec = genome.cut_buckets(65536, 150)[b]
+        seq = genome.record_seq(int(rec[0]))[int(rec[2]):int(rec[3])]
+        codes = np.zeros(256, np.uint32)
+        codes[list(b"ACGT")] = np.arange(4)
+        r = codes[seq]
+        h = np.zeros(len(r) - 8, np.uint32)
+        for t in range(9):
+            h = h * 4 + r[t:t + len(h)]
+        present = np.zeros(4 ** 9, bool)
+        present[h] = True
+        assert np.array_equal(((rows[:, b >> 3] >> (b & 7)) & 1).astype(bool), present), f"bucket {b}"
+    reads = host.Reads(genome, 65536, 150, 150, 100_000, seed=20240003, threads=16)
+    ws, wl, _, _ = bma.windows_for_reads(reads.offsets, 150)
+    ora = oracle_c.Index(oracle_c.params_from_cli(nb, **cli), rows, k2i)
+    c_ref, b_ref, rows_ref = oracle_map_windows(ora, reads.bases, reads.quals, ws, wl)
+    results = []
+    for f, what in zip(filters, ("default", "pruned", "two-pass")):
+        c, b = f.map_windows(reads.bases, reads.quals, ws, wl)
+        assert_same_candidates(c_ref, b_ref, c, b, f"GRCh38-like, 100 000 reads, {what}")
+        results.append((c, b))
+    batch = filters[0].batch(reads.bases, reads.quals, ws, wl)
+    batch.run()
+    assert batch.rows_anded() == rows_ref                                # the unit of the algorithmic-bytes figure
+    batch.close()
+    c, b = results[0]
+    s = reads.truth_rc.astype(np.int64)
+    i = np.arange(reads.n)
+    own, valid = b[i, s], np.arange(b.shape[2])[None, :] < c[i, s][:, None]
+    assert ((own == reads.truth_bucket[:, None]) & valid).any(axis=1).mean() > 0.97
+    for o in (0, 1):                                                     # ascending, in range
+        lst = b[:, o, :].astype(np.int64)
+        m = np.arange(lst.shape[1])[None, :] < c[:, o][:, None]
+        assert (lst[m] < nb).all() and ((np.diff(lst, axis=1) > 0) | ~m[:, 1:]).all()
+    perm = np.random.default_rng(4).permutation(len(ws))                 # permutation invariance, pruned kernels
+    cp, bp = filters[1].map_windows(reads.bases, reads.quals, ws[perm], wl[perm])
+    assert_same_candidates(c[perm], b[perm], cp, bp, "permutation")
+    for f in filters:
+        f.close()
+
+
+def parse_sam(path):
+    recs = []
+    for line in open(path):
+        if not line.startswith("@"):
+            f = line.rstrip("\n").split("\t")
+            recs.append((f[0], int(f[1]), f[2], int(f[3]), int(f[4]), f[5], len(f[9])))
+    return recs
+
+
+def test_config4_long_reads_bucketmap_align(grch38_like, tmp_path):
+    from bucket_map_amd import host
+    genome = grch38_like
+    genome.write_fasta(str(tmp_path / "g.fa"))
+    flags = ["--genome", "g.fa", "--bucket-len", "262144", "-f", "1", "-s", "30", "-e", "0.9", "-n", "0.1", "-l", "12", "-p", "20",
+             "-u", "5", "--version-check", "0"]
+    err = run("gpu_align", ["-x", "-i", "idx", *flags], tmp_path)
+    nb = genome.awk_bucket_num(262144)
+    assert f"number of buckets: {nb}." in err and 11_700 < nb < 12_000
+    # ONT profile: sub 0.03, ins = del 0.025, 10 kbp
+    few = host.Reads(genome, 262144, 300, 10_000, 12, sub=0.03, ins=0.025, dele=0.025, seed=20240007)
+    few.write_fastq(str(tmp_path / "few"))
+    many = host.Reads(genome, 262144, 300, 10_000, 1_500, sub=0.03, ins=0.025, dele=0.025, seed=20240008, threads=16)
+    many.write_fastq(str(tmp_path / "many"))
+    # (i) identical to the oracle-backed tool (C oracles behind mapper, scanner and verifier), plain and align builds
+    run("gpu_align", ["-i", "idx", *flags, "-q", "few.fastq", "-o", "few_gpu.sam"], tmp_path)
+    run("oracle_align", ["-i", "idx", *flags, "-q", "few.fastq", "-o", "few_cpu.sam"], tmp_path)
+    few_sam = (tmp_path / "few_gpu.sam").read_bytes()
+    assert few_sam == (tmp_path / "few_cpu.sam").read_bytes()
+    assert len({r[0] for r in parse_sam(tmp_path / "few_gpu.sam")}) >= 10
+    run("gpu", ["-i", "idx", *flags, "-q", "few.fastq", "-o", "few_plain_gpu.sam"], tmp_path)
+    run("oracle", ["-i", "idx", *flags, "-q", "few.fastq", "-o", "few_plain_cpu.sam"], tmp_path)
+    assert (tmp_path / "few_plain_gpu.sam").read_bytes() == (tmp_path / "few_plain_cpu.sam").read_bytes()
+    # (ii) 1 500 reads: the three-context split (filter, scan and verifier sharded) writes the same file
+    err = run("gpu_align", ["-i", "idx", *flags, "-q", "many.fastq", "-o", "one.sam"], tmp_path)
+    assert "GPU alignment verification" in err
+    run("gpu_align", ["-i", "idx", *flags, "-q", "many.fastq", "-o", "three.sam", "--gpus", "0,0,0"], tmp_path)
+    assert (tmp_path / "one.sam").read_bytes() == (tmp_path / "three.sam").read_bytes()
+    recs = parse_sam(tmp_path / "one.sam")
+    truth = [l.split() for l in open(tmp_path / "many.position_ground_truth")]
+    by_read = {}
+    for qname, flag, rname, pos, mapq, cigar, seqlen in recs:
+        # CIGAR consumes the whole read (global in the query): M + I = read length
+        num, used = "", 0
+        for ch in cigar:
+            if ch.isdigit():
+                num += ch
+            else:
+                used += int(num) if ch in "MI" else 0
+                num = ""
+        assert used == seqlen
+        by_read.setdefault(int(qname), []).append((flag, rname, pos, mapq))
+    # (on the reverse strand the reference adds the begin position counted in the FLIPPED text window, :576, so
+    # such records sit up to the window's slack -- n * len = 1 000 bases -- away from the true start)
+    good = 0
+    for i, t in enumerate(truth):
+        ref, pos, rc = int(t[0]), int(t[1]), int(t[2])
+        good += any(rname == f"synth{ref + 1}" and abs(p - pos) <= 1500 and (flag == 16) == bool(rc)
+                    for flag, rname, p, _ in by_read.get(i, []))
+    assert good > 0.9 * len(truth), f"{good}/{len(truth)} long reads have a record at their true position"
