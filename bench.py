@@ -385,6 +385,7 @@ def main():
                   "pass1_rows": fp.info()["pass1_rows"]}
         if pruned["pass1_rows"]:
             pruned["items_recounted"], pruned["items_slow_path"] = bp.pass2_counts()
+            pruned["recount_column_loads"] = bp.recount_loads()
         bp.close()
         if world == 1:
             pruned["pcie_inclusive_ms_pinned"] = time_map_windows(fp, pinned_b.array, pinned_q.array) * 1e3

@@ -216,8 +216,9 @@ struct bmf_ctx {
     bool profiling = false;
     uint32_t prof_max = 0, prof_n = 0;
     std::vector<hipEvent_t> ev;      // 3 per run: before sample, between, after vote
-    // bmf_map_windows: a batch is cut into pieces; while piece i runs on `stream`, piece i+1 is uploaded on `h2d`
-    // and the results of piece i-1 come back on `d2h`.  Two slots of device + pinned staging buffers.
+    // bmf_map_windows: a batch is cut into pieces; while piece i runs on `stream`, the next pieces are uploaded on
+    // `h2d` and the results of the previous one come back on `d2h`.  Three slots of device + pinned staging
+    // buffers: two pieces are queued behind the one whose results the host is unpacking.
     struct MapSlot {
         bmf_batch dev;
         DevBuf<uint32_t> pack;           // [total | ids of all lists back to back]
@@ -230,7 +231,8 @@ struct bmf_ctx {
         uint32_t first = 0, n = 0;
         size_t ids_copied = 0;
     };
-    MapSlot *slot[2] = {nullptr, nullptr};
+    static constexpr int kMapSlots = 3;
+    MapSlot *slot[kMapSlots] = {nullptr, nullptr, nullptr};
     hipStream_t h2d = nullptr, d2h = nullptr;
     DevBuf<uint8_t> whole_bases, whole_quals;   // windows in no particular order: the read buffer is uploaded once
 };
@@ -834,7 +836,7 @@ static hipError_t batch_reserve(bmf_ctx *c, bmf_batch *b, size_t n, size_t n_byt
         ok(b->slice_ids.need(2 * n * c->n_slices * c->p.max_candidates));
     }
     if (c->dp.pass1_rows) {
-        ok(b->q_counters.need(2));
+        ok(b->q_counters.need(4));
         ok(b->q_slow.need(2 * n));
         ok(b->q_live_n.need(2 * n));
         ok(b->q_live_chunks.need(2 * n * bmf::kMaxLive));
@@ -890,11 +892,11 @@ static int launch_filter(bmf_ctx *c, bmf_batch *b, const uint8_t *d_bases, const
     if (c->dp.pass1_rows) {
         // two-pass pruning: full-width lower-bound pass, then the queued items' exact recount (bmf_vote2.hip.h)
         const size_t n_items = 2 * (size_t)b->n_windows;
-        HIP_TRY(b->q_counters.need(2));
+        HIP_TRY(b->q_counters.need(4));
         HIP_TRY(b->q_slow.need(n_items));
         HIP_TRY(b->q_live_n.need(n_items));
         HIP_TRY(b->q_live_chunks.need(n_items * bmf::kMaxLive));
-        HIP_TRY(hipMemsetAsync(b->q_counters.p, 0, 2 * sizeof(uint32_t), c->stream));
+        HIP_TRY(hipMemsetAsync(b->q_counters.p, 0, 4 * sizeof(uint32_t), c->stream));
         const bmf::Pass2Queue q{b->q_counters.p, b->q_slow.p, b->q_live_n.p, b->q_live_chunks.p};
         hipLaunchKernelGGL(c->two_pass.pass1, dim3(2 * b->n_windows), dim3(bmf::kWave), 0, c->stream, c->dp, c->d_rows,
                            b->lists.p, b->list_n.p, b->counts.p, q);
@@ -1156,12 +1158,13 @@ int bmf_map_windows(bmf_ctx *c, const uint8_t *bases, const uint8_t *quals, uint
         HIP_TRY(hipMemcpyAsync(c->whole_bases.p, bases, (size_t)n_bytes, hipMemcpyHostToDevice, c->h2d));
         HIP_TRY(hipMemcpyAsync(c->whole_quals.p, quals, (size_t)n_bytes, hipMemcpyHostToDevice, c->h2d));
     }
-    // issue piece p, then finish piece p-1: its slot is free again before piece p+1 needs it
-    for (uint32_t p = 0; p <= n_pieces && rc == BMF_OK; p++) {
+    // issue piece p, then finish piece p - (slots - 1): its slot is free again before piece p + 1 needs it
+    constexpr uint32_t kLag = bmf_ctx::kMapSlots - 1;
+    for (uint32_t p = 0; p < n_pieces + kLag && rc == BMF_OK; p++) {
         if (p < n_pieces)
-            rc = map_piece_issue(c, c->slot[p & 1], bases, quals, win_start, win_len, p * piece,
+            rc = map_piece_issue(c, c->slot[p % bmf_ctx::kMapSlots], bases, quals, win_start, win_len, p * piece,
                                  std::min(piece, n_windows - p * piece), whole);
-        if (rc == BMF_OK && p > 0) rc = map_piece_finish(c, c->slot[(p - 1) & 1], out_counts, out_buckets);
+        if (rc == BMF_OK && p >= kLag) rc = map_piece_finish(c, c->slot[(p - kLag) % bmf_ctx::kMapSlots], out_counts, out_buckets);
     }
     if (rc != BMF_OK) {   // leave nothing in flight that still reads the caller's buffers
         (void)hipStreamSynchronize(c->h2d);
@@ -1230,6 +1233,16 @@ int bmf_batch_pass2_counts(bmf_ctx *c, bmf_batch *b, uint32_t *recounted, uint32
     if (c->dp.pass1_rows && b->q_counters.p) HIP_TRY(hipMemcpy(v, b->q_counters.p, sizeof v, hipMemcpyDeviceToHost));
     if (recounted) *recounted = v[0];
     if (slow) *slow = v[1];
+    return BMF_OK;
+}
+
+int bmf_batch_recount_loads(bmf_ctx *c, bmf_batch *b, uint64_t *loads) {
+    if (!c || !b || !loads) return fail(BMF_ERR_ARG, "bmf_batch_recount_loads: null argument");
+    uint32_t v[4] = {0, 0, 0, 0};
+    HIP_TRY(hipSetDevice(c->p.device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->dp.pass1_rows && b->q_counters.p) HIP_TRY(hipMemcpy(v, b->q_counters.p, sizeof v, hipMemcpyDeviceToHost));
+    *loads = v[2];
     return BMF_OK;
 }
 

@@ -38,7 +38,8 @@ constexpr int kDepthCol = 16;   // rows in flight in a 16-byte-column stream
 constexpr uint32_t kSlowItem = 0xFFFFFFFFu;   // live_n of an item that went to the slow queue
 
 struct Pass2Queue {
-    uint32_t *counters;         // [0] items bmf_recount_kernel has work for (statistics), [1] length of slow_items
+    uint32_t *counters;         // [0] items bmf_recount_kernel has work for (statistics), [1] length of slow_items,
+                                // [2] 16-byte column loads bmf_recount_kernel issued (statistics: one 64-byte sector each)
     uint32_t *slow_items;
     uint32_t *live_n;           // per item: live chunks after pass 1 (0: result already final), or kSlowItem
     uint16_t *live_chunks;      // per item: kMaxLive chunk ids, ascending
@@ -329,9 +330,9 @@ __device__ __forceinline__ void emit_best_group(const DevParams &P, const u128 (
 // S*r rows of a 16-byte column per lane -- rows g0 .. g0+r-1 of every sample; every lane has its own row-id
 // list (its item's).
 template <int PLANES>
-__device__ __forceinline__ void stream_column(const DevParams &P, const uint8_t *__restrict__ rows,
-                                              const uint32_t *__restrict__ list, uint32_t g0, uint32_t r, uint32_t off,
-                                              bool act, u128 (&cnt)[PLANES]) {
+__device__ __forceinline__ uint32_t stream_column(const DevParams &P, const uint8_t *__restrict__ rows,
+                                                  const uint32_t *__restrict__ list, uint32_t g0, uint32_t r, uint32_t off,
+                                                  bool act, u128 (&cnt)[PLANES]) {
     const uint32_t n_rows = P.S * r;
     u128 ring[kDepthCol];
 #pragma unroll
@@ -372,6 +373,7 @@ __device__ __forceinline__ void stream_column(const DevParams &P, const uint8_t 
     }
 #pragma unroll
     for (int p = 0; p < PLANES; p++) cnt[p] = c1[p][0];
+    return act ? n_rows : 0u;
 }
 
 template <int PLANES>
@@ -384,7 +386,7 @@ __global__ __launch_bounds__(kWave) void bmf_recount_kernel(DevParams P, const u
     const uint32_t lane = threadIdx.x, grp = lane / kMaxLive, gl = lane % kMaxLive;
     const uint32_t n_ids = P.S * P.G;
     uint32_t *list = lds_lists + grp * n_ids;
-    uint32_t recounted = 0;
+    uint32_t recounted = 0, loads = 0;
     for (uint32_t base = blockIdx.x * kPerWave; base < n_items; base += gridDim.x * kPerWave) {
         const uint32_t item = base + grp;
         uint32_t n_live = item < n_items ? Q.live_n[item] : 0u;
@@ -415,7 +417,7 @@ __global__ __launch_bounds__(kWave) void bmf_recount_kernel(DevParams P, const u
         // to nothing to kill.
         if (P.pass1_rows + 1u < P.G) {
             const bool thin = mine && n_live > 3u;
-            stream_column<PLANES>(P, rows, list, P.pass1_rows, 1u, chunk * 16u, thin, cnt);
+            loads += stream_column<PLANES>(P, rows, list, P.pass1_rows, 1u, chunk * 16u, thin, cnt);
             if (thin) {
                 u128 c1[PLANES][1];
 #pragma unroll
@@ -427,12 +429,16 @@ __global__ __launch_bounds__(kWave) void bmf_recount_kernel(DevParams P, const u
             }
             reset(act);
         }
-        stream_column<PLANES>(P, rows, list, 0u, P.G, chunk * 16u, act, cnt);
+        loads += stream_column<PLANES>(P, rows, list, 0u, P.G, chunk * 16u, act, cnt);
         emit_best_group<PLANES>(P, cnt, have, item, lane, chunk, out_counts, out_buckets);
     }
     // statistics only (bmf_batch_pass2_counts): one atomic per wave, not per item
     recounted += (uint32_t)__shfl_xor((int)recounted, kMaxLive, kWave);
-    if (lane == 0 && recounted) atomicAdd(&Q.counters[0], recounted);
+    loads = wave_sum(loads);
+    if (lane == 0 && recounted) {
+        atomicAdd(&Q.counters[0], recounted);
+        atomicAdd(&Q.counters[2], loads);
+    }
 }
 
 // One item the slow way: pass 1, then the exact recount of the live chunks -- one lane per chunk up to 64,

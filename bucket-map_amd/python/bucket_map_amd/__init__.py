@@ -72,6 +72,7 @@ SYMBOLS = {
     "bmf_info": (C.c_int, [C.c_void_p, _u32p, _u32p, _u32p, _u32p]),
     "bmf_pass1_rows": (C.c_int, [C.c_void_p, _u32p]),
     "bmf_batch_pass2_counts": (C.c_int, [C.c_void_p, C.c_void_p, _u32p, _u32p]),
+    "bmf_batch_recount_loads": (C.c_int, [C.c_void_p, C.c_void_p, _u64p]),
 }
 
 _lib = None
@@ -231,6 +232,12 @@ class Batch:
         a, b = C.c_uint32(), C.c_uint32()
         _check(lib().bmf_batch_pass2_counts(self._flt._h, self._h, C.byref(a), C.byref(b)))
         return int(a.value), int(b.value)
+
+    def recount_loads(self) -> int:
+        """16-byte column loads (one 64-byte sector each) of the recount kernel in the last run; two-pass pruning only."""
+        v = C.c_uint64()
+        _check(lib().bmf_batch_recount_loads(self._flt._h, self._h, C.byref(v)))
+        return int(v.value)
 
     def close(self) -> None:
         if self._h:

@@ -163,6 +163,9 @@ int  bmf_pass1_rows(bmf_ctx *ctx, uint32_t *out);
  * the first pass and went to the packed recount kernel, and how many took the slow full-width path.  Both 0
  * when another kernel served the run.  Synchronises. */
 int  bmf_batch_pass2_counts(bmf_ctx *ctx, bmf_batch *batch, uint32_t *recounted, uint32_t *slow);
+/* Same run: 16-byte column loads the recount kernel issued (each one its own 64-byte sector of a random row) --
+ * the unit its HBM traffic is priced in.  Synchronises. */
+int  bmf_batch_recount_loads(bmf_ctx *ctx, bmf_batch *batch, uint64_t *loads);
 
 #ifdef __cplusplus
 }

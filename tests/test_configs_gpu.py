@@ -8,7 +8,11 @@
   configs[4]  the same genome at bucket_len 262 144 with the reference's long-read flags
               (benchmark/long_read/benchmark_map.sh:25: -s 30 -e 0.9 -n 0.1 -l 12 -p 20 -u 5), 10-kbp ONT-profile reads
               through `bucketmap_align`: == the oracle-backed tool on a handful (the CPU verifier fills a 440 MB matrix per
-              alignment), properties and the --gpus split on 1 500.
+              alignment), properties and the --gpus split on 1 500.  One flag differs from the script: -k 10.  A
+              262 444-base bucket of a UNIFORM random genome holds 63 % of all 4^9 9-mers, so no row of a q = 9 index
+              has the 50 % zeros the distinguishability filter asks for (q_gram_mapper.h:189-196) and the reference's
+              algorithm -- oracle and GPU alike, checked -- maps nothing; real genomes are skewed enough for q = 9.
+              With q = 10 a bucket holds 22 % of the 10-mers and the path is exercised.
 
 Synthetic data as SURVEY.md 8d prescribes (real genomes are not available offline).
 """
@@ -178,13 +182,13 @@ def test_config4_long_reads_bucketmap_align(grch38_like, tmp_path):
     from bucket_map_amd import host
     genome = grch38_like
     genome.write_fasta(str(tmp_path / "g.fa"))
-    flags = ["--genome", "g.fa", "--bucket-len", "262144", "-f", "1", "-s", "30", "-e", "0.9", "-n", "0.1", "-l", "12", "-p", "20",
+    flags = ["--genome", "g.fa", "--bucket-len", "262144", "-f", "1", "-k", "10", "-s", "30", "-e", "0.9", "-n", "0.1", "-l", "12", "-p", "20",
              "-u", "5", "--version-check", "0"]
     err = run("gpu_align", ["-x", "-i", "idx", *flags], tmp_path)
     nb = genome.awk_bucket_num(262144)
     assert f"number of buckets: {nb}." in err and 11_700 < nb < 12_000
     # ONT profile: sub 0.03, ins = del 0.025, 10 kbp
-    few = host.Reads(genome, 262144, 300, 10_000, 12, sub=0.03, ins=0.025, dele=0.025, seed=20240007)
+    few = host.Reads(genome, 262144, 300, 10_000, 6, sub=0.03, ins=0.025, dele=0.025, seed=20240007)
     few.write_fastq(str(tmp_path / "few"))
     many = host.Reads(genome, 262144, 300, 10_000, 1_500, sub=0.03, ins=0.025, dele=0.025, seed=20240008, threads=16)
     many.write_fastq(str(tmp_path / "many"))
@@ -193,7 +197,7 @@ def test_config4_long_reads_bucketmap_align(grch38_like, tmp_path):
     run("oracle_align", ["-i", "idx", *flags, "-q", "few.fastq", "-o", "few_cpu.sam"], tmp_path)
     few_sam = (tmp_path / "few_gpu.sam").read_bytes()
     assert few_sam == (tmp_path / "few_cpu.sam").read_bytes()
-    assert len({r[0] for r in parse_sam(tmp_path / "few_gpu.sam")}) >= 10
+    assert len({r[0] for r in parse_sam(tmp_path / "few_gpu.sam")}) >= 5
     run("gpu", ["-i", "idx", *flags, "-q", "few.fastq", "-o", "few_plain_gpu.sam"], tmp_path)
     run("oracle", ["-i", "idx", *flags, "-q", "few.fastq", "-o", "few_plain_cpu.sam"], tmp_path)
     assert (tmp_path / "few_plain_gpu.sam").read_bytes() == (tmp_path / "few_plain_cpu.sam").read_bytes()
