@@ -20,7 +20,7 @@ all: $(PRODUCT) $(TESTINFRA)
 
 # one product library: the candidate-bucket filter (bmf_*), the locator scan (bml_*), the verifier (bmv_*)
 CSRC = $(PKG)/csrc
-$(CSRC)/%.o: $(CSRC)/%.hip $(wildcard $(CSRC)/*.hip.h) include/bmf.h include/bml.h include/bmv.h
+$(CSRC)/%.o: $(CSRC)/%.hip $(wildcard $(CSRC)/*.h) include/bmf.h include/bml.h include/bmv.h
 	$(HIPCC) $(HIPFLAGS) -Wno-unused-result -c -o $@ $<
 
 $(PKG)/libbmf.so: $(CSRC)/bmf_api.o $(CSRC)/bml_api.o $(CSRC)/bmv_api.o

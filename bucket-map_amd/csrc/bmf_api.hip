@@ -6,6 +6,7 @@
 #include "bmf_kernels.hip.h"
 #include "bmf_vote2.hip.h"
 #include "bmi_kernels.hip.h"
+#include "bm_hip_util.h"
 
 #include <hipcub/hipcub.hpp>
 
@@ -212,6 +213,8 @@ struct bmf_ctx {
     vote_fn vote = nullptr;
     TwoPass two_pass;                // used instead of `vote` when dp.pass1_rows > 0
     size_t sample_lds = 0;
+    bmf::SampleGeom sample_geom{};
+    bool sample_bitmap_lds = false;
     // profiling
     bool profiling = false;
     uint32_t prof_max = 0, prof_n = 0;
@@ -341,7 +344,32 @@ int bmf_create(const bmf_params *params, bmf_ctx **out) {
     d.ones_row = 0;
     d.n_kmers = 0;
     d.early_exit = (p.flags & BMF_FLAG_EARLY_EXIT) ? 1u : 0u;
-    c->sample_lds = ((2 * (size_t)p.read_len + 256 + 3) & ~(size_t)3) + 4 * (size_t)d.max_kmers;
+    // Sample kernel geometry: waves (= windows in flight) per workgroup and whether the 4^q-bit q-gram bitmap is
+    // staged in LDS.  Two workgroups per CU (80 KiB each) where the buffers allow it: 32 waves per CU.
+    {
+        bmf::SampleGeom &g = c->sample_geom;
+        g.bitmap_words = (uint32_t)(((1ull << (2 * p.q)) + 31) / 32);
+        g.raw_stride = (p.read_len + 30u + 15u) & ~15u;
+        g.wave_stride = (2u * g.raw_stride + 4u * d.max_kmers + 15u) & ~15u;
+        const size_t bitmap_bytes = ((size_t)g.bitmap_words * 4 + 15) & ~(size_t)15;
+        const size_t half = 80 * 1024, full = 160 * 1024 - 1024;
+        auto waves_in = [&](size_t budget, size_t fixed) -> uint32_t {
+            return budget > fixed ? (uint32_t)std::min<size_t>(16, (budget - fixed) / g.wave_stride) : 0u;
+        };
+        c->sample_bitmap_lds = true;
+        g.waves_per_wg = waves_in(half, bitmap_bytes);
+        if (g.waves_per_wg < 8) g.waves_per_wg = waves_in(full, bitmap_bytes);
+        if (g.waves_per_wg < 1) {   // the bitmap does not fit beside even one window: it stays in L2
+            c->sample_bitmap_lds = false;
+            g.waves_per_wg = waves_in(half, 0);
+            if (g.waves_per_wg < 4) g.waves_per_wg = waves_in(full, 0);
+        }
+        if (g.waves_per_wg < 1) {
+            delete c;
+            return fail(BMF_ERR_UNSUPPORTED, "read_len %u does not fit the sample kernel's LDS buffers", p.read_len);
+        }
+        c->sample_lds = (c->sample_bitmap_lds ? bitmap_bytes : 0) + (size_t)g.waves_per_wg * g.wave_stride;
+    }
 
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e != hipSuccess) {
@@ -369,8 +397,8 @@ int bmf_create(const bmf_params *params, bmf_ctx **out) {
         return fail(BMF_ERR_HIP, "uploading sampler table failed: %s", hipGetErrorString(hipGetLastError()));
     }
     if (c->sample_lds > 48 * 1024) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(bmf::bmf_sample_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->sample_lds);
+        e = bmhip::raise_dynamic_lds(c->sample_bitmap_lds ? reinterpret_cast<const void *>(bmf::bmf_sample_kernel<true>)
+                                                   : reinterpret_cast<const void *>(bmf::bmf_sample_kernel<false>), c->sample_lds);
         if (e != hipSuccess) {
             bmf_destroy(c);
             return fail(BMF_ERR_HIP, "cannot reserve %zu B of LDS: %s", c->sample_lds, hipGetErrorString(e));
@@ -638,8 +666,7 @@ int bmf_build_index(bmf_ctx *c, const uint8_t *genome, uint64_t n_bases, const u
     }
     const size_t lds = (size_t)n_words * 4 + 256;
     if (e == hipSuccess && lds > 48 * 1024)
-        ok(hipFuncSetAttribute(reinterpret_cast<const void *>(bmi::bmi_presence_kernel),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        ok(bmhip::raise_dynamic_lds(reinterpret_cast<const void *>(bmi::bmi_presence_kernel), lds));
     if (e == hipSuccess && n_buckets) {
         for (uint32_t b0 = 0; b0 < n_buckets; b0 += kPresenceSlice)
             hipLaunchKernelGGL(bmi::bmi_presence_kernel, dim3(std::min(kPresenceSlice, n_buckets - b0)), dim3(bmi::kThreads), lds,
@@ -819,9 +846,9 @@ static int check_windows(const bmf_ctx *c, const uint8_t *bases, const uint8_t *
 static hipError_t batch_reserve(bmf_ctx *c, bmf_batch *b, size_t n, size_t n_bytes) {
     hipError_t e = hipSuccess;
     auto ok = [&](hipError_t r) { if (e == hipSuccess) e = r; };
-    if (n_bytes) {
-        ok(b->bases.need(n_bytes));
-        ok(b->quals.need(n_bytes));
+    if (n_bytes) {   // + slack: the sample kernel loads the aligned 16-byte chunks that cover a window
+        ok(b->bases.need(n_bytes + 64));
+        ok(b->quals.need(n_bytes + 64));
     }
     ok(b->win_start.need(n));
     ok(b->win_len.need(n));
@@ -885,9 +912,15 @@ int bmf_batch_create(bmf_ctx *c, const uint8_t *bases, const uint8_t *quals, uin
 // The filter's kernels for the n_windows windows of `b`, reads at d_bases / d_quals, on the context's stream.
 static int launch_filter(bmf_ctx *c, bmf_batch *b, const uint8_t *d_bases, const uint8_t *d_quals, hipEvent_t *ev) {
     if (ev) HIP_TRY(hipEventRecord(ev[0], c->stream));
-    hipLaunchKernelGGL(bmf::bmf_sample_kernel, dim3(b->n_windows), dim3(bmf::kWave), c->sample_lds, c->stream, c->dp,
-                       d_bases, d_quals, b->win_start.p, b->win_len.p, c->d_lut, c->d_qgram_ok, c->d_k2i, c->d_pos_table,
-                       b->lists.p, b->list_n.p, b->rows_anded.p);
+    {
+        bmf::SampleGeom g = c->sample_geom;
+        g.n_windows = b->n_windows;
+        const unsigned wgs = std::min<unsigned>((b->n_windows + g.waves_per_wg - 1) / g.waves_per_wg, 2048u);
+        auto fn = c->sample_bitmap_lds ? bmf::bmf_sample_kernel<true> : bmf::bmf_sample_kernel<false>;
+        hipLaunchKernelGGL(fn, dim3(wgs), dim3(g.waves_per_wg * bmf::kWave), c->sample_lds, c->stream, c->dp, g, d_bases, d_quals,
+                           b->win_start.p, b->win_len.p, c->d_qgram_ok, c->d_k2i, c->d_pos_table, b->lists.p, b->list_n.p,
+                           b->rows_anded.p);
+    }
     if (ev) HIP_TRY(hipEventRecord(ev[1], c->stream));
     if (c->dp.pass1_rows) {
         // two-pass pruning: full-width lower-bound pass, then the queued items' exact recount (bmf_vote2.hip.h)
@@ -1153,8 +1186,8 @@ int bmf_map_windows(bmf_ctx *c, const uint8_t *bases, const uint8_t *quals, uint
     const bool whole = n_pieces > 1 && span_sum > n_bytes + n_bytes / 2;
     if (whole) {
         HIP_TRY(hipStreamSynchronize(c->stream));
-        HIP_TRY(c->whole_bases.need((size_t)n_bytes));
-        HIP_TRY(c->whole_quals.need((size_t)n_bytes));
+        HIP_TRY(c->whole_bases.need((size_t)n_bytes + 64));
+        HIP_TRY(c->whole_quals.need((size_t)n_bytes + 64));
         HIP_TRY(hipMemcpyAsync(c->whole_bases.p, bases, (size_t)n_bytes, hipMemcpyHostToDevice, c->h2d));
         HIP_TRY(hipMemcpyAsync(c->whole_quals.p, quals, (size_t)n_bytes, hipMemcpyHostToDevice, c->h2d));
     }

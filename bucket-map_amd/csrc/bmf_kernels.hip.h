@@ -1,7 +1,7 @@
 // bmf_kernels.hip.h -- gfx950 kernels of the candidate-bucket filter.
 //
 // Two kernels per batch of read windows:
-//   bmf_sample_kernel : one wave per window.  k-mer hashes, quality window sums, distinguishability +
+//   bmf_sample_kernel : one wave per window (persistent workgroups).  k-mer hashes, quality window sums, distinguishability +
 //                       quality filter, ordered compaction, deterministic sampling, q-gram -> row-id
 //                       lists for both orientations (reference: q_gram_mapper.h:431-469).
 //   bmf_vote_kernel   : one wave per (window, orientation).  Streams the S*G index rows of the list
@@ -132,96 +132,151 @@ __global__ void bmf_qgram_ok_kernel(const int32_t *k2i, uint64_t n_kmers, const 
 // sample kernel: q_gram_mapper::query_sequence up to (not including) the two query() calls
 // --------------------------------------------------------------------------------------------------
 //
-// LDS layout (dynamic): lut[256] u8 | code[read_len] u8 | qrank[read_len] u8 | pad to 4 |
-//                       goodh[max_kmers] u32
-__global__ __launch_bounds__(kWave) void bmf_sample_kernel(
-    DevParams P, const uint8_t *__restrict__ bases, const uint8_t *__restrict__ quals,
+// One wave per window, `waves_per_wg` waves per workgroup, workgroups persistent over the windows.  What a window
+// costs is a chain of dependent memory round trips, not instructions (round 1: 15 us per wave, of which five
+// rounds of byte loads for the bases and five rounds of bitmap gathers from L2), so the chain is cut:
+//   * bases and qualities arrive as ONE round of aligned 16-byte loads per lane (the window may start at any byte:
+//     lanes load the aligned chunks that cover it and the k-mer loop indexes behind `shift`);
+//   * ASCII -> dna4 rank is arithmetic on the loaded registers (SeqAn3's folding), no table;
+//   * the "highly distinguishable q-gram" bitmap (4^q bits, 32 KiB at q = 9) is staged in LDS once per workgroup
+//     and shared by its waves (BITMAP_LDS; it stays in L2 when it does not fit beside the waves' buffers).
+//
+// LDS (dynamic): [bitmap, bitmap_words u32] then per wave: code[raw_stride] u8 | qrank[raw_stride] u8 |
+//                goodh[max_kmers] u32 (wave_stride bytes in all, a multiple of 16)
+struct SampleGeom {
+    uint32_t n_windows;
+    uint32_t waves_per_wg;
+    uint32_t bitmap_words;   // u32 words of the q-gram bitmap (staged in LDS when BITMAP_LDS)
+    uint32_t raw_stride;     // bytes of the code / qrank arrays of a wave: read_len + 30, rounded up to 16
+    uint32_t wave_stride;    // LDS bytes per wave
+};
+
+// SeqAn3 dna4 assign_char without a table: letters fold by their low five bits (either case),
+// C Y S B -> 1, G K -> 2, T U -> 3, every other byte -> 0 (A).
+__device__ __forceinline__ uint32_t dna4_code(uint32_t c) {
+    constexpr uint64_t kRank = (1ull << (2 * 3)) | (1ull << (2 * 25)) | (1ull << (2 * 19)) | (1ull << (2 * 2)) |
+                               (2ull << (2 * 7)) | (2ull << (2 * 11)) | (3ull << (2 * 20)) | (3ull << (2 * 21));
+    const uint32_t letter = (c & 0xDFu) - 0x41u;
+    return letter < 26u ? (uint32_t)(kRank >> (2u * (c & 31u))) & 3u : 0u;
+}
+
+template <bool BITMAP_LDS>
+__global__ __launch_bounds__(1024) void bmf_sample_kernel(
+    DevParams P, SampleGeom Gm, const uint8_t *__restrict__ bases, const uint8_t *__restrict__ quals,
     const uint64_t *__restrict__ win_start, const uint32_t *__restrict__ win_len,
-    const uint8_t *__restrict__ dna4_lut,
     const uint32_t *__restrict__ qgram_ok, const int32_t *__restrict__ k2i,
     const uint16_t *__restrict__ pos_table, uint32_t *__restrict__ row_lists,
     uint32_t *__restrict__ list_n, uint32_t *__restrict__ rows_anded) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    uint8_t *lut = smem;
-    uint8_t *code = smem + 256;
-    uint8_t *qrank = code + P.read_len;
-    uint32_t *goodh = reinterpret_cast<uint32_t *>(smem + ((2 * P.read_len + 256 + 3) & ~3u));
-
-    const uint32_t w = blockIdx.x;
-    const uint32_t lane = threadIdx.x;
-    const uint64_t off = win_start[w];
-    const uint32_t len = win_len[w];
-
-    reinterpret_cast<uint32_t *>(lut)[lane] = reinterpret_cast<const uint32_t *>(dna4_lut)[lane];
-    __syncthreads();
-    for (uint32_t i = lane; i < len; i += kWave) {
-        code[i] = lut[bases[off + i]];
-        qrank[i] = (uint8_t)(quals[off + i] - 33u);   // phred94 rank (utils.h:192-204)
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint32_t *okmap_lds = reinterpret_cast<uint32_t *>(smem);
+    uint32_t lds_bitmap_bytes = 0;
+    if (BITMAP_LDS) {
+        for (uint32_t i = threadIdx.x; i < Gm.bitmap_words; i += blockDim.x) okmap_lds[i] = qgram_ok[i];
+        lds_bitmap_bytes = (Gm.bitmap_words * 4u + 15u) & ~15u;
+        __syncthreads();                       // the only workgroup barrier: from here on the waves are on their own
     }
-    __syncthreads();
+    uint8_t *code = smem + lds_bitmap_bytes + (size_t)wave * Gm.wave_stride;
+    uint8_t *qrank = code + Gm.raw_stride;
+    uint32_t *goodh = reinterpret_cast<uint32_t *>(qrank + Gm.raw_stride);
 
-    // k-mers j = 0 .. len-k (views::kmer_hash: size max(len+1,k)-k), 64 per round
-    const uint32_t nk = len >= P.k ? len - P.k + 1 : 0;
-    uint32_t n_good = 0;
-    for (uint32_t base = 0; base < nk; base += kWave) {
-        const uint32_t j = base + lane;
-        bool good = false;
-        uint32_t h = 0;
-        if (j < nk) {
-            uint32_t qs = 0;
-            for (uint32_t t = 0; t < P.k; t++) {
-                h = (h << 2) | code[j + t];
-                qs += qrank[j + t];                     // quality_filter.h:611-621 (plain sum)
+    for (uint32_t w = blockIdx.x * Gm.waves_per_wg + wave; w < Gm.n_windows; w += gridDim.x * Gm.waves_per_wg) {
+        const uint64_t off = win_start[w];
+        const uint32_t len = win_len[w];
+        // aligned 16-byte chunks covering [off, off + len): chunk c of this window is LDS bytes [16c, 16c + 16)
+        const uint32_t shift = (uint32_t)(off & 15u);
+        const uint64_t abase = off - shift;
+        const uint32_t n16 = (shift + len + 15u) >> 4;
+        __builtin_amdgcn_wave_barrier();       // the previous window's LDS reads are done (same wave: in order)
+        for (uint32_t c = lane; c < n16; c += kWave) {
+            const uint4 b = *reinterpret_cast<const uint4 *>(bases + abase + 16u * c);
+            const uint4 q = *reinterpret_cast<const uint4 *>(quals + abase + 16u * c);
+            const uint32_t bw[4] = {b.x, b.y, b.z, b.w}, qw[4] = {q.x, q.y, q.z, q.w};
+            uint32_t cw[4], rw[4];
+#pragma unroll
+            for (int x = 0; x < 4; x++) {
+                cw[x] = 0;
+                rw[x] = 0;
+#pragma unroll
+                for (int t = 0; t < 4; t++) {
+                    cw[x] |= dna4_code((bw[x] >> (8 * t)) & 0xFFu) << (8 * t);
+                    rw[x] |= ((((qw[x] >> (8 * t)) & 0xFFu) - 33u) & 0xFFu) << (8 * t);   // phred94 rank (utils.h:192-204)
+                }
             }
-            bool dist = false;                          // q_gram_mapper.h:189-196
+            *reinterpret_cast<uint4 *>(code + 16u * c) = make_uint4(cw[0], cw[1], cw[2], cw[3]);
+            *reinterpret_cast<uint4 *>(qrank + 16u * c) = make_uint4(rw[0], rw[1], rw[2], rw[3]);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const uint8_t *cd = code + shift, *qr = qrank + shift;
+
+        // k-mers j = 0 .. len-k (views::kmer_hash: size max(len+1,k)-k), 64 per round
+        const uint32_t nk = len >= P.k ? len - P.k + 1 : 0;
+        uint32_t n_good = 0;
+        for (uint32_t base = 0; base < nk; base += kWave) {
+            const uint32_t j = base + lane;
+            bool good = false;
+            uint32_t h = 0;
+            if (j < nk) {
+                uint32_t qs = 0;
+                for (uint32_t t = 0; t < P.k; t++) {
+                    h = (h << 2) | cd[j + t];
+                    qs += qr[j + t];                        // quality_filter.h:611-621 (plain sum)
+                }
+                bool dist = false;                          // q_gram_mapper.h:189-196
+                for (uint32_t g = 0; g < P.G; g++) {
+                    const uint32_t qg = (h >> (2 * g)) & P.qbits;
+                    const uint32_t word = BITMAP_LDS ? okmap_lds[qg >> 5] : qgram_ok[qg >> 5];
+                    dist = dist || ((word >> (qg & 31u)) & 1u);
+                }
+                good = dist && qs >= P.minq;                // q_gram_mapper.h:437-438
+            }
+            const uint64_t m = __ballot(good);
+            if (good) goodh[n_good + __popcll(m & ((1ull << lane) - 1ull))] = h;   // ascending j
+            n_good += (uint32_t)__popcll(m);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+        // q_gram_mapper.h:445: too few good k-mers -> both candidate lists empty
+        if (n_good < P.min_good) {
+            if (lane == 0) {
+                list_n[w] = 0;
+                rows_anded[w] = 0;
+            }
+            continue;
+        }
+
+        // q_gram_mapper.h:457-469: deterministic sample, then the reverse complements of the SAME
+        // sampled hashes in the same order; each sample expands to its G contained q-grams' rows.
+        uint32_t *list_fwd = row_lists + (size_t)(2 * w) * P.list_len;
+        uint32_t *list_rc = list_fwd + P.list_len;
+        uint32_t cnt = 0;
+        for (uint32_t s = lane; s < P.S; s += kWave) {
+            const uint32_t p = pos_table[(size_t)n_good * P.S + s];
+            const uint32_t h = goodh[p];
+            const uint32_t hr = hash_reverse_complement(h, P.k);
             for (uint32_t g = 0; g < P.G; g++) {
-                uint32_t qg = (h >> (2 * g)) & P.qbits;
-                dist = dist || ((qgram_ok[qg >> 5] >> (qg & 31u)) & 1u);
+                const uint32_t g1 = (h >> (2 * g)) & P.qbits, g2 = (hr >> (2 * g)) & P.qbits;
+                const int32_t i1 = g1 < P.n_kmers ? k2i[g1] : -1;   // index_of_kmer, q_gram_mapper.h:374-377
+                const int32_t i2 = g2 < P.n_kmers ? k2i[g2] : -1;
+                list_fwd[s * P.G + g] = i1 >= 0 ? (uint32_t)i1 : P.ones_row;
+                list_rc[s * P.G + g] = i2 >= 0 ? (uint32_t)i2 : P.ones_row;
+                cnt += (i1 >= 0) + (i2 >= 0);
             }
-            good = dist && qs >= P.minq;                // q_gram_mapper.h:437-438
         }
-        const uint64_t m = __ballot(good);
-        if (good) goodh[n_good + __popcll(m & ((1ull << lane) - 1ull))] = h;   // ascending j
-        n_good += (uint32_t)__popcll(m);
-    }
-    __syncthreads();
-
-    // q_gram_mapper.h:445: too few good k-mers -> both candidate lists empty
-    if (n_good < P.min_good) {
+        // pad both lists with the all-ones row (see bmf_vote_kernel)
+        for (uint32_t t = P.S * P.G + lane; t < P.list_len; t += kWave) {
+            list_fwd[t] = P.ones_row;
+            list_rc[t] = P.ones_row;
+        }
+        cnt = wave_sum(cnt);
         if (lane == 0) {
-            list_n[w] = 0;
-            rows_anded[w] = 0;
+            list_n[w] = P.S * P.G;
+            rows_anded[w] = cnt;
         }
-        return;
-    }
-
-    // q_gram_mapper.h:457-469: deterministic sample, then the reverse complements of the SAME
-    // sampled hashes in the same order; each sample expands to its G contained q-grams' rows.
-    uint32_t *list_fwd = row_lists + (size_t)(2 * w) * P.list_len;
-    uint32_t *list_rc = list_fwd + P.list_len;
-    uint32_t cnt = 0;
-    for (uint32_t s = lane; s < P.S; s += kWave) {
-        const uint32_t p = pos_table[(size_t)n_good * P.S + s];
-        const uint32_t h = goodh[p];
-        const uint32_t hr = hash_reverse_complement(h, P.k);
-        for (uint32_t g = 0; g < P.G; g++) {
-            const uint32_t g1 = (h >> (2 * g)) & P.qbits, g2 = (hr >> (2 * g)) & P.qbits;
-            const int32_t i1 = g1 < P.n_kmers ? k2i[g1] : -1;   // index_of_kmer, q_gram_mapper.h:374-377
-            const int32_t i2 = g2 < P.n_kmers ? k2i[g2] : -1;
-            list_fwd[s * P.G + g] = i1 >= 0 ? (uint32_t)i1 : P.ones_row;
-            list_rc[s * P.G + g] = i2 >= 0 ? (uint32_t)i2 : P.ones_row;
-            cnt += (i1 >= 0) + (i2 >= 0);
-        }
-    }
-    // pad both lists with the all-ones row (see bmf_vote_kernel)
-    for (uint32_t t = P.S * P.G + lane; t < P.list_len; t += kWave) {
-        list_fwd[t] = P.ones_row;
-        list_rc[t] = P.ones_row;
-    }
-    cnt = wave_sum(cnt);
-    if (lane == 0) {
-        list_n[w] = P.S * P.G;
-        rows_anded[w] = cnt;
     }
 }
 

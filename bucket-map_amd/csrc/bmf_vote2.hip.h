@@ -376,8 +376,9 @@ __device__ __forceinline__ uint32_t stream_column(const DevParams &P, const uint
     return act ? n_rows : 0u;
 }
 
+// (4 waves per SIMD asked for: at most 128 VGPRs, the latency of the short dependent streams needs the waves)
 template <int PLANES>
-__global__ __launch_bounds__(kWave) void bmf_recount_kernel(DevParams P, const uint8_t *__restrict__ rows,
+__global__ __launch_bounds__(kWave, 4) void bmf_recount_kernel(DevParams P, const uint8_t *__restrict__ rows,
                                                            const uint32_t *__restrict__ row_lists, uint32_t n_items,
                                                            uint32_t *__restrict__ out_counts,
                                                            uint32_t *__restrict__ out_buckets, Pass2Queue Q) {

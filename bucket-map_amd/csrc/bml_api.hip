@@ -2,6 +2,7 @@
 // Host side only: chunking of candidates per bucket, buffers, the occurrence sort (hipCUB radix sort,
 // a library primitive) and the automatic re-run when the occurrence buffer was too small.
 #include "bml_kernels.hip.h"
+#include "bm_hip_util.h"
 
 #include "../../include/bml.h"
 
@@ -123,8 +124,7 @@ int bml_create(const bml_params *params, bml_ctx **out) {
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     for (int i = 0; i < 4 && e == hipSuccess; i++) e = hipEventCreate(&c->ev[i]);
     if (e == hipSuccess && lds > 48 * 1024)
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(bml::bml_scan_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        e = bmhip::raise_dynamic_lds(reinterpret_cast<const void *>(bml::bml_scan_kernel), lds);
     uint8_t lut[256];
     build_dna4_lut(lut);
     if (e == hipSuccess) e = c->lut.need(256);
@@ -175,8 +175,7 @@ int bml_sample_windows(bml_ctx *c, const uint8_t *bases, const uint8_t *quals, u
     if (lds > 160 * 1024) return fail(BML_ERR_UNSUPPORTED, "windows of %u bases need %zu B of LDS", max_len, lds);
     HIP_TRY(hipSetDevice(c->p.device));
     if (lds > 48 * 1024)
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(bml::bml_sample_kernel),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIP_TRY(bmhip::raise_dynamic_lds(reinterpret_cast<const void *>(bml::bml_sample_kernel), lds));
     // Sampler(p).sample_deterministically(n - 1) for every possible selection size n (utils.h:160-178), in
     // fp64 on the host so that device rounding can never differ
     if (max_len > c->s_table_len) {

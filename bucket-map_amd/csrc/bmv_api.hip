@@ -3,6 +3,7 @@
 // that the traceback bits of one chunk fit the scratch budget, offsets of the packed CIGAR output
 // (hipCUB exclusive sum, a library primitive).
 #include "bmv_kernels.hip.h"
+#include "bm_hip_util.h"
 
 #include "../../include/bmv.h"
 
@@ -235,7 +236,7 @@ int bmv_align(bmv_ctx *c, const uint8_t *reads, uint64_t n_read_bytes, const uin
     const size_t lds = 256 + (size_t)gpw * (lds_stride + qry_stride);
     if (lds > 160 * 1024) return fail(BMV_ERR_UNSUPPORTED, "text windows of %u bases need %zu B of LDS", max_n, lds);
     if (lds > 48 * 1024)
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(sh.fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIP_TRY(bmhip::raise_dynamic_lds(reinterpret_cast<const void *>(sh.fn), lds));
     const uint64_t per_slot = trace_stride / gpw * 8u + (uint64_t)ops_stride * 4u;
     uint64_t chunk = std::max<uint64_t>(gpw, c->scratch_bytes / per_slot);
     chunk = std::min<uint64_t>(chunk, (uint64_t)gpw << 25);   // one wave per gpw alignments: waves * 64 threads < 2^32
