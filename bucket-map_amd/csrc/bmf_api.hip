@@ -349,8 +349,10 @@ int bmf_create(const bmf_params *params, bmf_ctx **out) {
     {
         bmf::SampleGeom &g = c->sample_geom;
         g.bitmap_words = (uint32_t)(((1ull << (2 * p.q)) + 31) / 32);
-        g.raw_stride = (p.read_len + 30u + 15u) & ~15u;
-        g.wave_stride = (2u * g.raw_stride + 4u * d.max_kmers + 15u) & ~15u;
+        const uint32_t stream = (p.read_len + 30u + 15u) & ~15u;   // stream positions of the aligned chunks covering a window
+        g.pk_bytes = ((stream / 16u + 1u) * 4u + 15u) & ~15u;
+        g.qsum_bytes = ((stream + 1u) * 4u + 15u) & ~15u;
+        g.wave_stride = (g.pk_bytes + g.qsum_bytes + 4u * d.max_kmers + 15u) & ~15u;
         const size_t bitmap_bytes = ((size_t)g.bitmap_words * 4 + 15) & ~(size_t)15;
         const size_t half = 80 * 1024, full = 160 * 1024 - 1024;
         auto waves_in = [&](size_t budget, size_t fixed) -> uint32_t {

@@ -141,13 +141,20 @@ __global__ void bmf_qgram_ok_kernel(const int32_t *k2i, uint64_t n_kmers, const 
 //   * the "highly distinguishable q-gram" bitmap (4^q bits, 32 KiB at q = 9) is staged in LDS once per workgroup
 //     and shared by its waves (BITMAP_LDS; it stays in L2 when it does not fit beside the waves' buffers).
 //
-// LDS (dynamic): [bitmap, bitmap_words u32] then per wave: code[raw_stride] u8 | qrank[raw_stride] u8 |
-//                goodh[max_kmers] u32 (wave_stride bytes in all, a multiple of 16)
+//   * the window's bases are kept as a 2-bit big-endian stream (16 bases per word): a k-mer hash is a 64-bit
+//     funnel shift over two words instead of k byte reads; the k-mer quality sums (quality_filter.h:611-631) are
+//     differences of a prefix-sum array built by one wave scan instead of k byte reads each -- the kernel is
+//     bound by LDS instructions once the global round trips are gone.
+//
+// LDS (dynamic): [bitmap, bitmap_words u32] then per wave: pk[pk_bytes / 4] u32 (packed bases of the aligned chunks
+//                covering the window, one pad word) | qsum[qsum_bytes / 4] u32 (exclusive prefix sums of the phred
+//                ranks over the same chunks, + the total) | goodh[max_kmers] u32; wave_stride bytes in all
 struct SampleGeom {
     uint32_t n_windows;
     uint32_t waves_per_wg;
     uint32_t bitmap_words;   // u32 words of the q-gram bitmap (staged in LDS when BITMAP_LDS)
-    uint32_t raw_stride;     // bytes of the code / qrank arrays of a wave: read_len + 30, rounded up to 16
+    uint32_t pk_bytes;       // multiples of 16
+    uint32_t qsum_bytes;
     uint32_t wave_stride;    // LDS bytes per wave
 };
 
@@ -176,40 +183,62 @@ __global__ __launch_bounds__(1024) void bmf_sample_kernel(
         lds_bitmap_bytes = (Gm.bitmap_words * 4u + 15u) & ~15u;
         __syncthreads();                       // the only workgroup barrier: from here on the waves are on their own
     }
-    uint8_t *code = smem + lds_bitmap_bytes + (size_t)wave * Gm.wave_stride;
-    uint8_t *qrank = code + Gm.raw_stride;
-    uint32_t *goodh = reinterpret_cast<uint32_t *>(qrank + Gm.raw_stride);
+    uint32_t *pk = reinterpret_cast<uint32_t *>(smem + lds_bitmap_bytes + (size_t)wave * Gm.wave_stride);
+    uint32_t *qsum = pk + Gm.pk_bytes / 4;
+    uint32_t *goodh = qsum + Gm.qsum_bytes / 4;
+    const uint32_t kmask = P.k >= 16 ? 0xFFFFFFFFu : (1u << (2 * P.k)) - 1u;
 
     for (uint32_t w = blockIdx.x * Gm.waves_per_wg + wave; w < Gm.n_windows; w += gridDim.x * Gm.waves_per_wg) {
         const uint64_t off = win_start[w];
         const uint32_t len = win_len[w];
-        // aligned 16-byte chunks covering [off, off + len): chunk c of this window is LDS bytes [16c, 16c + 16)
+        // aligned 16-byte chunks covering [off, off + len): chunk c holds stream positions [16c, 16c + 16), the
+        // window's base j sits at stream position shift + j
         const uint32_t shift = (uint32_t)(off & 15u);
         const uint64_t abase = off - shift;
         const uint32_t n16 = (shift + len + 15u) >> 4;
         __builtin_amdgcn_wave_barrier();       // the previous window's LDS reads are done (same wave: in order)
-        for (uint32_t c = lane; c < n16; c += kWave) {
-            const uint4 b = *reinterpret_cast<const uint4 *>(bases + abase + 16u * c);
-            const uint4 q = *reinterpret_cast<const uint4 *>(quals + abase + 16u * c);
+        uint32_t carry = 0;                    // quality ranks summed over the chunks of earlier rounds
+        for (uint32_t c0 = 0; c0 < n16; c0 += kWave) {
+            const uint32_t c = c0 + lane;
+            uint4 b = make_uint4(0, 0, 0, 0), q = make_uint4(0x21212121u, 0x21212121u, 0x21212121u, 0x21212121u);
+            if (c < n16) {
+                b = *reinterpret_cast<const uint4 *>(bases + abase + 16u * c);
+                q = *reinterpret_cast<const uint4 *>(quals + abase + 16u * c);
+            }
             const uint32_t bw[4] = {b.x, b.y, b.z, b.w}, qw[4] = {q.x, q.y, q.z, q.w};
-            uint32_t cw[4], rw[4];
+            uint32_t packed = 0, run = 0, before[16];
 #pragma unroll
-            for (int x = 0; x < 4; x++) {
-                cw[x] = 0;
-                rw[x] = 0;
+            for (int x = 0; x < 4; x++)
 #pragma unroll
                 for (int t = 0; t < 4; t++) {
-                    cw[x] |= dna4_code((bw[x] >> (8 * t)) & 0xFFu) << (8 * t);
-                    rw[x] |= ((((qw[x] >> (8 * t)) & 0xFFu) - 33u) & 0xFFu) << (8 * t);   // phred94 rank (utils.h:192-204)
+                    packed = (packed << 2) | dna4_code((bw[x] >> (8 * t)) & 0xFFu);
+                    before[4 * x + t] = run;
+                    run += (((qw[x] >> (8 * t)) & 0xFFu) - 33u) & 0xFFu;        // phred94 rank (utils.h:192-204)
                 }
+            uint32_t incl = run;                // wave scan of the chunk totals
+#pragma unroll
+            for (int o = 1; o < kWave; o <<= 1) {
+                const uint32_t t = __shfl_up(incl, o, kWave);
+                if (lane >= (uint32_t)o) incl += t;
             }
-            *reinterpret_cast<uint4 *>(code + 16u * c) = make_uint4(cw[0], cw[1], cw[2], cw[3]);
-            *reinterpret_cast<uint4 *>(qrank + 16u * c) = make_uint4(rw[0], rw[1], rw[2], rw[3]);
+            const uint32_t base_sum = carry + incl - run;
+            if (c < n16) {
+                pk[c] = packed;
+#pragma unroll
+                for (int x = 0; x < 4; x++)
+                    *reinterpret_cast<uint4 *>(qsum + 16u * c + 4u * x) =
+                        make_uint4(base_sum + before[4 * x], base_sum + before[4 * x + 1], base_sum + before[4 * x + 2],
+                                   base_sum + before[4 * x + 3]);
+            }
+            carry += __shfl(incl, kWave - 1, kWave);
+        }
+        if (lane == 0) {
+            pk[n16] = 0;                        // the funnel shift of the last k-mers reads one word past the stream
+            qsum[16u * n16] = carry;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        const uint8_t *cd = code + shift, *qr = qrank + shift;
 
         // k-mers j = 0 .. len-k (views::kmer_hash: size max(len+1,k)-k), 64 per round
         const uint32_t nk = len >= P.k ? len - P.k + 1 : 0;
@@ -219,18 +248,17 @@ __global__ __launch_bounds__(1024) void bmf_sample_kernel(
             bool good = false;
             uint32_t h = 0;
             if (j < nk) {
-                uint32_t qs = 0;
-                for (uint32_t t = 0; t < P.k; t++) {
-                    h = (h << 2) | cd[j + t];
-                    qs += qr[j + t];                        // quality_filter.h:611-621 (plain sum)
-                }
-                bool dist = false;                          // q_gram_mapper.h:189-196
+                const uint32_t at = shift + j, lo = at >> 4, r = at & 15u;
+                const uint64_t two = ((uint64_t)pk[lo] << 32) | pk[lo + 1];
+                h = (uint32_t)(two >> (64u - 2u * r - 2u * P.k)) & kmask;
+                const uint32_t qs = qsum[at + P.k] - qsum[at];                  // quality_filter.h:611-621 (plain sum)
+                bool dist = false;                                               // q_gram_mapper.h:189-196
                 for (uint32_t g = 0; g < P.G; g++) {
                     const uint32_t qg = (h >> (2 * g)) & P.qbits;
                     const uint32_t word = BITMAP_LDS ? okmap_lds[qg >> 5] : qgram_ok[qg >> 5];
                     dist = dist || ((word >> (qg & 31u)) & 1u);
                 }
-                good = dist && qs >= P.minq;                // q_gram_mapper.h:437-438
+                good = dist && qs >= P.minq;                                     // q_gram_mapper.h:437-438
             }
             const uint64_t m = __ballot(good);
             if (good) goodh[n_good + __popcll(m & ((1ull << lane) - 1ull))] = h;   // ascending j
