@@ -110,37 +110,38 @@ struct TwoPass {
 };
 
 template <int CPL, int PLANES>
-TwoPass two_pass_of() {
+TwoPass two_pass_of(int max_live) {
     constexpr int D = depth_for(CPL);
     pass1_fn p1 = bmf::bmf_pass1_kernel<CPL, PLANES, D>;
     if constexpr (D > 2) {
         const char *env = getenv("BMF_PASS1_SHALLOW");
         if (env && env[0] == '1') p1 = bmf::bmf_pass1_kernel<CPL, PLANES, D - 1>;
     }
-    return {p1, bmf::bmf_recount_kernel<PLANES>, bmf::bmf_vote2_slow_kernel<CPL, PLANES, D>};
+    recount_fn rc = max_live <= 16 ? bmf::bmf_recount_kernel<PLANES, 16> : bmf::bmf_recount_kernel<PLANES, 32>;
+    return {p1, rc, bmf::bmf_vote2_slow_kernel<CPL, PLANES, D>};
 }
 
 template <int CPL>
-TwoPass pick_planes2(int planes) {
+TwoPass pick_planes2(int planes, int max_live) {
     switch (planes) {
-    case 2: return two_pass_of<CPL, 2>();
-    case 3: return two_pass_of<CPL, 3>();
-    case 4: return two_pass_of<CPL, 4>();
-    case 5: return two_pass_of<CPL, 5>();
+    case 2: return two_pass_of<CPL, 2>(max_live);
+    case 3: return two_pass_of<CPL, 3>(max_live);
+    case 4: return two_pass_of<CPL, 4>(max_live);
+    case 5: return two_pass_of<CPL, 5>(max_live);
     }
     return {};
 }
 
-TwoPass pick_vote2(int cpl, int planes) {
+TwoPass pick_vote2(int cpl, int planes, int max_live) {
     switch (cpl) {
-    case 1: return pick_planes2<1>(planes);
-    case 2: return pick_planes2<2>(planes);
-    case 3: return pick_planes2<3>(planes);
-    case 4: return pick_planes2<4>(planes);
-    case 5: return pick_planes2<5>(planes);
-    case 6: return pick_planes2<6>(planes);
-    case 7: return pick_planes2<7>(planes);
-    case 8: return pick_planes2<8>(planes);
+    case 1: return pick_planes2<1>(planes, max_live);
+    case 2: return pick_planes2<2>(planes, max_live);
+    case 3: return pick_planes2<3>(planes, max_live);
+    case 4: return pick_planes2<4>(planes, max_live);
+    case 5: return pick_planes2<5>(planes, max_live);
+    case 6: return pick_planes2<6>(planes, max_live);
+    case 7: return pick_planes2<7>(planes, max_live);
+    case 8: return pick_planes2<8>(planes, max_live);
     }
     return {};
 }
@@ -349,8 +350,8 @@ int bmf_create(const bmf_params *params, bmf_ctx **out) {
     {
         bmf::SampleGeom &g = c->sample_geom;
         g.bitmap_words = (uint32_t)(((1ull << (2 * p.q)) + 31) / 32);
-        const uint32_t stream = (p.read_len + 30u + 15u) & ~15u;   // stream positions of the aligned chunks covering a window
-        g.pk_bytes = ((stream / 16u + 1u) * 4u + 15u) & ~15u;
+        const uint32_t stream = (p.read_len + 14u + 15u) & ~15u;   // stream positions of the aligned 8-byte chunks covering a window
+        g.pk_bytes = ((stream / 16u + 3u) * 4u + 15u) & ~15u;      // + the words the last positions' shifts touch
         g.qsum_bytes = ((stream + 1u) * 4u + 15u) & ~15u;
         g.wave_stride = (g.pk_bytes + g.qsum_bytes + 4u * d.max_kmers + 15u) & ~15u;
         const size_t bitmap_bytes = ((size_t)g.bitmap_words * 4 + 15) & ~(size_t)15;
@@ -432,6 +433,7 @@ static void free_index(bmf_ctx *c) {
 static int select_pruned_variant(bmf_ctx *c) {
     const bmf::DevParams &d = c->dp;
     c->dp.pass1_rows = 0;
+    c->dp.max_live = bmf::kMaxLive;
     if (!(c->p.flags & BMF_FLAG_EARLY_EXIT) || c->n_slices > 1) return BMF_OK;
     c->vote = pick_vote(c->cpl, c->planes, true);
     if (d.G < 2 || c->n_rows == 0) return BMF_OK;
@@ -461,7 +463,7 @@ static int select_pruned_variant(bmf_ctx *c) {
     const double row_bytes = (double)d.n_chunks * 16.0, sector = 64.0;
     const double prune_cost = (double)d.F * d.G * row_bytes;
     uint32_t best_r = 0;
-    double best = 0.95 * prune_cost;
+    double best = 0.95 * prune_cost, best_live = 0.0;
     for (uint32_t r = 1; r < d.G; r++) {
         const double live = (double)d.nb * binom_tail(d.S, pow(hit1, (double)r), d.S - d.F + 1u);
         if (live > 20.0) continue;   // more than kMaxLive live chunks send an item down the slow path
@@ -469,15 +471,25 @@ static int select_pruned_variant(bmf_ctx *c) {
         if (cost < best) {
             best = cost;
             best_r = r;
+            best_live = live;
         }
     }
     if (const char *env = getenv("BMF_PASS1_ROWS")) {
         const long v = strtol(env, nullptr, 10);
         best_r = v > 0 && (uint32_t)v < d.G ? (uint32_t)v : 0u;
+        if (best_r) best_live = (double)d.nb * binom_tail(d.S, pow(hit1, (double)best_r), d.S - d.F + 1u);
     }
     if (best_r) {
-        c->two_pass = pick_vote2(c->cpl, c->planes);
-        if (c->two_pass.pass1) c->dp.pass1_rows = best_r;
+        // Lanes per item in the recount kernel: 16 (four items per wave) while items with more than 16 live chunks stay
+        // rare -- the by-chance survivors are Poisson around best_live, plus the read's own chunk -- else 32.
+        // BMF_MAX_LIVE=16|32 overrides (the sweeps force both).
+        int max_live = best_live + 1.0 <= 9.0 ? 16 : 32;
+        if (const char *env = getenv("BMF_MAX_LIVE")) max_live = atoi(env) == 16 ? 16 : 32;
+        c->two_pass = pick_vote2(c->cpl, c->planes, max_live);
+        if (c->two_pass.pass1) {
+            c->dp.pass1_rows = best_r;
+            c->dp.max_live = (uint32_t)max_live;
+        }
     }
     return BMF_OK;
 }
@@ -937,8 +949,9 @@ static int launch_filter(bmf_ctx *c, bmf_batch *b, const uint8_t *d_bases, const
                            b->lists.p, b->list_n.p, b->counts.p, q);
         // fixed grids: the recount walks all items (most keep a few live chunks), the slow kernel strides over
         // the queue length it reads from HBM -- nothing comes back to the host in between
-        const unsigned recount_blocks = (unsigned)std::min<size_t>((n_items + 1) / 2, 32768);
-        const size_t recount_lds = 2 * (size_t)c->dp.S * c->dp.G * sizeof(uint32_t);
+        const size_t per_wave = bmf::kWave / c->dp.max_live;   // items per wave
+        const unsigned recount_blocks = (unsigned)std::min<size_t>((n_items + per_wave - 1) / per_wave, 32768);
+        const size_t recount_lds = per_wave * (size_t)c->dp.S * c->dp.G * sizeof(uint32_t);
         hipLaunchKernelGGL(c->two_pass.recount, dim3(recount_blocks), dim3(bmf::kWave), recount_lds, c->stream, c->dp, c->d_rows,
                            b->lists.p, (uint32_t)n_items, b->counts.p, b->buckets.p, q);
         const unsigned slow_blocks = (unsigned)std::min<size_t>(n_items, 2048);

@@ -41,6 +41,7 @@ struct DevParams {
     uint32_t n_kmers;    // entries of kmer_to_index (4^q, or 0 when no .kmers_index was loaded)
     uint32_t early_exit; // BMF_FLAG_EARLY_EXIT: a pruning kernel variant is in use (informational)
     uint32_t pass1_rows; // two-pass variant: q-gram rows of each sample read at full width in pass 1 (1..G)
+    uint32_t max_live;   // two-pass variant: live chunks (= lanes) an item may bring to the recount kernel (16 or 32)
 };
 
 __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
@@ -132,22 +133,26 @@ __global__ void bmf_qgram_ok_kernel(const int32_t *k2i, uint64_t n_kmers, const 
 // sample kernel: q_gram_mapper::query_sequence up to (not including) the two query() calls
 // --------------------------------------------------------------------------------------------------
 //
-// One wave per window, `waves_per_wg` waves per workgroup, workgroups persistent over the windows.  What a window
-// costs is a chain of dependent memory round trips, not instructions (round 1: 15 us per wave, of which five
-// rounds of byte loads for the bases and five rounds of bitmap gathers from L2), so the chain is cut:
-//   * bases and qualities arrive as ONE round of aligned 16-byte loads per lane (the window may start at any byte:
-//     lanes load the aligned chunks that cover it and the k-mer loop indexes behind `shift`);
-//   * ASCII -> dna4 rank is arithmetic on the loaded registers (SeqAn3's folding), no table;
-//   * the "highly distinguishable q-gram" bitmap (4^q bits, 32 KiB at q = 9) is staged in LDS once per workgroup
-//     and shared by its waves (BITMAP_LDS; it stays in L2 when it does not fit beside the waves' buffers).
-//
-//   * the window's bases are kept as a 2-bit big-endian stream (16 bases per word): a k-mer hash is a 64-bit
-//     funnel shift over two words instead of k byte reads; the k-mer quality sums (quality_filter.h:611-631) are
-//     differences of a prefix-sum array built by one wave scan instead of k byte reads each -- the kernel is
-//     bound by LDS instructions once the global round trips are gone.
+// One wave per window, `waves_per_wg` waves per workgroup, workgroups persistent over the windows.
+// History of what bounds it (profiles/r02).  Round 1's kernel spent 15 us per window in a chain of
+// dependent round trips (five rounds of byte loads for the bases, five rounds of bitmap gathers from L2); with
+// those gone it turned out to be bound by VALU issue -- 632 wave-instructions per window at 4 cycles each on a
+// 16-lane SIMD is 1.0 of its 1.65 ms -- so the instruction stream is what this version cuts:
+//   * bases and qualities arrive as one round of aligned 8-byte loads per lane (the window may start at any
+//     byte: lanes load the aligned chunks that cover it, positions are counted from the first chunk);
+//   * ASCII -> dna4 rank four bytes at a time: ((c >> 1) & 3) ^ (that >> 1) is right for A C G T in either case,
+//     v_perm_b32 rebuilds the letters those ranks stand for, and only a word that is NOT its own rebuild (N,
+//     IUPAC, anything else) takes the byte-wise exact folding (SeqAn3's);
+//   * the bases are kept as a 2-bit big-endian stream (16 per word): a k-mer or q-gram hash is one 64-bit shift
+//     over two words; the k-mer quality sums (quality_filter.h:611-631) are differences of a prefix-sum array;
+//   * is_highly_distinguishable (q_gram_mapper.h:189-196) asks, for each of the G = k-q+1 q-grams of a k-mer,
+//     one bit of a 4^q-bit map; consecutive k-mers share all but one of them, so the map (staged in LDS once per
+//     workgroup when BITMAP_LDS) is read once per POSITION, the bits of a round of 64 positions are a wave ballot,
+//     and "any of my G q-grams" is G-1 scalar shift-ORs of that ballot with the next round's;
+//   * the reverse complement of a hash is a bit reversal and three masks, not a loop over k bases.
 //
 // LDS (dynamic): [bitmap, bitmap_words u32] then per wave: pk[pk_bytes / 4] u32 (packed bases of the aligned chunks
-//                covering the window, one pad word) | qsum[qsum_bytes / 4] u32 (exclusive prefix sums of the phred
+//                covering the window, + one pad word) | qsum[qsum_bytes / 4] u32 (exclusive prefix sums of the phred
 //                ranks over the same chunks, + the total) | goodh[max_kmers] u32; wave_stride bytes in all
 struct SampleGeom {
     uint32_t n_windows;
@@ -167,8 +172,28 @@ __device__ __forceinline__ uint32_t dna4_code(uint32_t c) {
     return letter < 26u ? (uint32_t)(kRank >> (2u * (c & 31u))) & 3u : 0u;
 }
 
+// Four ASCII bytes -> their four dna4 ranks as one byte, the first (lowest-address) base in the top two bits.
+__device__ __forceinline__ uint32_t dna4_pack4(uint32_t w) {
+    const uint32_t t = (w >> 1) & 0x03030303u;
+    uint32_t code = t ^ ((t >> 1) & 0x01010101u);                       // A C G T (a c g t) -> 0 1 2 3
+    if (__builtin_amdgcn_perm(0u, 0x54474341u, code) != (w & 0xDFDFDFDFu)) {   // some byte is none of those
+        code = dna4_code(w & 0xFFu) | (dna4_code((w >> 8) & 0xFFu) << 8) | (dna4_code((w >> 16) & 0xFFu) << 16) |
+               (dna4_code(w >> 24) << 24);
+    }
+    const uint32_t r = __builtin_amdgcn_perm(0u, code, 0x00010203u);    // byte-reversed: first base in byte 3
+    const uint32_t x = r | (r >> 6);
+    return (x | (x >> 12)) & 0xFFu;
+}
+
+// utils.h:291-302 without the loop: reverse the bits, swap the two bits of every base back, complement
+__device__ __forceinline__ uint32_t revcomp_fast(uint32_t h, uint32_t k) {
+    const uint32_t br = __brev(h);
+    const uint32_t sw = ((br >> 1) & 0x55555555u) | ((br & 0x55555555u) << 1);
+    return (~sw) >> (32u - 2u * k);
+}
+
 template <bool BITMAP_LDS>
-__global__ __launch_bounds__(1024) void bmf_sample_kernel(
+__global__ __launch_bounds__(1024, 8) void bmf_sample_kernel(   // 8 waves per SIMD (two workgroups per CU): at most 64 VGPRs
     DevParams P, SampleGeom Gm, const uint8_t *__restrict__ bases, const uint8_t *__restrict__ quals,
     const uint64_t *__restrict__ win_start, const uint32_t *__restrict__ win_len,
     const uint32_t *__restrict__ qgram_ok, const int32_t *__restrict__ k2i,
@@ -184,37 +209,44 @@ __global__ __launch_bounds__(1024) void bmf_sample_kernel(
         __syncthreads();                       // the only workgroup barrier: from here on the waves are on their own
     }
     uint32_t *pk = reinterpret_cast<uint32_t *>(smem + lds_bitmap_bytes + (size_t)wave * Gm.wave_stride);
+    uint16_t *pk16 = reinterpret_cast<uint16_t *>(pk);
     uint32_t *qsum = pk + Gm.pk_bytes / 4;
     uint32_t *goodh = qsum + Gm.qsum_bytes / 4;
     const uint32_t kmask = P.k >= 16 ? 0xFFFFFFFFu : (1u << (2 * P.k)) - 1u;
+    const uint64_t lane_bit = 1ull << lane;
 
     for (uint32_t w = blockIdx.x * Gm.waves_per_wg + wave; w < Gm.n_windows; w += gridDim.x * Gm.waves_per_wg) {
         const uint64_t off = win_start[w];
         const uint32_t len = win_len[w];
-        // aligned 16-byte chunks covering [off, off + len): chunk c holds stream positions [16c, 16c + 16), the
+        // aligned 8-byte chunks covering [off, off + len): chunk c holds stream positions [8c, 8c + 8), the
         // window's base j sits at stream position shift + j
-        const uint32_t shift = (uint32_t)(off & 15u);
+        const uint32_t shift = (uint32_t)(off & 7u);
         const uint64_t abase = off - shift;
-        const uint32_t n16 = (shift + len + 15u) >> 4;
+        const uint32_t n8 = (shift + len + 7u) >> 3;
         __builtin_amdgcn_wave_barrier();       // the previous window's LDS reads are done (same wave: in order)
         uint32_t carry = 0;                    // quality ranks summed over the chunks of earlier rounds
-        for (uint32_t c0 = 0; c0 < n16; c0 += kWave) {
+        for (uint32_t c0 = 0; c0 < n8; c0 += kWave) {
             const uint32_t c = c0 + lane;
-            uint4 b = make_uint4(0, 0, 0, 0), q = make_uint4(0x21212121u, 0x21212121u, 0x21212121u, 0x21212121u);
-            if (c < n16) {
-                b = *reinterpret_cast<const uint4 *>(bases + abase + 16u * c);
-                q = *reinterpret_cast<const uint4 *>(quals + abase + 16u * c);
+            uint2 b = make_uint2(0x41414141u, 0x41414141u), q = make_uint2(0x21212121u, 0x21212121u);
+            if (c < n8) {
+                b = *reinterpret_cast<const uint2 *>(bases + abase + 8u * c);
+                q = *reinterpret_cast<const uint2 *>(quals + abase + 8u * c);
             }
-            const uint32_t bw[4] = {b.x, b.y, b.z, b.w}, qw[4] = {q.x, q.y, q.z, q.w};
-            uint32_t packed = 0, run = 0, before[16];
+            const uint32_t packed = (dna4_pack4(b.x) << 8) | dna4_pack4(b.y);    // 8 bases, the first in the top bits
+            // phred94 rank = byte - 33 (utils.h:192-204), byte-wise exact: no borrow runs into the neighbour
+            const uint32_t H = 0x80808080u, K = 0x21212121u;
+            const uint32_t r0 = ((q.x | H) - K) ^ ((q.x ^ ~K) & H), r1 = ((q.y | H) - K) ^ ((q.y ^ ~K) & H);
+            uint32_t before[8], run = 0;
 #pragma unroll
-            for (int x = 0; x < 4; x++)
+            for (int t = 0; t < 4; t++) {
+                before[t] = run;
+                run += (r0 >> (8 * t)) & 0xFFu;
+            }
 #pragma unroll
-                for (int t = 0; t < 4; t++) {
-                    packed = (packed << 2) | dna4_code((bw[x] >> (8 * t)) & 0xFFu);
-                    before[4 * x + t] = run;
-                    run += (((qw[x] >> (8 * t)) & 0xFFu) - 33u) & 0xFFu;        // phred94 rank (utils.h:192-204)
-                }
+            for (int t = 0; t < 4; t++) {
+                before[4 + t] = run;
+                run += (r1 >> (8 * t)) & 0xFFu;
+            }
             uint32_t incl = run;                // wave scan of the chunk totals
 #pragma unroll
             for (int o = 1; o < kWave; o <<= 1) {
@@ -222,47 +254,58 @@ __global__ __launch_bounds__(1024) void bmf_sample_kernel(
                 if (lane >= (uint32_t)o) incl += t;
             }
             const uint32_t base_sum = carry + incl - run;
-            if (c < n16) {
-                pk[c] = packed;
-#pragma unroll
-                for (int x = 0; x < 4; x++)
-                    *reinterpret_cast<uint4 *>(qsum + 16u * c + 4u * x) =
-                        make_uint4(base_sum + before[4 * x], base_sum + before[4 * x + 1], base_sum + before[4 * x + 2],
-                                   base_sum + before[4 * x + 3]);
+            if (c < n8) {
+                pk16[c ^ 1u] = (uint16_t)packed;   // a stream word is big-endian: its first 8 bases are its high half
+                *reinterpret_cast<uint4 *>(qsum + 8u * c) =
+                    make_uint4(base_sum + before[0], base_sum + before[1], base_sum + before[2], base_sum + before[3]);
+                *reinterpret_cast<uint4 *>(qsum + 8u * c + 4u) =
+                    make_uint4(base_sum + before[4], base_sum + before[5], base_sum + before[6], base_sum + before[7]);
             }
             carry += __shfl(incl, kWave - 1, kWave);
         }
         if (lane == 0) {
-            pk[n16] = 0;                        // the funnel shift of the last k-mers reads one word past the stream
-            qsum[16u * n16] = carry;
+            // the shifts of the last positions read up to two words past the last chunk
+            if (n8 & 1u) pk16[n8 ^ 1u] = 0;
+            pk[(n8 + 1u) >> 1] = 0;
+            pk[((n8 + 1u) >> 1) + 1u] = 0;
+            qsum[8u * n8] = carry;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
-        // k-mers j = 0 .. len-k (views::kmer_hash: size max(len+1,k)-k), 64 per round
+        // q-gram starts p = 0 .. len-q; k-mer j owns the q-grams that start at j .. j+G-1 (q_gram_mapper.h:402-403).
+        // One bitmap bit per q-gram start, a ballot (scalar) per 64 starts; a round of k-mers needs its own ballot
+        // and the next round's first G-1 bits.
         const uint32_t nk = len >= P.k ? len - P.k + 1 : 0;
+        const uint32_t nq = nk ? nk + P.G - 1u : 0;
+        const uint32_t rounds = (nk + kWave - 1u) / kWave;
+        auto ok_ballot = [&](uint32_t rd) -> uint64_t {
+            const uint32_t p = rd * kWave + lane;
+            const uint32_t at = shift + p, lo = at >> 4, r = at & 15u;
+            const uint64_t two = ((uint64_t)pk[lo] << 32) | pk[lo + 1];
+            const uint32_t qg = (uint32_t)(two >> (64u - 2u * r - 2u * P.q)) & P.qbits;
+            const uint32_t word = BITMAP_LDS ? okmap_lds[qg >> 5] : qgram_ok[qg >> 5];
+            return __ballot(p < nq && ((word >> (qg & 31u)) & 1u));
+        };
+        // k-mers j = 0 .. len-k (views::kmer_hash: size max(len+1,k)-k), 64 per round
         uint32_t n_good = 0;
-        for (uint32_t base = 0; base < nk; base += kWave) {
-            const uint32_t j = base + lane;
-            bool good = false;
-            uint32_t h = 0;
-            if (j < nk) {
-                const uint32_t at = shift + j, lo = at >> 4, r = at & 15u;
-                const uint64_t two = ((uint64_t)pk[lo] << 32) | pk[lo + 1];
-                h = (uint32_t)(two >> (64u - 2u * r - 2u * P.k)) & kmask;
-                const uint32_t qs = qsum[at + P.k] - qsum[at];                  // quality_filter.h:611-621 (plain sum)
-                bool dist = false;                                               // q_gram_mapper.h:189-196
-                for (uint32_t g = 0; g < P.G; g++) {
-                    const uint32_t qg = (h >> (2 * g)) & P.qbits;
-                    const uint32_t word = BITMAP_LDS ? okmap_lds[qg >> 5] : qgram_ok[qg >> 5];
-                    dist = dist || ((word >> (qg & 31u)) & 1u);
-                }
-                good = dist && qs >= P.minq;                                     // q_gram_mapper.h:437-438
-            }
+        uint64_t m0 = rounds ? ok_ballot(0) : 0ull;
+        for (uint32_t rd = 0; rd < rounds; rd++) {
+            const uint64_t m1 = (rd + 1u) * kWave < nq ? ok_ballot(rd + 1u) : 0ull;
+            // bit l of dist: some q-gram starting at j .. j+G-1 is highly distinguishable (wave-uniform, scalar)
+            uint64_t dist = m0;
+            for (uint32_t g = 1; g < P.G; g++) dist |= (m0 >> g) | (m1 << (64u - g));
+            const uint32_t j = rd * kWave + lane;
+            const uint32_t at = shift + j, lo = at >> 4, r = at & 15u;
+            const uint64_t two = ((uint64_t)pk[lo] << 32) | pk[lo + 1];
+            const uint32_t h = (uint32_t)(two >> (64u - 2u * r - 2u * P.k)) & kmask;
+            const uint32_t qs = qsum[at + P.k] - qsum[at];                       // quality_filter.h:611-621 (plain sum)
+            const bool good = j < nk && (dist & lane_bit) != 0 && qs >= P.minq;  // q_gram_mapper.h:437-438
             const uint64_t m = __ballot(good);
-            if (good) goodh[n_good + __popcll(m & ((1ull << lane) - 1ull))] = h;   // ascending j
+            if (good) goodh[n_good + __popcll(m & (lane_bit - 1ull))] = h;       // ascending j
             n_good += (uint32_t)__popcll(m);
+            m0 = m1;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -285,7 +328,7 @@ __global__ __launch_bounds__(1024) void bmf_sample_kernel(
         for (uint32_t s = lane; s < P.S; s += kWave) {
             const uint32_t p = pos_table[(size_t)n_good * P.S + s];
             const uint32_t h = goodh[p];
-            const uint32_t hr = hash_reverse_complement(h, P.k);
+            const uint32_t hr = revcomp_fast(h, P.k);
             for (uint32_t g = 0; g < P.G; g++) {
                 const uint32_t g1 = (h >> (2 * g)) & P.qbits, g2 = (hr >> (2 * g)) & P.qbits;
                 const int32_t i1 = g1 < P.n_kmers ? k2i[g1] : -1;   // index_of_kmer, q_gram_mapper.h:374-377

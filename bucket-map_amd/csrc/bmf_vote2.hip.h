@@ -9,7 +9,7 @@
 //                       (q_gram_mapper.h:75-102: it is in no level of the filter).  No live bucket: the
 //                       result is empty, done.  Otherwise the ids of the 128-bucket chunks that still hold a
 //                       live bucket go to HBM (ascending, <= kMaxLive of them) with their number.
-//   bmf_recount_kernel  kMaxLive lanes per item, two items per wave: lane i recounts live chunk i
+//   bmf_recount_kernel  LIVE (16 or 32) lanes per item, 64 / LIVE items per wave: lane i recounts live chunk i
 //                       exactly from its 16-byte column of ALL S*G rows -- after one more lower bound from a
 //                       row per sample that pass 1 has not seen, which kills most chunks that survived
 //                       pass 1 by chance for S sectors instead of S*G -- and the
@@ -32,7 +32,9 @@
 
 namespace bmf {
 
-constexpr int kMaxLive = 32;    // live chunks (= lanes) per item in the recount kernel
+constexpr int kMaxLive = 32;    // most live chunks (= lanes) an item can bring to the recount kernel; the kernel
+                                // comes in a 16-lane form too (4 items per wave: its instruction stream is per wave,
+                                // and only the live chunks' lanes do useful work) -- DevParams::max_live picks
 constexpr int kDepthCol = 16;   // rows in flight in a 16-byte-column stream
 
 constexpr uint32_t kSlowItem = 0xFFFFFFFFu;   // live_n of an item that went to the slow queue
@@ -259,12 +261,12 @@ __device__ __forceinline__ void pass1_item(const DevParams &P, const uint8_t *__
         const bool live = a != 0;
         const uint64_t m = __ballot(live);
         const uint32_t at = n_live + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-        if (live && at < (uint32_t)kMaxLive) Q.live_chunks[(size_t)item * kMaxLive + at] = (uint16_t)cidx[j];
+        if (live && at < P.max_live) Q.live_chunks[(size_t)item * P.max_live + at] = (uint16_t)cidx[j];
         n_live += (uint32_t)__popcll(m);
     }
     if (lane == 0) {
         if (n_live == 0) out_counts[item] = 0;
-        if (n_live > (uint32_t)kMaxLive) {
+        if (n_live > P.max_live) {
             Q.slow_items[atomicAdd(&Q.counters[1], 1u)] = item;
             n_live = kSlowItem;
         }
@@ -283,12 +285,12 @@ __global__ __launch_bounds__(kWave) void bmf_pass1_kernel(DevParams P, const uin
 // best_results (q_gram_mapper.h:90-102,471-476) over the kMaxLive lanes of one item: lane i holds the exact
 // counters of one 128-bucket chunk, chunks ascending with the lane.  Group-wide steps use wave ballots
 // masked to the group, so the two items of a wave need not agree on anything.
-template <int PLANES>
+template <int PLANES, int LIVE>
 __device__ __forceinline__ void emit_best_group(const DevParams &P, const u128 (&cnt)[PLANES], bool have, uint32_t item,
                                                 uint32_t lane, uint32_t chunk, uint32_t *__restrict__ out_counts,
                                                 uint32_t *__restrict__ out_buckets) {
-    const uint32_t gl = lane % kMaxLive;
-    const uint64_t gmask = ((1ull << kMaxLive) - 1ull) << (lane - gl);
+    const uint32_t gl = lane % LIVE;
+    const uint64_t gmask = ((1ull << LIVE) - 1ull) << (lane - gl);
     uint32_t cand[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
     uint32_t m_min = 0;
 #pragma unroll
@@ -304,11 +306,11 @@ __device__ __forceinline__ void emit_best_group(const DevParams &P, const u128 (
     const uint32_t pc = __popc(cand[0]) + __popc(cand[1]) + __popc(cand[2]) + __popc(cand[3]);
     uint32_t incl = pc;
 #pragma unroll
-    for (int o = 1; o < kMaxLive; o <<= 1) {
-        const uint32_t t = __shfl_up(incl, o, kMaxLive);
+    for (int o = 1; o < LIVE; o <<= 1) {
+        const uint32_t t = __shfl_up(incl, o, LIVE);
         if (gl >= (uint32_t)o) incl += t;
     }
-    const uint32_t total = __shfl(incl, kMaxLive - 1, kMaxLive);
+    const uint32_t total = __shfl(incl, LIVE - 1, LIVE);
     if (!have) return;
     if (m_min == (1u << PLANES) - 1u || total > P.max_cand) {   // biased counters: all ones = F misses or more
         if (gl == 0) out_counts[item] = 0;
@@ -377,14 +379,14 @@ __device__ __forceinline__ uint32_t stream_column(const DevParams &P, const uint
 }
 
 // (4 waves per SIMD asked for: at most 128 VGPRs, the latency of the short dependent streams needs the waves)
-template <int PLANES>
+template <int PLANES, int LIVE>
 __global__ __launch_bounds__(kWave, 4) void bmf_recount_kernel(DevParams P, const uint8_t *__restrict__ rows,
                                                            const uint32_t *__restrict__ row_lists, uint32_t n_items,
                                                            uint32_t *__restrict__ out_counts,
                                                            uint32_t *__restrict__ out_buckets, Pass2Queue Q) {
-    extern __shared__ uint32_t lds_lists[];      // the row-id lists of the wave's two items: every lane of a
-    constexpr uint32_t kPerWave = kWave / kMaxLive;   // group reads the same entry at every step
-    const uint32_t lane = threadIdx.x, grp = lane / kMaxLive, gl = lane % kMaxLive;
+    extern __shared__ uint32_t lds_lists[];      // the row-id lists of the wave's items: every lane of a
+    constexpr uint32_t kPerWave = kWave / LIVE;   // group reads the same entry at every step
+    const uint32_t lane = threadIdx.x, grp = lane / LIVE, gl = lane % LIVE;
     const uint32_t n_ids = P.S * P.G;
     uint32_t *list = lds_lists + grp * n_ids;
     uint32_t recounted = 0, loads = 0;
@@ -393,14 +395,14 @@ __global__ __launch_bounds__(kWave, 4) void bmf_recount_kernel(DevParams P, cons
         uint32_t n_live = item < n_items ? Q.live_n[item] : 0u;
         if (n_live == kSlowItem) n_live = 0;
         const bool have = n_live != 0;
-        if (__ballot(have) == 0) continue;       // both results are final already
+        if (__ballot(have) == 0) continue;       // all results are final already
         recounted += (have && gl == 0) ? 1u : 0u;
         __syncthreads();                          // (one wave per block: orders the LDS reuse between rounds)
         if (have)
-            for (uint32_t i = gl; i < n_ids; i += kMaxLive) list[i] = row_lists[(size_t)item * P.list_len + i];
+            for (uint32_t i = gl; i < n_ids; i += LIVE) list[i] = row_lists[(size_t)item * P.list_len + i];
         __syncthreads();
         const bool mine = gl < n_live;
-        const uint32_t chunk = mine ? Q.live_chunks[(size_t)item * kMaxLive + gl] : 0u;
+        const uint32_t chunk = mine ? Q.live_chunks[(size_t)item * LIVE + gl] : 0u;
         u128 cnt[PLANES];
         auto reset = [&](bool on) {
 #pragma unroll
@@ -431,10 +433,10 @@ __global__ __launch_bounds__(kWave, 4) void bmf_recount_kernel(DevParams P, cons
             reset(act);
         }
         loads += stream_column<PLANES>(P, rows, list, 0u, P.G, chunk * 16u, act, cnt);
-        emit_best_group<PLANES>(P, cnt, have, item, lane, chunk, out_counts, out_buckets);
+        emit_best_group<PLANES, LIVE>(P, cnt, have, item, lane, chunk, out_counts, out_buckets);
     }
     // statistics only (bmf_batch_pass2_counts): one atomic per wave, not per item
-    recounted += (uint32_t)__shfl_xor((int)recounted, kMaxLive, kWave);
+    recounted = wave_sum(recounted);
     loads = wave_sum(loads);
     if (lane == 0 && recounted) {
         atomicAdd(&Q.counters[0], recounted);

@@ -52,12 +52,15 @@ def random_case(rng, *, nb, q, k, S, F, max_cand, kmer_frac, density, read_len, 
     assert_same_candidates(c_ref, b_ref, c_1, b_1, "single-pass pruning forced")
     if k > q:
         # the two-pass pruning kernel, forced (the library only picks it for sparse indexes), r rows in pass 1
+        # and either form of the recount kernel (16 or 32 lanes per item), whatever the density model would pick
         os.environ["BMF_PASS1_ROWS"] = str(int(rng.integers(1, k - q + 1)))
+        os.environ["BMF_MAX_LIVE"] = str(int(rng.choice([16, 32])))
         try:
             f2 = bma.Filter(bma.Params(num_buckets=nb, flags=bma.BMF_FLAG_EARLY_EXIT, **kw))
             f2.load_index(rows, k2i)
         finally:
             del os.environ["BMF_PASS1_ROWS"]
+            del os.environ["BMF_MAX_LIVE"]
         assert f2.info()["pass1_rows"] >= 1
         out += list(f2.map_windows(bases, quals, ws, wl))
         f2.close()
