@@ -13,7 +13,7 @@ PKG  = bucket-map_amd
 HOST = $(PKG)/host
 HOST_HDRS = $(wildcard $(HOST)/*.h) include/bmf.h include/bml.h include/bmv.h
 
-PRODUCT = $(PKG)/libbmf.so $(PKG)/libbmhost.so $(PKG)/bucketmap $(PKG)/bucketmap_align
+PRODUCT = $(PKG)/libbmf.so $(PKG)/libbmhost.so $(PKG)/bucketmap $(PKG)/bucketmap_align $(PKG)/mapper_test
 TESTINFRA = oracle/libbm_oracle.so tests/cpp/bucketmap_oracle tests/cpp/bucketmap_align_oracle tests/cpp/umm_order
 
 all: $(PRODUCT) $(TESTINFRA)
@@ -37,6 +37,10 @@ $(PKG)/bucketmap: $(HOST)/main.cpp $(HOST)/make_mapper_gpu.cpp $(HOST_HDRS) $(PK
 # (the reference builds `bucketmap_align` the same way, bucket_map/CMakeLists.txt:138)
 $(PKG)/bucketmap_align: $(HOST)/main.cpp $(HOST)/make_mapper_gpu.cpp $(HOST_HDRS) $(PKG)/libbmf.so
 	$(CXX) $(CXXFLAGS) -DBM_ALIGN -o $@ $(HOST)/main.cpp $(HOST)/make_mapper_gpu.cpp -L$(PKG) -lbmf -Wl,-rpath,'$$ORIGIN'
+
+# the reference's mapper benchmark (mapper_test.cpp): _query_file + _check_ground_truth on the GPU filter
+$(PKG)/mapper_test: $(HOST)/mapper_test.cpp $(HOST_HDRS) $(PKG)/libbmf.so
+	$(CXX) $(CXXFLAGS) -o $@ $(HOST)/mapper_test.cpp -L$(PKG) -lbmf -Wl,-rpath,'$$ORIGIN'
 
 ORACLE_SRC = oracle/bm_oracle.c oracle/bm_locator_oracle.c oracle/bm_align_oracle.c
 ORACLE_HDR = oracle/bm_oracle.h oracle/bm_locator_oracle.h oracle/bm_align_oracle.h

@@ -12,9 +12,11 @@
 #include "bm_genome.h"
 #include "mapper.h"
 
+#include <algorithm>
 #include <chrono>
 #include <cstdlib>
 #include <cstring>
+#include <fstream>
 #include <functional>
 #include <iostream>
 #include <thread>
@@ -200,11 +202,87 @@ public:
                   << static_cast<float>(num_buckets_rev_comp) / mapped_reads << ".\n";
         return std::make_pair(std::move(res_orig), std::move(res_rev_comp));
     }
+
+    // The reference's two benchmark-only entry points (used by bucket_map/mapper_test.cpp:61-63).
+    using query_result_t = std::vector<std::pair<std::vector<unsigned int>, std::vector<unsigned int>>>;
+
+    // q_gram_mapper::_query_file (q_gram_mapper.h:560-578): query_sequence on every whole record -- no windowing, no
+    // truncation, so records longer than the read length the mapper was built for are an error here.
+    query_result_t _query_file(std::filesystem::path const &sequence_file) {
+        query_result_t res;
+        auto t0 = std::chrono::steady_clock::now();
+        std::vector<uint8_t> bases, quals;
+        std::vector<uint64_t> win_start;
+        std::vector<uint32_t> win_len, counts, buckets;
+        auto flush = [&]() {
+            const uint32_t n = static_cast<uint32_t>(win_start.size());
+            if (n == 0) return;
+            counts.resize(2 * static_cast<size_t>(n));
+            buckets.resize(2 * static_cast<size_t>(n) * max_candidates_);
+            if (!index_loaded()) {
+                std::cerr << "[ERROR]\t\tThe q-gram index is empty. Cannot accept query.\n";
+                std::fill(counts.begin(), counts.end(), 0u);
+            } else if (!query_windows(bases.data(), quals.data(), bases.size(), win_start.data(), win_len.data(), n, counts.data(),
+                                      buckets.data())) {
+                throw std::runtime_error("the candidate-bucket filter failed (see the [ERROR] line above)");
+            }
+            for (uint32_t w = 0; w < n; w++) {
+                const uint32_t *bf = buckets.data() + static_cast<size_t>(2 * w) * max_candidates_, *br = bf + max_candidates_;
+                res.emplace_back(std::vector<unsigned int>(bf, bf + counts[2 * w]), std::vector<unsigned int>(br, br + counts[2 * w + 1]));
+            }
+            bases.clear(); quals.clear(); win_start.clear(); win_len.clear();
+        };
+        for_each_fastq(sequence_file.string(), [&](const FastqRecord &rec) {
+            win_start.push_back(bases.size());
+            win_len.push_back(static_cast<uint32_t>(rec.seq.size()));
+            bases.insert(bases.end(), rec.seq.begin(), rec.seq.end());
+            quals.insert(quals.end(), rec.qual.begin(), rec.qual.end());
+            if (win_start.size() >= batch_reads_) flush();
+        });
+        flush();
+        const float time = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count() / 1000.0f;
+        std::cerr << "[BENCHMARK]\tElapsed time for bucket query: " << time << " s (" << time * 1000 * 1000 / res.size() << " μs/seq).\n";
+        return res;
+    }
+
+    // q_gram_mapper::_check_ground_truth (q_gram_mapper.h:580-636): `bucket offset is_rev_comp cigar` per read, as the
+    // read simulator writes its .bucket_ground_truth file.
+    void _check_ground_truth(const query_result_t &query_results, std::filesystem::path const &ground_truth_file) const {
+        std::ifstream is(ground_truth_file);
+        int bucket = 0, exact_location = 0, correct_map = 0, total_bucket_numbers = 0;
+        std::string cigar;
+        bool rev_comp = false;
+        std::vector<int> with_n_buckets(2 * static_cast<size_t>(max_candidates_) + 1, 0);
+        for (const auto &[buckets_orig, buckets_rev_comp] : query_results) {
+            is >> bucket >> exact_location >> rev_comp >> cigar;
+            const auto &own = rev_comp ? buckets_rev_comp : buckets_orig;
+            if (std::find(own.begin(), own.end(), static_cast<unsigned int>(bucket)) != own.end()) correct_map++;
+            total_bucket_numbers += static_cast<int>(buckets_orig.size() + buckets_rev_comp.size());
+            ++with_n_buckets[buckets_orig.size() + buckets_rev_comp.size()];
+        }
+        const float n = static_cast<float>(query_results.size());
+        auto line = [&](const char *what, int v) {
+            std::cerr << "[BENCHMARK]\t" << what << v << " (" << v / n * 100 << "%).\n";
+        };
+        auto up_to = [&](size_t m) {
+            int s = 0;
+            for (size_t i = 1; i <= m && i < with_n_buckets.size(); i++) s += with_n_buckets[i];
+            return s;
+        };
+        std::cerr << "[BENCHMARK]\tTotal number of sequences: " << query_results.size() << ".\n";
+        line("Correct bucket predictions: ", correct_map);
+        std::cerr << "[BENCHMARK]\tAverage number of buckets returned: " << total_bucket_numbers / n << ".\n";
+        line("Number of sequences that have no candidate bucket: ", with_n_buckets[0]);
+        line("Number of uniquely mapped sequences: ", with_n_buckets.size() > 1 ? with_n_buckets[1] : 0);
+        line("Number of sequences mapped to <= 5 buckets: ", up_to(5));
+        line("Number of sequences mapped to <= 10 buckets: ", up_to(10));
+    }
 };
 
 class gpu_q_gram_mapper : public batched_mapper {
     std::vector<bmf_ctx *> ctx_;
     bool loaded_ = false;
+    float distinguishability_ = 0.5f;
 
 protected:
     bool index_loaded() const override { return loaded_; }
@@ -255,6 +333,7 @@ public:
                       std::vector<int> devices = {0}, unsigned int flags = 0)
         : batched_mapper(num_buckets, read_len, num_candidate_buckets, num_segment_samples) {
         (void)bucket_len;
+        distinguishability_ = distinguishability;
         std::cerr << "[INFO]\t\tSet query seed length to be " << static_cast<int>(query_seed_length)
                   << ", and index seed length " << static_cast<int>(index_seed_length) << ".\n";
         bmf_params p{};
@@ -303,6 +382,18 @@ public:
             if (rc != BMF_OK) throw std::runtime_error(std::string("loading the index failed: ") + bmf_last_error());
         }
         loaded_ = true;
+        {   // distinguishability_filter::read's log line (q_gram_mapper.h:171-186): rows with MORE zeros than the threshold
+            uint64_t n_rows = 0;
+            if (bmf_index_download(ctx_[0], nullptr, &n_rows) == BMF_OK && n_rows) {
+                std::vector<uint32_t> zeros(n_rows);
+                if (bmf_index_zeros(ctx_[0], zeros.data()) == BMF_OK) {
+                    const unsigned int threshold = bmf_threshold(distinguishability_, num_buckets_);
+                    const size_t valid = static_cast<size_t>(std::count_if(zeros.begin(), zeros.end(), [&](uint32_t z) { return z > threshold; }));
+                    std::cerr << "[BENCHMARK]\tNumber of Q-grams with distinguishability >= " << static_cast<float>(threshold) / num_buckets_
+                              << ": " << valid << " (" << static_cast<float>(valid) / n_rows * 100 << "%).\n";
+                }
+            }
+        }
         const float s = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count() / 1000.0f;
         std::cerr << "[INFO]\t\tSuccessfully loaded " << (index_directory / (indicator + ".kmers_index")) << ".\n";
         std::cerr << "[BENCHMARK]\tElapsed time for loading index files: " << s << " s.\n";

@@ -181,3 +181,43 @@ def test_sam_identical_with_fracminhash_index(tmp_path):
     gpu_sam = (tmp_path / "gpu.sam").read_bytes()
     assert gpu_sam == (tmp_path / "cpu.sam").read_bytes()
     assert gpu_sam.count(b"\n") > 0.8 * rd.n
+
+
+def test_mapper_test_tool_and_distinguishability_line(tmp_path):
+    """The reference's benchmark-only entry points (_query_file / _check_ground_truth, q_gram_mapper.h:560-636, driven by
+    mapper_test.cpp) and distinguishability_filter::read's log line (:183-185), on the GPU filter."""
+    import re
+    from bucket_map_amd import host
+    g = host.Genome.synth(27, [600_000, 70_000])
+    g.write_fasta(str(tmp_path / "g.fa"))
+    rd = host.Reads(g, 8192, 150, 150, 4000, sub=0.005, seed=13)
+    rd.write_fastq(str(tmp_path / "reads"))
+    common = ["-i", "idx", "--genome", "g.fa", "--bucket-len", "8192", "-r", "150", "-f", "1"]
+    _run(GPU_CLI, ["-x", *common], tmp_path)
+    err = _run(os.path.join(ROOT, "bucket-map_amd", "mapper_test"),
+               [*common, "-q", "reads.fastq", "--ground-truth", "reads.bucket_ground_truth"], tmp_path)
+    m = re.search(r"Number of Q-grams with distinguishability >= ([0-9.]+): (\d+) \(", err)
+    assert m and abs(float(m.group(1)) - 0.5) < 0.01
+    # every row of this index has more zeros than half the buckets except the densest few: count them on the host
+    index = host.Index(g, g.awk_bucket_num(8192), 8192, 150, q=9)
+    nb = g.awk_bucket_num(8192)
+    ones = np.unpackbits(index.rows(), axis=1, bitorder="little")[:, :nb].sum(axis=1)
+    thr = int(np.float32(0.5) * np.float32(nb))
+    assert int(m.group(2)) == int((nb - ones > thr).sum())
+    assert f"Total number of sequences: {rd.n}." in err
+    correct = int(re.search(r"Correct bucket predictions: (\d+) ", err).group(1))
+    assert correct > 0.97 * rd.n
+    for line in ("Elapsed time for bucket query", "Average number of buckets returned", "no candidate bucket",
+                 "uniquely mapped sequences", "mapped to <= 5 buckets", "mapped to <= 10 buckets"):
+        assert line in err
+    # the same numbers from the C ABI directly: source bucket among the candidates of the true strand
+    import bucket_map_amd as bma
+    flt = bma.Filter(bma.Params.from_cli(nb, read_len=150))
+    flt.load_index_ptr(index.rows_ptr, index.num_rows, index.k2i_ptr, index.num_kmers)
+    ws, wl, _, _ = bma.windows_for_reads(rd.offsets, 150)
+    c, b = flt.map_windows(rd.bases, rd.quals, ws, wl)
+    flt.close()
+    s = rd.truth_rc.astype(np.int64)
+    i = np.arange(rd.n)
+    own, valid = b[i, s], np.arange(b.shape[2])[None, :] < c[i, s][:, None]
+    assert correct == int(((own == rd.truth_bucket[:, None]) & valid).any(axis=1).sum())
