@@ -194,8 +194,11 @@ def test_mapper_test_tool_and_distinguishability_line(tmp_path):
     rd.write_fastq(str(tmp_path / "reads"))
     common = ["-i", "idx", "--genome", "g.fa", "--bucket-len", "8192", "-r", "150", "-f", "1"]
     _run(GPU_CLI, ["-x", *common], tmp_path)
+    # _query_file hands WHOLE records to query_sequence (no truncation to -r): reads with insertions are 151+ bases,
+    # so the mapper is built for -r 200 (the index files do not depend on the mapper's -r)
     err = _run(os.path.join(ROOT, "bucket-map_amd", "mapper_test"),
-               [*common, "-q", "reads.fastq", "--ground-truth", "reads.bucket_ground_truth"], tmp_path)
+               ["-i", "idx", "--genome", "g.fa", "--bucket-len", "8192", "-r", "200", "-f", "1", "-q", "reads.fastq",
+                "--ground-truth", "reads.bucket_ground_truth"], tmp_path)
     m = re.search(r"Number of Q-grams with distinguishability >= ([0-9.]+): (\d+) \(", err)
     assert m and abs(float(m.group(1)) - 0.5) < 0.01
     # every row of this index has more zeros than half the buckets except the densest few: count them on the host
@@ -212,9 +215,9 @@ def test_mapper_test_tool_and_distinguishability_line(tmp_path):
         assert line in err
     # the same numbers from the C ABI directly: source bucket among the candidates of the true strand
     import bucket_map_amd as bma
-    flt = bma.Filter(bma.Params.from_cli(nb, read_len=150))
+    flt = bma.Filter(bma.Params.from_cli(nb, read_len=200))
     flt.load_index_ptr(index.rows_ptr, index.num_rows, index.k2i_ptr, index.num_kmers)
-    ws, wl, _, _ = bma.windows_for_reads(rd.offsets, 150)
+    ws, wl, _, _ = bma.windows_for_reads(rd.offsets, 200)
     c, b = flt.map_windows(rd.bases, rd.quals, ws, wl)
     flt.close()
     s = rd.truth_rc.astype(np.int64)
