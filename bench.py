@@ -330,14 +330,14 @@ def main():
     # compacted D2H of the results; the batch goes through in pieces so that the copies of one piece run under
     # the kernels of its neighbours).  From page-locked buffers, as the `bucketmap` tool stages its reads, and
     # from ordinary pageable memory.  Reported for DESIGN.md only; it is never `value`.
-    out_arrays = (np.zeros((len(win_start), 2), np.uint32), np.zeros((len(win_start), 2, params.max_candidates), np.uint32))
+    out_arrays = (np.zeros((len(win_start), 2), np.uint32), np.empty(2 * len(win_start) * params.max_candidates, np.uint32))
 
     def time_map_windows(f, b, q):
-        f.map_windows(b, q, win_start, win_len, out=out_arrays)          # first call allocates
+        f.map_windows_compact(b, q, win_start, win_len, out=out_arrays)          # first call allocates
         best = 1e9
         for _ in range(3):
             t_h = time.perf_counter()
-            f.map_windows(b, q, win_start, win_len, out=out_arrays)
+            f.map_windows_compact(b, q, win_start, win_len, out=out_arrays)
             best = min(best, time.perf_counter() - t_h)
         return best
     pinned_b, pinned_q = bma.pinned_copy(reads.bases), bma.pinned_copy(reads.quals)
@@ -440,8 +440,9 @@ def main():
             "weak_scaling": weak_leg,
             "pcie_inclusive": {"reads_per_s_per_gpu": reads.n / host_pinned_s, "ms": host_pinned_s * 1e3,
                                "ms_pageable": host_buffer_s * 1e3, "reads": int(reads.n),
-                               "what": "bmf_map_windows, host buffers in and out: H2D of the reads, kernels and compacted D2H "
-                                       "pipelined in pieces; page-locked source (ms) and pageable source (ms_pageable)"},
+                               "what": "bmf_map_windows_compact (the entry point the bucketmap tool calls), host buffers in and out: "
+                                       "H2D of the reads, kernels and packed D2H pipelined in pieces; page-locked source (ms) "
+                                       "and pageable source (ms_pageable)"},
         }
 
         # HBM-side traffic of the vote kernel, measured NOW: PMC counters cannot be read in-process, so a child

@@ -1058,8 +1058,9 @@ static uint32_t piece_windows_of(uint32_t n_windows) {
         const long v = strtol(e, nullptr, 10);
         if (v > 0) return (uint32_t)std::min<long>(v, 0x3FFFFFFF);
     }
-    // at least four pieces where the batch allows it, pieces of 8 Ki ... 64 Ki windows
-    return std::min<uint32_t>(65536u, std::max<uint32_t>(8192u, (n_windows + 3u) / 4u));
+    // at least four pieces where the batch allows it, pieces of 8 Ki ... 128 Ki windows (a piece costs the host about
+    // half a millisecond of submissions and unpacking: with the pruning kernels a 64 Ki piece is 1.3 ms of GPU work)
+    return std::min<uint32_t>(131072u, std::max<uint32_t>(8192u, (n_windows + 3u) / 4u));
 }
 
 static int map_slots_init(bmf_ctx *c) {
@@ -1145,8 +1146,17 @@ static int map_piece_issue(bmf_ctx *c, bmf_ctx::MapSlot *sl, const uint8_t *base
     return BMF_OK;
 }
 
-// Waits for the piece in the slot and scatters its results into the caller's arrays.
-static int map_piece_finish(bmf_ctx *c, bmf_ctx::MapSlot *sl, uint32_t *out_counts, uint32_t *out_buckets) {
+// Where the results of a call go: dense (max_candidates slots per list, bmf_map_windows) or packed back to back
+// (bmf_map_windows_compact).
+struct MapOut {
+    uint32_t *counts = nullptr;
+    uint32_t *dense = nullptr;     // [2n x max_candidates], or
+    uint32_t *ids = nullptr;       // the lists one after the other
+    uint64_t ids_cap = 0, ids_used = 0;
+};
+
+// Waits for the piece in the slot and hands its results to the caller's arrays.
+static int map_piece_finish(bmf_ctx *c, bmf_ctx::MapSlot *sl, MapOut &out) {
     HIP_TRY(hipEventSynchronize(sl->landed));
     const size_t n_items = 2 * (size_t)sl->n, mc = c->p.max_candidates;
     const uint32_t *counts = sl->h_out, *ids = sl->h_out + n_items + 1;
@@ -1163,8 +1173,16 @@ static int map_piece_finish(bmf_ctx *c, bmf_ctx::MapSlot *sl, uint32_t *out_coun
         HIP_TRY(hipMemcpy(rest.data(), sl->pack.p + 1, total * sizeof(uint32_t), hipMemcpyDeviceToHost));
         ids = rest.data();
     }
-    uint32_t *oc = out_counts + 2 * (size_t)sl->first, *ob = out_buckets + 2 * (size_t)sl->first * mc;
-    memcpy(oc, counts, n_items * sizeof(uint32_t));
+    memcpy(out.counts + 2 * (size_t)sl->first, counts, n_items * sizeof(uint32_t));
+    if (out.ids) {                  // pieces finish in order: this piece's lists follow the previous piece's
+        if (out.ids_used + total > out.ids_cap)
+            return fail(BMF_ERR_ARG, "ids_capacity %llu is too small (2 * n_windows * max_candidates always suffices)",
+                        (unsigned long long)out.ids_cap);
+        memcpy(out.ids + out.ids_used, ids, total * sizeof(uint32_t));
+        out.ids_used += total;
+        return BMF_OK;
+    }
+    uint32_t *ob = out.dense + 2 * (size_t)sl->first * mc;
     size_t at = 0;
     for (size_t i = 0; i < n_items; i++) {
         for (uint32_t t = 0; t < counts[i]; t++) ob[i * mc + t] = ids[at + t];
@@ -1173,13 +1191,41 @@ static int map_piece_finish(bmf_ctx *c, bmf_ctx::MapSlot *sl, uint32_t *out_coun
     return BMF_OK;
 }
 
+static int map_windows_impl(bmf_ctx *c, const uint8_t *bases, const uint8_t *quals, uint64_t n_bytes,
+                            const uint64_t *win_start, const uint32_t *win_len, uint32_t n_windows, MapOut &out);
+
 int bmf_map_windows(bmf_ctx *c, const uint8_t *bases, const uint8_t *quals, uint64_t n_bytes,
                     const uint64_t *win_start, const uint32_t *win_len, uint32_t n_windows,
                     uint32_t *out_counts, uint32_t *out_buckets) {
     if (!c) return fail(BMF_ERR_ARG, "bmf_map_windows: null context");
+    if (n_windows && (!out_counts || !out_buckets)) return fail(BMF_ERR_ARG, "bmf_map_windows: null output");
+    MapOut out;
+    out.counts = out_counts;
+    out.dense = out_buckets;
+    return map_windows_impl(c, bases, quals, n_bytes, win_start, win_len, n_windows, out);
+}
+
+int bmf_map_windows_compact(bmf_ctx *c, const uint8_t *bases, const uint8_t *quals, uint64_t n_bytes,
+                            const uint64_t *win_start, const uint32_t *win_len, uint32_t n_windows,
+                            uint32_t *out_counts, uint32_t *out_ids, uint64_t ids_capacity, uint64_t *n_ids) {
+    if (!c) return fail(BMF_ERR_ARG, "bmf_map_windows_compact: null context");
+    if (!n_ids || (n_windows && (!out_counts || (!out_ids && ids_capacity))))
+        return fail(BMF_ERR_ARG, "bmf_map_windows_compact: null output");
+    *n_ids = 0;
+    static uint32_t none;           // ids_capacity == 0 with a null pointer: still the compact form
+    MapOut out;
+    out.counts = out_counts;
+    out.ids = out_ids ? out_ids : &none;
+    out.ids_cap = ids_capacity;
+    const int rc = map_windows_impl(c, bases, quals, n_bytes, win_start, win_len, n_windows, out);
+    *n_ids = out.ids_used;
+    return rc;
+}
+
+static int map_windows_impl(bmf_ctx *c, const uint8_t *bases, const uint8_t *quals, uint64_t n_bytes,
+                            const uint64_t *win_start, const uint32_t *win_len, uint32_t n_windows, MapOut &out) {
     if (!c->loaded) return fail(BMF_ERR_STATE, "the q-gram index is empty; cannot accept query");
     if (n_windows == 0) return BMF_OK;
-    if (!out_counts || !out_buckets) return fail(BMF_ERR_ARG, "bmf_map_windows: null output");
     int rc = check_windows(c, bases, quals, n_bytes, win_start, win_len, n_windows);
     if (rc != BMF_OK) return rc;
     HIP_TRY(hipSetDevice(c->p.device));
@@ -1212,7 +1258,7 @@ int bmf_map_windows(bmf_ctx *c, const uint8_t *bases, const uint8_t *quals, uint
         if (p < n_pieces)
             rc = map_piece_issue(c, c->slot[p % bmf_ctx::kMapSlots], bases, quals, win_start, win_len, p * piece,
                                  std::min(piece, n_windows - p * piece), whole);
-        if (rc == BMF_OK && p >= kLag) rc = map_piece_finish(c, c->slot[(p - kLag) % bmf_ctx::kMapSlots], out_counts, out_buckets);
+        if (rc == BMF_OK && p >= kLag) rc = map_piece_finish(c, c->slot[(p - kLag) % bmf_ctx::kMapSlots], out);
     }
     if (rc != BMF_OK) {   // leave nothing in flight that still reads the caller's buffers
         (void)hipStreamSynchronize(c->h2d);

@@ -19,6 +19,7 @@
 #include <fstream>
 #include <functional>
 #include <iostream>
+#include <memory>
 #include <thread>
 
 namespace bm {
@@ -33,11 +34,12 @@ protected:
     unsigned int num_buckets_, read_length_, num_segment_samples_, max_candidates_;
     size_t batch_reads_ = 1u << 18;   // reads per batch: small enough to overlap parsing with the devices
 
-    // query_sequence for n windows (views into bases/quals); counts: 2 per window, buckets:
-    // 2 x max_candidates per window.  Returns false on failure (message already printed).
+    // query_sequence for n windows (views into bases/quals); counts: 2 per window (read as-is, reverse complement),
+    // ids: the candidate lists back to back in that order (resized by the callee).  Returns false on failure
+    // (message already printed).
     virtual bool query_windows(const uint8_t *bases, const uint8_t *quals, uint64_t n_bytes,
                                const uint64_t *win_start, const uint32_t *win_len, uint32_t n, uint32_t *counts,
-                               uint32_t *buckets) = 0;
+                               std::vector<uint32_t> &ids) = 0;
     virtual bool index_loaded() const = 0;
     // staging memory for reads (overridden with pinned memory where a device copies from it)
     virtual uint8_t *host_alloc(size_t bytes) { return static_cast<uint8_t *>(std::malloc(bytes ? bytes : 1)); }
@@ -49,7 +51,7 @@ private:
         size_t cap = 0, n_bytes = 0, n_reads = 0;
         unsigned int first_read = 0;
         std::vector<uint64_t> win_start;
-        std::vector<uint32_t> win_len, win_read, counts, buckets;
+        std::vector<uint32_t> win_len, win_read, counts, ids;
         std::vector<int> win_pos;
         bool ok = true;
     };
@@ -100,18 +102,15 @@ public:
             s.ok = false;
             try {
                 const uint32_t n = static_cast<uint32_t>(s.win_start.size());
-                // only entries below a list's count are ever read back: no need to clear 240 bytes per window per batch
-                s.counts.resize(2 * static_cast<size_t>(n));
-                s.buckets.resize(2 * static_cast<size_t>(n) * max_candidates_);
-                if (!index_loaded()) std::fill(s.counts.begin(), s.counts.end(), 0u);
+                s.counts.assign(2 * static_cast<size_t>(n), 0);
+                s.ids.clear();
                 s.ok = true;
                 if (n == 0) return;
                 if (!index_loaded()) {
                     // q_gram_mapper.h:389-393 (printed once per query in the reference; once per batch here)
                     std::cerr << "[ERROR]\t\tThe q-gram index is empty. Cannot accept query.\n";
                 } else {
-                    s.ok = query_windows(s.bases, s.quals, s.n_bytes, s.win_start.data(), s.win_len.data(), n, s.counts.data(),
-                                         s.buckets.data());
+                    s.ok = query_windows(s.bases, s.quals, s.n_bytes, s.win_start.data(), s.win_len.data(), n, s.counts.data(), s.ids);
                 }
             } catch (const std::exception &e) {
                 std::cerr << "[ERROR]\t\t" << e.what() << "\n";
@@ -123,11 +122,12 @@ public:
             if (!s.ok) throw std::runtime_error("the candidate-bucket filter failed (see the [ERROR] line above)");
             const uint32_t n = static_cast<uint32_t>(s.win_start.size());
             read_mapped.assign(s.n_reads, 0);
+            const uint32_t *next = s.ids.data();
             for (uint32_t w = 0; w < n; w++) {
                 const segment_info_t seg{s.win_read[w], s.win_pos[w]};
                 const uint32_t cf = s.counts[2 * w], cr = s.counts[2 * w + 1];
-                const uint32_t *bf = s.buckets.data() + static_cast<size_t>(2 * w) * max_candidates_;
-                const uint32_t *br = bf + max_candidates_;
+                const uint32_t *bf = next, *br = next + cf;
+                next += cf + cr;
                 for (uint32_t i = 0; i < cf; i++) res_orig[bf[i]].push_back(seg);
                 for (uint32_t i = 0; i < cr; i++) res_rev_comp[br[i]].push_back(seg);
                 if (cf || cr) {
@@ -213,22 +213,22 @@ public:
         auto t0 = std::chrono::steady_clock::now();
         std::vector<uint8_t> bases, quals;
         std::vector<uint64_t> win_start;
-        std::vector<uint32_t> win_len, counts, buckets;
+        std::vector<uint32_t> win_len, counts, ids;
         auto flush = [&]() {
             const uint32_t n = static_cast<uint32_t>(win_start.size());
             if (n == 0) return;
-            counts.resize(2 * static_cast<size_t>(n));
-            buckets.resize(2 * static_cast<size_t>(n) * max_candidates_);
+            counts.assign(2 * static_cast<size_t>(n), 0);
+            ids.clear();
             if (!index_loaded()) {
                 std::cerr << "[ERROR]\t\tThe q-gram index is empty. Cannot accept query.\n";
-                std::fill(counts.begin(), counts.end(), 0u);
-            } else if (!query_windows(bases.data(), quals.data(), bases.size(), win_start.data(), win_len.data(), n, counts.data(),
-                                      buckets.data())) {
+            } else if (!query_windows(bases.data(), quals.data(), bases.size(), win_start.data(), win_len.data(), n, counts.data(), ids)) {
                 throw std::runtime_error("the candidate-bucket filter failed (see the [ERROR] line above)");
             }
+            const uint32_t *next = ids.data();
             for (uint32_t w = 0; w < n; w++) {
-                const uint32_t *bf = buckets.data() + static_cast<size_t>(2 * w) * max_candidates_, *br = bf + max_candidates_;
-                res.emplace_back(std::vector<unsigned int>(bf, bf + counts[2 * w]), std::vector<unsigned int>(br, br + counts[2 * w + 1]));
+                const uint32_t *bf = next, *br = next + counts[2 * w];
+                next = br + counts[2 * w + 1];
+                res.emplace_back(std::vector<unsigned int>(bf, br), std::vector<unsigned int>(br, next));
             }
             bases.clear(); quals.clear(); win_start.clear(); win_len.clear();
         };
@@ -281,6 +281,8 @@ public:
 
 class gpu_q_gram_mapper : public batched_mapper {
     std::vector<bmf_ctx *> ctx_;
+    std::vector<std::unique_ptr<uint32_t[]>> ids_buf_;   // per device: the packed candidate lists of its window range
+    std::vector<uint64_t> ids_cap_;
     bool loaded_ = false;
     float distinguishability_ = 0.5f;
 
@@ -294,18 +296,23 @@ protected:
     void host_free(uint8_t *p) override { bmf_pinned_free(p); }
 
     bool query_windows(const uint8_t *bases, const uint8_t *quals, uint64_t n_bytes, const uint64_t *win_start,
-                       const uint32_t *win_len, uint32_t n, uint32_t *counts, uint32_t *buckets) override {
+                       const uint32_t *win_len, uint32_t n, uint32_t *counts, std::vector<uint32_t> &ids) override {
         const size_t D = ctx_.size();
         std::vector<int> rc(D, BMF_OK);
         std::vector<std::string> msg(D);
-        // every context is handed the shared buffers and ITS window range: bmf_map_windows uploads only the byte
-        // span those windows cover
+        std::vector<uint64_t> used(D, 0);
+        // every context is handed the shared buffers and ITS window range: bmf_map_windows_compact uploads only the
+        // byte span those windows cover, and packs the range's candidate lists into the device's own buffer
         auto work = [&](size_t d) {
             const uint32_t w0 = static_cast<uint32_t>(static_cast<uint64_t>(n) * d / D);
             const uint32_t w1 = static_cast<uint32_t>(static_cast<uint64_t>(n) * (d + 1) / D);
-            rc[d] = bmf_map_windows(ctx_[d], bases, quals, n_bytes, win_start + w0, win_len + w0, w1 - w0,
-                                    counts + 2 * static_cast<size_t>(w0),
-                                    buckets + 2 * static_cast<size_t>(w0) * max_candidates_);
+            const uint64_t cap = 2ull * (w1 - w0) * max_candidates_;
+            if (cap > ids_cap_[d]) {   // uninitialised on purpose: a worst case of 240 bytes per window, mostly never touched
+                ids_buf_[d].reset(new uint32_t[cap]);
+                ids_cap_[d] = cap;
+            }
+            rc[d] = bmf_map_windows_compact(ctx_[d], bases, quals, n_bytes, win_start + w0, win_len + w0, w1 - w0,
+                                            counts + 2 * static_cast<size_t>(w0), ids_buf_[d].get(), cap, &used[d]);
             if (rc[d] != BMF_OK) msg[d] = bmf_last_error();
         };
         if (D == 1) {
@@ -320,6 +327,7 @@ protected:
                 std::cerr << "[ERROR]\t\tGPU " << d << ": " << msg[d] << "\n";
                 return false;
             }
+        for (size_t d = 0; d < D; d++) ids.insert(ids.end(), ids_buf_[d].get(), ids_buf_[d].get() + used[d]);   // contiguous ranges: device order is window order
         return true;
     }
 
@@ -358,6 +366,8 @@ public:
             }
             ctx_.push_back(c);
         }
+        ids_buf_.resize(ctx_.size());
+        ids_cap_.assign(ctx_.size(), 0);
     }
 
     ~gpu_q_gram_mapper() override {

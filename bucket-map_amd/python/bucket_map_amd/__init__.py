@@ -58,6 +58,8 @@ SYMBOLS = {
     "bmf_index_zeros": (C.c_int, [C.c_void_p, _u32p]),
     "bmf_window_starts": (C.c_uint32, [C.c_uint32, C.c_uint32, C.c_uint32, _u32p]),
     "bmf_map_windows": (C.c_int, [C.c_void_p, _u8p, _u8p, C.c_uint64, _u64p, _u32p, C.c_uint32, _u32p, _u32p]),
+    "bmf_map_windows_compact": (C.c_int, [C.c_void_p, _u8p, _u8p, C.c_uint64, _u64p, _u32p, C.c_uint32, _u32p, _u32p,
+                                          C.c_uint64, _u64p]),
     "bmf_batch_create": (C.c_int, [C.c_void_p, _u8p, _u8p, C.c_uint64, _u64p, _u32p, C.c_uint32,
                                    C.POINTER(C.c_void_p)]),
     "bmf_batch_run": (C.c_int, [C.c_void_p, C.c_void_p]),
@@ -335,6 +337,23 @@ class Filter:
                                      _ptr(win_start, _u64p), _ptr(win_len, _u32p), n,
                                      _ptr(counts, _u32p), _ptr(buckets, _u32p)))
         return counts, buckets
+
+    def map_windows_compact(self, bases, quals, win_start, win_len, out=None):
+        """Same, packed: (counts[n,2], ids) with the lists back to back in window order.  `out` = (counts, ids buffer)
+        to reuse; the ids come back as a view of the buffer."""
+        bases = np.ascontiguousarray(bases, dtype=np.uint8)
+        quals = np.ascontiguousarray(quals, dtype=np.uint8)
+        win_start = np.ascontiguousarray(win_start, dtype=np.uint64)
+        win_len = np.ascontiguousarray(win_len, dtype=np.uint32)
+        n = len(win_start)
+        if out is None:
+            out = (np.zeros((n, 2), dtype=np.uint32), np.empty(2 * n * self.params.max_candidates, dtype=np.uint32))
+        counts, ids = out
+        used = C.c_uint64()
+        _check(lib().bmf_map_windows_compact(self._h, _ptr(bases, _u8p), _ptr(quals, _u8p), len(bases), _ptr(win_start, _u64p),
+                                             _ptr(win_len, _u32p), n, _ptr(counts, _u32p), _ptr(ids, _u32p), ids.size,
+                                             C.byref(used)))
+        return counts, ids[: used.value]
 
     def batch(self, bases, quals, win_start, win_len) -> Batch:
         return Batch(self, bases, quals, win_start, win_len)

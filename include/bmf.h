@@ -131,6 +131,14 @@ int  bmf_map_windows(bmf_ctx *ctx, const uint8_t *bases, const uint8_t *quals, u
                      const uint64_t *win_start, const uint32_t *win_len, uint32_t n_windows,
                      uint32_t *out_counts, uint32_t *out_buckets);
 
+/* Same computation, packed output -- what the host mapper uses: the lists hold < 1 id on average, so
+ * max_candidates slots per list is mostly air.  out_counts as above; out_ids receives the lists back to back in
+ * window order (read as-is, then reverse complement, per window), *n_ids their total.  ids_capacity is the room
+ * in out_ids; 2 * n_windows * max_candidates always suffices (BMF_ERR_ARG when it was too small). */
+int  bmf_map_windows_compact(bmf_ctx *ctx, const uint8_t *bases, const uint8_t *quals, uint64_t n_bytes,
+                             const uint64_t *win_start, const uint32_t *win_len, uint32_t n_windows,
+                             uint32_t *out_counts, uint32_t *out_ids, uint64_t ids_capacity, uint64_t *n_ids);
+
 /* Device-resident form (benchmarks, pipelines): upload once, run many times, download when needed. */
 int  bmf_batch_create(bmf_ctx *ctx, const uint8_t *bases, const uint8_t *quals, uint64_t n_bytes,
                       const uint64_t *win_start, const uint32_t *win_len, uint32_t n_windows, bmf_batch **out);

@@ -33,6 +33,10 @@ def _compare(case, n=None, what=""):
     c_ref, b_ref, rows_ref = oracle_map_windows(ix, rd.bases, rd.quals, ws, wl)
     c_got, b_got = flt.map_windows(rd.bases, rd.quals, ws, wl)
     assert_same_candidates(c_ref, b_ref, c_got, b_got, what)
+    # the packed form of the same call (what the host mapper uses): same counts, the lists back to back
+    c_pk, ids = flt.map_windows_compact(rd.bases, rd.quals, ws, wl)
+    assert np.array_equal(c_pk, c_ref)
+    assert np.array_equal(ids, b_ref[np.arange(b_ref.shape[-1])[None, None, :] < c_ref[:, :, None]])
     # the opt-in early exit must not change a single output
     fe = case.gpu_filter(flags=bma.BMF_FLAG_EARLY_EXIT)
     c_e, b_e = fe.map_windows(rd.bases, rd.quals, ws, wl)
@@ -298,6 +302,20 @@ def test_error_behaviour():
     flt.close()
     with pytest.raises(bma.BmfError):
         bma.Filter(bma.Params.from_cli(17_000_000))  # NB > 16 777 216 unsupported
+    # packed output with too little room for the ids: an error, not an overrun
+    flt = bma.Filter(p)
+    rows[:] = 0xFF                                   # every bucket hits every sample: 2 x 30 ids per window
+    flt.load_index(rows, np.arange(4 ** 9, dtype=np.int32))
+    flt2 = bma.Filter(bma.Params(num_buckets=20, read_len=50))
+    flt2.load_index(np.full((4 ** 9, 3), 0xFF, np.uint8), np.arange(4 ** 9, dtype=np.int32))
+    c, ids = flt2.map_windows_compact(bases, quals, ws, wl)
+    assert c.tolist() == [[20, 20]] and ids.tolist() == list(range(20)) * 2
+    with pytest.raises(bma.BmfError) as e:
+        flt2.map_windows_compact(bases, quals, ws, wl, out=(np.zeros((1, 2), np.uint32), np.zeros(39, np.uint32)))
+    assert e.value.code == bma.BMF_ERR_ARG
+    c, ids = flt.map_windows_compact(bases, quals, ws, wl)   # 100 buckets tie: more than 30 -> cleared, nothing to pack
+    assert c.sum() == 0 and len(ids) == 0
+    flt.close(); flt2.close()
 
 
 def test_zeros_match_oracle(ecoli_like):
