@@ -85,7 +85,8 @@ def live_pmc_traffic(args, log):
     out = tempfile.mkdtemp(prefix="bm_pmc_", dir="/tmp")
     cmd = [exe, "--pmc", "FETCH_SIZE", "--output-format", "csv", "-d", out, "--", sys.executable, os.path.abspath(__file__),
            "--pmc-child", "--workload", args.workload, "--params", args.params, "--kmer-frac", str(args.kmer_frac),
-           "--reads", str(args.reads), "--total-bp", str(args.total_bp), "--host-threads", str(args.host_threads)]
+           "--reads", str(args.reads), "--total-bp", str(args.total_bp), "--bucket-len", str(args.bucket_len),
+           "--host-threads", str(args.host_threads)]
     t0 = time.perf_counter()
     try:
         r = subprocess.run(cmd, cwd="/tmp", env={**os.environ, "TMPDIR": "/tmp"}, capture_output=True, text=True, timeout=600)
@@ -123,6 +124,7 @@ def pmc_child(args):
     total_bp, bucket_len, read_len, n_reads = WORKLOADS[args.workload]
     n_reads = args.reads or n_reads
     total_bp = args.total_bp or total_bp
+    bucket_len = args.bucket_len or bucket_len
     threads = args.host_threads or usable_cores()
     cli = (dict(index_seed=9, query_seed=14, read_len=read_len, mapper_samples=20, max_error_rate=0.6, distinguishability=0.5,
                 average_base_quality=10) if args.params == "bench" else
@@ -163,6 +165,7 @@ def main():
     ap.add_argument("--workload", default="egu", choices=sorted(WORKLOADS))
     ap.add_argument("--reads", type=int, default=0, help="reads per GPU (default: the workload's)")
     ap.add_argument("--total-bp", type=int, default=0, help="override the workload's genome size (other NB geometries)")
+    ap.add_argument("--bucket-len", type=int, default=0, help="override the workload's bucket length (other NB geometries)")
     ap.add_argument("--params", default="default", choices=["default", "bench"],
                     help="default = CLI defaults (k12 q9 S15 F6); bench = benchmark_map.sh (-s 20 -e 0.6 -l 14 -b 10)")
     ap.add_argument("--cpu-sample", type=int, default=200000, help="reads timed on the CPU oracle (0 = skip)")
@@ -221,6 +224,8 @@ def main():
         n_reads = args.reads
     if args.total_bp:
         total_bp = args.total_bp
+    if args.bucket_len:
+        bucket_len = args.bucket_len
     threads = args.host_threads or max(1, usable_cores() // world)
     if args.params == "bench":
         cli = dict(index_seed=9, query_seed=14, read_len=read_len, mapper_samples=20, max_error_rate=0.6,
@@ -461,7 +466,7 @@ def main():
                 for e in pmc.get("entries", [pmc]):
                     if (e.get("workload") == args.workload and e.get("params") == args.params
                             and e.get("reads") == int(n_mine) and not args.early_exit and args.kmer_frac == 1.0
-                            and not args.total_bp):
+                            and not args.total_bp and not args.bucket_len):
                         result["roofline"]["traffic"] = e["vote_kernel_traffic_bytes"]
                         result["roofline"]["traffic_source"] = "NOT measured in this run; committed pass " + e["source"]
             except (OSError, ValueError, KeyError):

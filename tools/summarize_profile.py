@@ -19,7 +19,8 @@ src, tag, workload, params, reads = sys.argv[1], sys.argv[2], sys.argv[3], sys.a
 root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 dst = os.path.join(root, "profiles", tag)
 os.makedirs(dst, exist_ok=True)
-stem = f"bench_{workload}_{params}"
+name = os.path.basename(os.path.normpath(src)).split(tag + "_", 1)[-1]   # prof_<tag>_<name>
+stem = "bench_" + name
 OURS = ("bmf::", "bmi::", "bml::", "bmv::")
 
 
@@ -60,6 +61,12 @@ for d in ("pmc_fetch", "pmc_l2"):
         summary.setdefault(k, {})[c] = {"grid_threads": top, "dispatches": len(vals), "mean": sum(vals) / len(vals), "per_dispatch": vals}
 json.dump(summary, open(os.path.join(dst, stem + "_pmc_summary.json"), "w"), indent=1)
 
+for fname in ("bench_kt.json", "bench_pmc.json"):      # the bench lines of the profiled runs themselves
+    p = os.path.join(src, fname)
+    if os.path.exists(p) and open(p).read().strip():
+        line = open(p).read().strip().splitlines()[-1]
+        open(os.path.join(dst, f"{stem}_{fname.replace('bench_', '')}"), "w").write(line + "\n")
+
 # the headline kernel: the vote kernel without pruning (template arguments ..., false, false>)
 vote = next(k for k in summary if "bmf_vote_kernel" in k and k.rstrip().endswith("false, false>"))
 fetch_kib = summary[vote]["FETCH_SIZE"]["mean"]
@@ -82,6 +89,9 @@ for k in summary:
         latest.setdefault("pruning_kernels_traffic_bytes", {})[k] = int(kib * 1024 * 2)
     elif "bmf_recount_kernel" in k or "bmf_vote2_slow_kernel" in k:
         latest.setdefault("pruning_kernels_traffic_bytes", {})[k] = int(kib * 1024)
+print(json.dumps(latest, indent=1))
+if name != f"{workload}_{params}":      # a one-off geometry (extra bench flags): not what bench.py's default run is
+    sys.exit(0)
 path = os.path.join(root, "profiles", "pmc_latest.json")
 try:
     table = json.load(open(path))
@@ -91,9 +101,3 @@ except (OSError, ValueError):
     table = {"entries": []}
 table["entries"] = [e for e in table["entries"] if (e.get("workload"), e.get("params")) != (workload, params)] + [latest]
 json.dump(table, open(path, "w"), indent=1)
-print(json.dumps(latest, indent=1))
-for name in ("bench_kt.json", "bench_pmc.json"):
-    p = os.path.join(src, name)
-    if os.path.exists(p):
-        line = open(p).read().strip().splitlines()[-1]
-        open(os.path.join(dst, f"{stem}_{name.replace('bench_', '')}"), "w").write(line + "\n")
