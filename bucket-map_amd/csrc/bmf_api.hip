@@ -301,6 +301,10 @@ int bmf_create(const bmf_params *params, bmf_ctx **out) {
     int planes = 0;
     while (((1u << planes) - 1u) < p.num_fault) planes++;
     if (planes < 2) planes = 2;
+    if (const char *env = getenv("BMF_MIN_PLANES")) {   // experiments: a wider counter than F needs (same outputs)
+        const int v = atoi(env);
+        if (v >= 2 && v <= 5 && v > planes) planes = v;
+    }
 
     int n_dev = 0;
     HIP_TRY(hipGetDeviceCount(&n_dev));

@@ -68,7 +68,7 @@ for fname in ("bench_kt.json", "bench_pmc.json"):      # the bench lines of the 
         open(os.path.join(dst, f"{stem}_{fname.replace('bench_', '')}"), "w").write(line + "\n")
 
 # the headline kernel: the vote kernel without pruning (template arguments ..., false, false>)
-vote = next(k for k in summary if "bmf_vote_kernel" in k and k.rstrip().endswith("false, false>"))
+vote = next(k for k in summary if "bmf_vote_kernel" in k and k.rstrip().endswith("false>"))   # PRUNE = false
 fetch_kib = summary[vote]["FETCH_SIZE"]["mean"]
 latest = {
     "workload": workload, "params": params, "reads": reads, "kernel": vote,
