@@ -192,6 +192,7 @@ struct bmf_batch {
     DevBuf<uint32_t> slice_min, slice_cnt, slice_ids;   // NB > 65 536 only
     DevBuf<uint32_t> q_counters, q_slow, q_live_n;   // two-pass pruning only (bmf::Pass2Queue)
     DevBuf<uint16_t> q_live_chunks;
+    DevBuf<uint4> q_live_mask;
 };
 
 struct bmf_ctx {
@@ -503,7 +504,7 @@ static void release_batch(bmf_batch *b) {
     b->lists.release(); b->list_n.release(); b->rows_anded.release(); b->counts.release(); b->buckets.release();
     b->offsets.release(); b->compact.release();
     b->slice_min.release(); b->slice_cnt.release(); b->slice_ids.release();
-    b->q_counters.release(); b->q_slow.release(); b->q_live_n.release(); b->q_live_chunks.release();
+    b->q_counters.release(); b->q_slow.release(); b->q_live_n.release(); b->q_live_chunks.release(); b->q_live_mask.release();
 }
 
 static void free_map_slots(bmf_ctx *c) {
@@ -885,6 +886,7 @@ static hipError_t batch_reserve(bmf_ctx *c, bmf_batch *b, size_t n, size_t n_byt
         ok(b->q_slow.need(2 * n));
         ok(b->q_live_n.need(2 * n));
         ok(b->q_live_chunks.need(2 * n * bmf::kMaxLive));
+        ok(b->q_live_mask.need(2 * n * c->dp.max_live));
     }
     return e;
 }
@@ -947,8 +949,9 @@ static int launch_filter(bmf_ctx *c, bmf_batch *b, const uint8_t *d_bases, const
         HIP_TRY(b->q_slow.need(n_items));
         HIP_TRY(b->q_live_n.need(n_items));
         HIP_TRY(b->q_live_chunks.need(n_items * bmf::kMaxLive));
+        HIP_TRY(b->q_live_mask.need(n_items * c->dp.max_live));
         HIP_TRY(hipMemsetAsync(b->q_counters.p, 0, 4 * sizeof(uint32_t), c->stream));
-        const bmf::Pass2Queue q{b->q_counters.p, b->q_slow.p, b->q_live_n.p, b->q_live_chunks.p};
+        const bmf::Pass2Queue q{b->q_counters.p, b->q_slow.p, b->q_live_n.p, b->q_live_chunks.p, b->q_live_mask.p};
         hipLaunchKernelGGL(c->two_pass.pass1, dim3(2 * b->n_windows), dim3(bmf::kWave), 0, c->stream, c->dp, c->d_rows,
                            b->lists.p, b->list_n.p, b->counts.p, q);
         // fixed grids: the recount walks all items (most keep a few live chunks), the slow kernel strides over

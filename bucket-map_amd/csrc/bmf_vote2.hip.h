@@ -44,7 +44,8 @@ struct Pass2Queue {
                                 // [2] 16-byte column loads bmf_recount_kernel issued (statistics: one 64-byte sector each)
     uint32_t *slow_items;
     uint32_t *live_n;           // per item: live chunks after pass 1 (0: result already final), or kSlowItem
-    uint16_t *live_chunks;      // per item: kMaxLive chunk ids, ascending
+    uint16_t *live_chunks;      // per item: max_live chunk ids, ascending
+    uint4 *live_mask;           // per live chunk: which of its 128 buckets were still below F misses after pass 1
 };
 
 // Counters in this file are BIASED: a bucket starts at 2^PLANES-1-F instead of 0, so that "F misses or more"
@@ -261,7 +262,12 @@ __device__ __forceinline__ void pass1_item(const DevParams &P, const uint8_t *__
         const bool live = a != 0;
         const uint64_t m = __ballot(live);
         const uint32_t at = n_live + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-        if (live && at < P.max_live) Q.live_chunks[(size_t)item * P.max_live + at] = (uint16_t)cidx[j];
+        if (live && at < P.max_live) {
+            Q.live_chunks[(size_t)item * P.max_live + at] = (uint16_t)cidx[j];
+            Q.live_mask[(size_t)item * P.max_live + at] =
+                make_uint4(alive_word<CPL, PLANES>(cnt, j, 0), alive_word<CPL, PLANES>(cnt, j, 1),
+                           alive_word<CPL, PLANES>(cnt, j, 2), alive_word<CPL, PLANES>(cnt, j, 3));
+        }
         n_live += (uint32_t)__popcll(m);
     }
     if (lane == 0) {
@@ -329,19 +335,19 @@ __device__ __forceinline__ void emit_best_group(const DevParams &P, const u128 (
     if (gl == 0) out_counts[item] = total;
 }
 
-// S*r rows of a 16-byte column per lane -- rows g0 .. g0+r-1 of every sample; every lane has its own row-id
-// list (its item's).
+// Rows of a 16-byte column per lane -- rows g0 .. g0+r-1 of the samples s0 .. s1-1; every lane has its own row-id
+// list (its item's).  The counters carry on from what they hold.
 template <int PLANES>
 __device__ __forceinline__ uint32_t stream_column(const DevParams &P, const uint8_t *__restrict__ rows,
                                                   const uint32_t *__restrict__ list, uint32_t g0, uint32_t r, uint32_t off,
-                                                  bool act, u128 (&cnt)[PLANES]) {
-    const uint32_t n_rows = P.S * r;
+                                                  bool act, u128 (&cnt)[PLANES], uint32_t s0, uint32_t s1) {
+    const uint32_t n_rows = (s1 - s0) * r;
     u128 ring[kDepthCol];
 #pragma unroll
     for (int d = 0; d < kDepthCol; d++)
 #pragma unroll
         for (int x = 0; x < 4; x++) ring[d].v[x] = 0;
-    uint32_t ps = 0, pg = 0;
+    uint32_t ps = s0, pg = 0;
     auto fetch = [&](u128 &dst) {
         if (act) dst = load_chunk(rows + (size_t)list[ps * P.G + g0 + pg] * P.pitch + off);
         if (++pg == r) {
@@ -416,23 +422,28 @@ __global__ __launch_bounds__(kWave, 4) void bmf_recount_kernel(DevParams P, cons
         bool act = mine;
         // First one row per sample that pass 1 has NOT seen, on its own: its miss count is an independent lower
         // bound, so a chunk that survived pass 1 by chance (probability ~1e-4 per bucket) dies here with the
-        // same odds, for S sectors instead of G*S.  Not worth a dependent round of loads when there is next
-        // to nothing to kill.
+        // same odds, for at most S sectors instead of G*S.  Only the buckets pass 1 left alive matter (its mask), so
+        // the stream is cut in two: after F + 2 samples three chunks in four are already dead and skip the rest.
+        // Not worth a dependent round of loads when there is next to nothing to kill.
         if (P.pass1_rows + 1u < P.G) {
             const bool thin = mine && n_live > 3u;
-            loads += stream_column<PLANES>(P, rows, list, P.pass1_rows, 1u, chunk * 16u, thin, cnt);
-            if (thin) {
+            uint4 mask = make_uint4(0, 0, 0, 0);
+            if (thin) mask = Q.live_mask[(size_t)item * LIVE + gl];
+            auto still_alive = [&]() {
                 u128 c1[PLANES][1];
 #pragma unroll
                 for (int p = 0; p < PLANES; p++) c1[p][0] = cnt[p];
-                uint32_t a = 0;
-#pragma unroll
-                for (int x = 0; x < 4; x++) a |= alive_word<1, PLANES>(c1, 0, x);
-                act = a != 0;
-            }
+                return ((alive_word<1, PLANES>(c1, 0, 0) & mask.x) | (alive_word<1, PLANES>(c1, 0, 1) & mask.y) |
+                        (alive_word<1, PLANES>(c1, 0, 2) & mask.z) | (alive_word<1, PLANES>(c1, 0, 3) & mask.w)) != 0;
+            };
+            const uint32_t s_cut = min(P.S, P.F + 2u);
+            loads += stream_column<PLANES>(P, rows, list, P.pass1_rows, 1u, chunk * 16u, thin, cnt, 0u, s_cut);
+            const bool more = thin && still_alive();
+            loads += stream_column<PLANES>(P, rows, list, P.pass1_rows, 1u, chunk * 16u, more, cnt, s_cut, P.S);
+            if (thin) act = more && still_alive();
             reset(act);
         }
-        loads += stream_column<PLANES>(P, rows, list, 0u, P.G, chunk * 16u, act, cnt);
+        loads += stream_column<PLANES>(P, rows, list, 0u, P.G, chunk * 16u, act, cnt, 0u, P.S);
         emit_best_group<PLANES, LIVE>(P, cnt, have, item, lane, chunk, out_counts, out_buckets);
     }
     // statistics only (bmf_batch_pass2_counts): one atomic per wave, not per item
