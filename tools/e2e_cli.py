@@ -25,6 +25,9 @@ ap.add_argument("--out", default="")
 ap.add_argument("--extra", default="", help="extra CLI flags, e.g. '--early-exit'")
 ap.add_argument("--align", action="store_true", help="run bucketmap_align (alignment verification + CIGAR)")
 ap.add_argument("--kmer-frac", default="1", help="-f of the index (the reference's default is 0.25)")
+ap.add_argument("--bucket-len", type=int, default=0, help="override the workload's bucket length (BASELINE configs[4]: 262144)")
+ap.add_argument("--index-seed", default="", help="-k of the index (default 9; 262144-bp buckets of a uniform genome need 10)")
+ap.add_argument("--gpus", default="", help="--gpus of the tool, e.g. 0,0,0")
 ap.add_argument("--long", action="store_true",
                 help="the reference's long-read profile (benchmark/long_read/benchmark_map.sh:25): 10-kbp ONT-like reads "
                      "(sub 0.03, ins = del 0.025), -s 30 -e 0.9 -n 0.1 -l 12 -p 20 -u 5; the workload's 65536-bp buckets "
@@ -33,6 +36,9 @@ ap.add_argument("--long", action="store_true",
 args = ap.parse_args()
 
 total_bp, bucket_len, read_len, _ = bench.WORKLOADS[args.workload]
+bucket_len = args.bucket_len or bucket_len
+if args.long:
+    read_len = 300              # the long-read script keeps the default -r 300: reads are cut into 5 windows of 300
 sim_len, err, profile = read_len, {}, []
 if args.long:
     sim_len = 10000
@@ -48,14 +54,18 @@ def say(msg):
 
 
 t = time.perf_counter()
-lens = [total_bp] if args.workload in ("ecoli", "mini") else bench.egu_like_record_lengths(total_bp)
-g = host.Genome.synth(20240001, lens)
+lens = [total_bp] if args.workload == "mini" else bench.workload_record_lengths(args.workload, total_bp)
+g = host.Genome.synth(20240001, lens, 16)
 g.write_fasta(os.path.join(args.dir, "g.fa"))
-rd = host.Reads(g, bucket_len, read_len, sim_len, args.reads, seed=20240003, **err)
+rd = host.Reads(g, bucket_len, read_len, sim_len, args.reads, seed=20240003, threads=16, **err)
 rd.write_fastq(os.path.join(args.dir, "reads"))
 say(f"[e2e] inputs written in {time.perf_counter() - t:.1f} s ({g.total_length()} bp, {rd.n} reads)")
 exe = os.path.join(ROOT, "bucket-map_amd", "bucketmap")
 common = ["-i", "idx", "--genome", "g.fa", "--bucket-len", str(bucket_len), "-r", str(read_len), "-f", args.kmer_frac, *profile]
+if args.index_seed:
+    common += ["-k", args.index_seed]
+if args.gpus:
+    common += ["--gpus", args.gpus]
 for f in ("idx.qgram", "idx.kmers_index", "idx.bucket_id", "out.sam"):
     p = os.path.join(args.dir, f)
     if os.path.exists(p):
