@@ -17,6 +17,7 @@
 #include "mapper.h"
 
 #include <algorithm>
+#include <array>
 #include <atomic>
 #include <chrono>
 #include <iostream>
@@ -193,9 +194,14 @@ private:
     // SEQ as seqan3 writes a dna4 vector: the reads were folded to A/C/G/T when they were parsed
     // (_phred94_traits, utils.h:192-204), so N / IUPAC / lower case never reach the SAM file.
     static void append_dna4(std::string &out, std::string_view seq) {
+        static const std::array<char, 256> fold = [] {
+            std::array<char, 256> t{};
+            for (int c = 0; c < 256; c++) t[static_cast<size_t>(c)] = dna4_char(dna4_rank(static_cast<uint8_t>(c)));
+            return t;
+        }();
         const size_t at = out.size();
         out.resize(at + seq.size());
-        for (size_t i = 0; i < seq.size(); i++) out[at + i] = dna4_char(dna4_rank(static_cast<uint8_t>(seq[i])));
+        for (size_t i = 0; i < seq.size(); i++) out[at + i] = fold[static_cast<uint8_t>(seq[i])];
     }
 
 public:
