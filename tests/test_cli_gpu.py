@@ -90,6 +90,24 @@ def test_gpu_index_writes_identical_files(tmp_path, frac):
         assert (tmp_path / f"gpu.{ext}").read_bytes() == (tmp_path / f"host.{ext}").read_bytes(), ext
 
 
+def test_gpu_index_is_not_bound_by_the_mappers_limits(tmp_path):
+    # index-only runs must not inherit the mapper's limits: -r beyond 16 384 (the filter's longest window) and a
+    # query seed far from the index seed (k - q + 1 > 8) still build on the device, byte-identical to the host indexer
+    from bucket_map_amd import host
+    g = host.Genome.synth(28, [300_000])
+    g.write_fasta(str(tmp_path / "g.fa"))
+    common = ["--genome", "g.fa", "--bucket-len", "65536", "-r", "20000", "-k", "4", "-l", "14", "-f", "1"]
+    _run(GPU_CLI, ["-x", "-i", "host", "--host-index", *common], tmp_path)
+    _run(GPU_CLI, ["-x", "-i", "gpu", "--gpu-index", *common], tmp_path)
+    _run(GPU_CLI, ["-x", "-i", "auto", *common], tmp_path)
+    for ext in ("qgram", "kmers_index", "bucket_id"):
+        ref = (tmp_path / f"host.{ext}").read_bytes()
+        assert (tmp_path / f"gpu.{ext}").read_bytes() == ref and (tmp_path / f"auto.{ext}").read_bytes() == ref, ext
+    # q = 12 is beyond the device build (3 <= q <= 10): the default falls back to the host indexer instead of failing
+    _run(GPU_CLI, ["-x", "-i", "q12", "--genome", "g.fa", "--bucket-len", "65536", "-r", "150", "-k", "12", "-l", "14", "-f", "1"], tmp_path)
+    assert (tmp_path / "q12.qgram").stat().st_size == 4 ** 12 * 1
+
+
 def test_cli_without_index_files_builds_them(tmp_path):
     # locator::initialize indexes first when the files are missing (locator.h:33-34)
     from bucket_map_amd import host

@@ -127,6 +127,41 @@ def test_long_reads_are_cut_into_five_windows():
     assert frac > 0.9
 
 
+@pytest.mark.parametrize("read_len,expect_bitmap_lds", [(2000, True), (9000, True), (16384, False)])
+def test_sample_kernel_lds_regimes(read_len, expect_bitmap_lds):
+    """The sample kernel sizes its workgroups by -r: 16 waves beside the 32 KiB q-gram bitmap for short reads, fewer
+    for long ones, and at -r 16384 one wave per workgroup with the bitmap left in L2.  Same outputs in every regime,
+    with windows that start at every byte alignment and end anywhere."""
+    import bucket_map_amd as bma
+    from oracle import oracle_c
+    case = Case(record_lengths=[3_000_000], bucket_len=65536, read_len=read_len, n_reads=64, sim_read_len=read_len, sub=0.01,
+                ins=0.002, dele=0.002, seed=90 + read_len)
+    rd = case.reads
+    rng = np.random.default_rng(read_len)
+    # whole reads, plus windows cut at random offsets and lengths inside them (every alignment of the 8-byte loads)
+    ws = [int(rd.offsets[r]) for r in range(rd.n)]
+    wl = [min(read_len, int(rd.offsets[r + 1] - rd.offsets[r])) for r in range(rd.n)]
+    for r in range(rd.n):
+        n = int(rd.offsets[r + 1] - rd.offsets[r])
+        a = int(rng.integers(0, max(1, n - 20)))
+        ws.append(int(rd.offsets[r]) + a)
+        wl.append(int(rng.integers(0, min(read_len, n - a) + 1)))
+    ws, wl = np.array(ws, np.uint64), np.array(wl, np.uint32)
+    ix = case.oracle_index()
+    c_ref, b_ref, rows_ref = oracle_map_windows(ix, rd.bases, rd.quals, ws, wl)
+    for flags in (0, bma.BMF_FLAG_EARLY_EXIT):
+        flt = case.gpu_filter(flags=flags)
+        c, b = flt.map_windows(rd.bases, rd.quals, ws, wl)
+        assert_same_candidates(c_ref, b_ref, c, b, f"-r {read_len} flags {flags}")
+        flt.close()
+    assert (c_ref.sum(axis=1) > 0).mean() > 0.5
+    # the regime this -r was meant to exercise (bmf_create's sizing: packed bases, prefix sums, good k-mers per wave)
+    up16 = lambda x: (x + 15) & ~15
+    stream = up16(read_len + 14)
+    per_wave = up16(up16((stream // 16 + 3) * 4) + up16((stream + 1) * 4) + 4 * (read_len - 12 + 1))
+    assert (32768 + per_wave <= 159 * 1024) == expect_bitmap_lds
+
+
 def test_repeats_overflow_max_candidates():
     # 40 identical records -> a read matches > 30 buckets equally well -> list cleared (q_gram_mapper.h:471-476)
     from bucket_map_amd import host
