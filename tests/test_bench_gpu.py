@@ -28,7 +28,11 @@ def test_single_gpu_line_has_roofline_traffic_and_cpu_baseline():
     assert roof["bound"] == "hbm" and 0 < roof["frac"] < 1.05 and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-9
     # measured in this very run by the profiler child, and close to the algorithmic bytes (no wasted re-reads)
     assert roof["traffic_source"].startswith("live:"), roof["traffic_source"]
-    assert 0.9 < roof["traffic"] / roof["algorithmic_bytes_per_launch"] < 1.2
+    # (this small genome's rows are 77 bytes at a 128-byte pitch: whole lines are fetched, so the bound is the pitch)
+    import re
+    row_bytes = int(re.search(r"rows x (\d+) B", d["config"]["workload"]).group(1))
+    pitch = roof["index_bytes_in_hbm"] / (4 ** 9 + 1)
+    assert 0.9 < roof["traffic"] / (roof["algorithmic_bytes_per_launch"] * pitch / row_bytes) < 1.2
     assert 0 < roof["infinity_cache_share"] <= 1 and roof["hbm_side_estimate_GBps"] <= roof["achieved"]
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] == 1 and d["cpu_baseline"]["value"] > 0
     assert d["checks"]["gpu_equals_oracle_on_sample"] is True and d["checks"]["source_bucket_recovered"] > 0.97
