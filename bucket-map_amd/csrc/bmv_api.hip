@@ -74,10 +74,13 @@ struct Shape {
 // A group is exactly as many lanes as the longest query has words (CW words per lane beyond 64 words); the
 // kernel variant only fixes how many of the group's lanes hold the traceback's 16 pairs of trace words.
 Shape pick_shape(uint32_t words) {
-    const int cw = words <= 64 ? 1 : (words <= 128 ? 2 : 4);
+    // the fewest words per lane that fit the query into one wave: every lane the group leaves idle is a lane's worth
+    // of the instruction stream wasted (a 10-kbp read is 157 words: 53 lanes x 3 words, not 40 x 4)
+    const int cw = words <= 64 ? 1 : (words <= 128 ? 2 : (words <= 192 ? 3 : 4));
     // beyond 256 words the whole wave carries strips of 256 words, one after the other
     const uint32_t g = std::min(64u, std::max(1u, (words + (uint32_t)cw - 1u) / (uint32_t)cw));
     if (cw == 2) return {g, 2, bmv::bmv_align_kernel<1, 2, false>};
+    if (cw == 3) return {g, 3, bmv::bmv_align_kernel<1, 3, false>};
     if (cw == 4) return {g, 4, words <= 256 ? bmv::bmv_align_kernel<1, 4, false> : bmv::bmv_align_kernel<1, 4, true>};
     if (g >= 16) return {g, 1, bmv::bmv_align_kernel<1, 1, false>};
     if (g >= 8) return {g, 1, bmv::bmv_align_kernel<2, 1, false>};

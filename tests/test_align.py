@@ -186,8 +186,9 @@ def test_gpu_verifier_matches_oracle(max_m, n, err):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("m,n_align", [(6000, 3), (10000, 2), (16384, 1), (16385, 1), (20000, 2), (33000, 1)])
-# 2 and 4 words per lane; beyond 16 384 bases the query is processed in strips (2, 2 and 3 of them)
+@pytest.mark.parametrize("m,n_align", [(6000, 3), (10000, 2), (12288, 1), (12289, 1), (16384, 1), (16385, 1), (20000, 2), (33000, 1)])
+# 2, 3 (up to 192 words = 12 288 bases) and 4 words per lane; beyond 16 384 bases the query is processed in strips
+# (2, 2 and 3 of them)
 def test_gpu_verifier_long_reads(m, n_align):
     from bucket_map_amd import verify
     rng = np.random.default_rng(m)
