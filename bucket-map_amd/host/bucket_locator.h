@@ -19,6 +19,7 @@
 #include <algorithm>
 #include <array>
 #include <atomic>
+#include <charconv>
 #include <chrono>
 #include <iostream>
 #include <memory>
@@ -61,6 +62,55 @@ public:
                        const uint8_t *text_rc, const uint64_t *query_start, const uint32_t *query_len, uint32_t n,
                        std::vector<int32_t> &score, std::vector<uint32_t> &begin, std::vector<uint64_t> &cigar_offset,
                        std::vector<uint32_t> &cigar) = 0;
+};
+
+// SAM text as seqan3::sam_file_output lays it out: records are appended to one buffer with
+// std::to_chars and go to the file a few megabytes at a time (a million `ostream <<` chains were the slowest stage
+// of the tool after the device work had shrunk to milliseconds).
+class sam_text {
+    std::ofstream out_;
+    std::string buf_;
+
+    void number(uint64_t v) {
+        char tmp[24];
+        const auto r = std::to_chars(tmp, tmp + sizeof tmp, v);
+        buf_.append(tmp, static_cast<size_t>(r.ptr - tmp));
+    }
+
+public:
+    explicit sam_text(std::filesystem::path const &file) : out_(file, std::ios::binary) {
+        if (!out_) throw std::runtime_error("cannot write " + file.string());
+        buf_.reserve(5u << 20);
+    }
+    ~sam_text() { flush(); }
+    void flush() {
+        out_.write(buf_.data(), static_cast<std::streamsize>(buf_.size()));
+        buf_.clear();
+    }
+    void header(const std::vector<std::string> &ref_ids, const std::vector<size_t> &ref_lengths) {
+        buf_ += "@HD\tVN:1.6\n";
+        for (size_t i = 0; i < ref_ids.size(); i++) {
+            buf_ += "@SQ\tSN:";
+            buf_ += ref_ids[i];
+            buf_ += "\tLN:";
+            number(ref_lengths[i]);
+            buf_ += '\n';
+        }
+    }
+    // QNAME FLAG RNAME POS MAPQ CIGAR * 0 0 SEQ QUAL
+    void record(std::string_view qname, unsigned flag, std::string_view rname, uint64_t pos, unsigned mapq, std::string_view cigar,
+                std::string_view seq, std::string_view qual) {
+        buf_.append(qname); buf_ += '\t';
+        number(flag); buf_ += '\t';
+        buf_.append(rname); buf_ += '\t';
+        number(pos); buf_ += '\t';
+        number(mapq); buf_ += '\t';
+        buf_.append(cigar);
+        buf_ += "\t*\t0\t0\t";
+        buf_.append(seq); buf_ += '\t';
+        buf_.append(qual); buf_ += '\n';
+        if (buf_.size() > (4u << 20)) flush();
+    }
 };
 
 class bucket_locator {
@@ -233,12 +283,11 @@ public:
 
     // _locate (:613-705)
     std::vector<std::vector<locate_t>> locate_reads(const std::string &sequence_file) {
-        auto [sequence_ids_orig, sequence_ids_rev_comp] = _m->map(sequence_file);
-        _m->reset();
-        // _initialize_kmer_index (:151-160): the bucket sequences, here as views into one byte string
-        auto t0 = std::chrono::steady_clock::now();
+        // _initialize_kmer_index (:151-160): the bucket sequences, here as views into one byte string that goes to
+        // the scanner's (and the verifier's) devices.  Nothing in it depends on the mapper, so it runs on its own
+        // thread while _m->map() parses the reads and drives the filter.
         buckets_ = cut_buckets(*genome_, static_cast<int>(bucket_length), static_cast<int>(read_length));
-        {
+        auto upload_genome = [&]() {
             std::vector<uint64_t> rec_off(genome_->seqs.size() + 1, 0);
             for (size_t r = 0; r < genome_->seqs.size(); r++) rec_off[r + 1] = rec_off[r] + genome_->seqs[r].size();
             // the records back to back, for the uploads only: uninitialised storage, copied by a few threads
@@ -256,17 +305,34 @@ public:
                 copy_records();
                 for (auto &t : pool) t.join();
             }
-            std::vector<uint64_t> &bstart = bstart_;
-            std::vector<uint32_t> &blen = blen_;
-            bstart.assign(buckets_.size(), 0);
-            blen.assign(buckets_.size(), 0);
+            bstart_.assign(buckets_.size(), 0);
+            blen_.assign(buckets_.size(), 0);
             for (size_t b = 0; b < buckets_.size(); b++) {
-                bstart[b] = rec_off[buckets_[b].record] + buckets_[b].start;
-                blen[b] = buckets_[b].end - buckets_[b].start;
+                bstart_[b] = rec_off[buckets_[b].record] + buckets_[b].start;
+                blen_[b] = buckets_[b].end - buckets_[b].start;
             }
-            _s->load_genome(flat.get(), total, bstart.data(), blen.data(), static_cast<uint32_t>(buckets_.size()));
+            _s->load_genome(flat.get(), total, bstart_.data(), blen_.data(), static_cast<uint32_t>(buckets_.size()));
             if (_v) _v->load_genome(flat.get(), total);
+        };
+        std::exception_ptr upload_error;
+        std::thread uploader([&]() {
+            try {
+                upload_genome();
+            } catch (...) {
+                upload_error = std::current_exception();
+            }
+        });
+        segments_t sequence_ids_orig, sequence_ids_rev_comp;
+        try {
+            std::tie(sequence_ids_orig, sequence_ids_rev_comp) = _m->map(sequence_file);
+            _m->reset();
+        } catch (...) {
+            uploader.join();
+            throw;
         }
+        auto t0 = std::chrono::steady_clock::now();
+        uploader.join();
+        if (upload_error) std::rethrow_exception(upload_error);
         prepare_read_query(sequence_file);
 
         // Candidates in the order of the reference's bucket loop (:651-693): buckets ascending; inside a
@@ -359,11 +425,8 @@ public:
         auto locate_res = locate_reads(sequence_file);
         const sam_header h = read_bucket_ids(index_file);
 
-        // SAM as seqan3::sam_file_output writes it
-        std::ofstream sam(sam_file, std::ios::binary);
-        if (!sam) throw std::runtime_error("cannot write " + sam_file.string());
-        sam << "@HD\tVN:1.6\n";
-        for (size_t i = 0; i < h.ref_ids.size(); i++) sam << "@SQ\tSN:" << h.ref_ids[i] << "\tLN:" << h.ref_lengths[i] << "\n";
+        sam_text sam(sam_file);
+        sam.header(h.ref_ids, h.ref_lengths);
         unsigned int read_id = 0, mapped_locations = 0;
         auto t0 = std::chrono::steady_clock::now();
         if (_v) {
@@ -380,8 +443,7 @@ public:
                     (void)segment_offset;
                     const unsigned int map_qual = std::min(60u, 6 * votes);                      // :591
                     const size_t ref_offset = static_cast<size_t>(h.bucket_offsets[bucket_id]) + offset;  // :592, 0-based
-                    sam << rec.id << '\t' << (is_original ? 0 : 16) << '\t' << h.bucket_name[bucket_id] << '\t'
-                        << ref_offset + 1 << '\t' << map_qual << "\t*\t*\t0\t0\t" << seq << '\t' << rec.qual << '\n';
+                    sam.record(rec.id, is_original ? 0 : 16, h.bucket_name[bucket_id], ref_offset + 1, map_qual, "*", seq, rec.qual);
                     mapped_locations++;
                 }
                 read_id++;
@@ -406,7 +468,7 @@ private:
     // Deviation: a negative `offset` indexes before the bucket in the reference (undefined behaviour); here
     // the window is clipped to start at the bucket's first base.
     unsigned int write_verified(const std::string &sequence_file, const std::vector<std::vector<locate_t>> &locate_res,
-                                const sam_header &h, std::ofstream &sam, unsigned int quality_threshold, unsigned int &read_id) {
+                                const sam_header &h, sam_text &sam, unsigned int quality_threshold, unsigned int &read_id) {
         struct held { std::string id, seq, qual; uint64_t start; };
         std::vector<held> block;
         std::vector<uint8_t> bases;
@@ -436,9 +498,8 @@ private:
                             cg += "MID"[cigar[x] & 15u];
                         }
                         if (cg.empty()) cg = "*";
-                        sam << block[r].id << '\t' << (is_original ? 0 : 16) << '\t' << h.bucket_name[bucket_id] << '\t'
-                            << ref_offset + 1 << '\t' << static_cast<unsigned int>(static_cast<uint8_t>(map_qual)) << '\t' << cg
-                            << "\t*\t0\t0\t" << block[r].seq << '\t' << block[r].qual << '\n';
+                        sam.record(block[r].id, is_original ? 0 : 16, h.bucket_name[bucket_id], ref_offset + 1,
+                                   static_cast<uint8_t>(map_qual), cg, block[r].seq, block[r].qual);
                         mapped_locations++;
                     }
                     a++;
