@@ -239,6 +239,11 @@ struct bmf_ctx {
     static constexpr int kMapSlots = 3;
     MapSlot *slot[kMapSlots] = {nullptr, nullptr, nullptr};
     hipStream_t h2d = nullptr, d2h = nullptr;
+    // two-pass pruning: the batch goes out in slices, the recount of slice i on `side` under pass 1 of slice i+1
+    static constexpr int kSlices = 8;
+    hipStream_t side = nullptr;
+    hipEvent_t slice_done[kSlices] = {};
+    hipEvent_t side_done = nullptr;
     DevBuf<uint8_t> whole_bases, whole_quals;   // windows in no particular order: the read buffer is uploaded once
 };
 
@@ -439,6 +444,7 @@ static int select_pruned_variant(bmf_ctx *c) {
     const bmf::DevParams &d = c->dp;
     c->dp.pass1_rows = 0;
     c->dp.max_live = bmf::kMaxLive;
+    c->dp.item_base = 0;
     if (!(c->p.flags & BMF_FLAG_EARLY_EXIT) || c->n_slices > 1) return BMF_OK;
     c->vote = pick_vote(c->cpl, c->planes, true);
     if (d.G < 2 || c->n_rows == 0) return BMF_OK;
@@ -524,6 +530,14 @@ static void free_map_slots(bmf_ctx *c) {
     if (c->h2d) (void)hipStreamDestroy(c->h2d);
     if (c->d2h) (void)hipStreamDestroy(c->d2h);
     c->h2d = c->d2h = nullptr;
+    if (c->side) (void)hipStreamDestroy(c->side);
+    c->side = nullptr;
+    for (auto &e : c->slice_done) {
+        if (e) (void)hipEventDestroy(e);
+        e = nullptr;
+    }
+    if (c->side_done) (void)hipEventDestroy(c->side_done);
+    c->side_done = nullptr;
 }
 
 void bmf_destroy(bmf_ctx *c) {
@@ -952,15 +966,43 @@ static int launch_filter(bmf_ctx *c, bmf_batch *b, const uint8_t *d_bases, const
         HIP_TRY(b->q_live_mask.need(n_items * c->dp.max_live));
         HIP_TRY(hipMemsetAsync(b->q_counters.p, 0, 4 * sizeof(uint32_t), c->stream));
         const bmf::Pass2Queue q{b->q_counters.p, b->q_slow.p, b->q_live_n.p, b->q_live_chunks.p, b->q_live_mask.p};
-        hipLaunchKernelGGL(c->two_pass.pass1, dim3(2 * b->n_windows), dim3(bmf::kWave), 0, c->stream, c->dp, c->d_rows,
-                           b->lists.p, b->list_n.p, b->counts.p, q);
-        // fixed grids: the recount walks all items (most keep a few live chunks), the slow kernel strides over
-        // the queue length it reads from HBM -- nothing comes back to the host in between
-        const size_t per_wave = bmf::kWave / c->dp.max_live;   // items per wave
-        const unsigned recount_blocks = (unsigned)std::min<size_t>((n_items + per_wave - 1) / per_wave, 32768);
+        const size_t per_wave = bmf::kWave / c->dp.max_live;   // items per wave of the recount kernel
         const size_t recount_lds = per_wave * (size_t)c->dp.S * c->dp.G * sizeof(uint32_t);
-        hipLaunchKernelGGL(c->two_pass.recount, dim3(recount_blocks), dim3(bmf::kWave), recount_lds, c->stream, c->dp, c->d_rows,
-                           b->lists.p, (uint32_t)n_items, b->counts.p, b->buckets.p, q);
+        // Pass 1 is bound by bandwidth, the recount by the latency of its short dependent streams of sectors: they
+        // share the chip well.  The batch goes out in slices; the recount of slice i runs on a second stream under
+        // pass 1 of slice i+1.  (Fixed grids per slice: the recount walks the slice's items -- most keep a few live
+        // chunks -- and the slow kernel strides over the queue length it reads from HBM; nothing comes back to the
+        // host in between.)  BMF_SLICES=1 keeps everything on one stream.
+        int n_sl = n_items >= 8 * 65536 ? bmf_ctx::kSlices : 1;
+        if (const char *env = getenv("BMF_SLICES")) n_sl = std::max(1, std::min(bmf_ctx::kSlices, atoi(env)));
+        if (n_sl > 1 && !c->side) {
+            HIP_TRY(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+            for (auto &e : c->slice_done) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&c->side_done, hipEventDisableTiming));
+        }
+        const size_t per_slice = ((n_items + n_sl - 1) / n_sl + 1) & ~(size_t)1;   // whole windows
+        for (int sl = 0; sl < n_sl; sl++) {
+            const size_t first = (size_t)sl * per_slice;
+            if (first >= n_items) break;
+            const size_t count = std::min(per_slice, n_items - first);
+            bmf::DevParams dp = c->dp;
+            dp.item_base = (uint32_t)first;
+            hipLaunchKernelGGL(c->two_pass.pass1, dim3((unsigned)count), dim3(bmf::kWave), 0, c->stream, dp, c->d_rows, b->lists.p,
+                               b->list_n.p, b->counts.p, q);
+            hipStream_t rs = c->stream;
+            if (n_sl > 1) {
+                HIP_TRY(hipEventRecord(c->slice_done[sl], c->stream));
+                HIP_TRY(hipStreamWaitEvent(c->side, c->slice_done[sl], 0));
+                rs = c->side;
+            }
+            const unsigned recount_blocks = (unsigned)std::min<size_t>((count + per_wave - 1) / per_wave, 32768);
+            hipLaunchKernelGGL(c->two_pass.recount, dim3(recount_blocks), dim3(bmf::kWave), recount_lds, rs, dp, c->d_rows, b->lists.p,
+                               (uint32_t)count, b->counts.p, b->buckets.p, q);
+        }
+        if (n_sl > 1) {
+            HIP_TRY(hipEventRecord(c->side_done, c->side));
+            HIP_TRY(hipStreamWaitEvent(c->stream, c->side_done, 0));
+        }
         const unsigned slow_blocks = (unsigned)std::min<size_t>(n_items, 2048);
         hipLaunchKernelGGL(c->two_pass.slow, dim3(slow_blocks), dim3(bmf::kWave), 0, c->stream, c->dp, c->d_rows, b->lists.p,
                            b->counts.p, b->buckets.p, q);

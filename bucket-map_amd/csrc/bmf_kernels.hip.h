@@ -42,6 +42,7 @@ struct DevParams {
     uint32_t early_exit; // BMF_FLAG_EARLY_EXIT: a pruning kernel variant is in use (informational)
     uint32_t pass1_rows; // two-pass variant: q-gram rows of each sample read at full width in pass 1 (1..G)
     uint32_t max_live;   // two-pass variant: live chunks (= lanes) an item may bring to the recount kernel (16 or 32)
+    uint32_t item_base;  // two-pass variant: first (window, orientation) item of this launch (the batch goes out in slices)
 };
 
 __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {

@@ -231,7 +231,7 @@ template <int CPL, int PLANES, int DEPTH>
 __device__ __forceinline__ void pass1_item(const DevParams &P, const uint8_t *__restrict__ rows,
                                            const uint32_t *__restrict__ row_lists, const uint32_t *__restrict__ list_n,
                                            uint32_t *__restrict__ out_counts, const Pass2Queue &Q) {
-    const uint32_t item = blockIdx.x;          // 2*window + orientation
+    const uint32_t item = P.item_base + blockIdx.x;   // 2*window + orientation
     const uint32_t lane = threadIdx.x;
     if (list_n[item >> 1] == 0) {              // window rejected by the sample kernel
         if (lane == 0) {
@@ -396,9 +396,11 @@ __global__ __launch_bounds__(kWave, 4) void bmf_recount_kernel(DevParams P, cons
     const uint32_t n_ids = P.S * P.G;
     uint32_t *list = lds_lists + grp * n_ids;
     uint32_t recounted = 0, loads = 0;
-    for (uint32_t base = blockIdx.x * kPerWave; base < n_items; base += gridDim.x * kPerWave) {
+    // items [item_base, item_base + n_items) of the batch
+    const uint32_t item_end = P.item_base + n_items;
+    for (uint32_t base = P.item_base + blockIdx.x * kPerWave; base < item_end; base += gridDim.x * kPerWave) {
         const uint32_t item = base + grp;
-        uint32_t n_live = item < n_items ? Q.live_n[item] : 0u;
+        uint32_t n_live = item < item_end ? Q.live_n[item] : 0u;
         if (n_live == kSlowItem) n_live = 0;
         const bool have = n_live != 0;
         if (__ballot(have) == 0) continue;       // all results are final already

@@ -62,7 +62,12 @@ def random_case(rng, *, nb, q, k, S, F, max_cand, kmer_frac, density, read_len, 
             del os.environ["BMF_PASS1_ROWS"]
             del os.environ["BMF_MAX_LIVE"]
         assert f2.info()["pass1_rows"] >= 1
-        out += list(f2.map_windows(bases, quals, ws, wl))
+        # ... in one piece, or in slices whose recounts run on a second stream under the next slice's first pass
+        os.environ["BMF_SLICES"] = str(int(rng.choice([1, 3, 8])))
+        try:
+            out += list(f2.map_windows(bases, quals, ws, wl))
+        finally:
+            del os.environ["BMF_SLICES"]
         f2.close()
     return out
 
