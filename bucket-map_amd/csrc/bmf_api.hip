@@ -968,12 +968,14 @@ static int launch_filter(bmf_ctx *c, bmf_batch *b, const uint8_t *d_bases, const
         const bmf::Pass2Queue q{b->q_counters.p, b->q_slow.p, b->q_live_n.p, b->q_live_chunks.p, b->q_live_mask.p};
         const size_t per_wave = bmf::kWave / c->dp.max_live;   // items per wave of the recount kernel
         const size_t recount_lds = per_wave * (size_t)c->dp.S * c->dp.G * sizeof(uint32_t);
-        // Pass 1 is bound by bandwidth, the recount by the latency of its short dependent streams of sectors: they
-        // share the chip well.  The batch goes out in slices; the recount of slice i runs on a second stream under
-        // pass 1 of slice i+1.  (Fixed grids per slice: the recount walks the slice's items -- most keep a few live
-        // chunks -- and the slow kernel strides over the queue length it reads from HBM; nothing comes back to the
-        // host in between.)  BMF_SLICES=1 keeps everything on one stream.
-        int n_sl = n_items >= 8 * 65536 ? bmf_ctx::kSlices : 1;
+        // Fixed grids: the recount walks all items (most keep a few live chunks), the slow kernel strides over the
+        // queue length it reads from HBM -- nothing comes back to the host in between.
+        // BMF_SLICES=n (experiment, off by default) sends the batch out in n slices with the recount of slice i on a
+        // second stream under pass 1 of slice i+1.  Measured on the Egu batch: 19.1 ms in one piece, 19.3 / 19.8 /
+        // 22.2 ms in 2 / 4 / 8 slices -- the recount's waves take wave slots from the bandwidth-bound pass 1, which
+        // loses more than the recount's time that was to be hidden (the same outcome as overlapping the sample
+        // kernel with the vote kernel in round 1).
+        int n_sl = 1;
         if (const char *env = getenv("BMF_SLICES")) n_sl = std::max(1, std::min(bmf_ctx::kSlices, atoi(env)));
         if (n_sl > 1 && !c->side) {
             HIP_TRY(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
