@@ -387,7 +387,8 @@ def main():
         same = same and bool(np.array_equal(bkp[maskp], buckets[maskp]))
         pruned = {"value": reads_per_step * args.steps / pruned_s, "unit": "reads/s", "ms_per_step": pruned_s / args.steps * 1e3,
                   "outputs_identical_to_headline_run": same, "flag": "BMF_FLAG_EARLY_EXIT",
-                  "pass1_rows": fp.info()["pass1_rows"]}
+                  "pass1_rows": fp.info()["pass1_rows"], "pass1_fold": fp.info()["pass1_fold"],
+                  "pass1_fold_rows": fp.info()["pass1_fold_rows"]}
         if pruned["pass1_rows"]:
             pruned["items_recounted"], pruned["items_slow_path"] = bp.pass2_counts()
             pruned["recount_column_loads"] = bp.recount_loads()

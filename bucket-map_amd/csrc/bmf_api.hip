@@ -146,6 +146,22 @@ TwoPass pick_vote2(int cpl, int planes, int max_live) {
     return {};
 }
 
+// first pass over the folded index: NB <= 65 536 folds to at most 128 chunks per row, CPL 1 or 2
+template <int CPL>
+pass1_fn pick_fold_planes(int planes) {
+    constexpr int D = depth_for(CPL);
+    switch (planes) {
+    case 2: return bmf::bmf_pass1_kernel<CPL, 2, D, true>;
+    case 3: return bmf::bmf_pass1_kernel<CPL, 3, D, true>;
+    case 4: return bmf::bmf_pass1_kernel<CPL, 4, D, true>;
+    case 5: return bmf::bmf_pass1_kernel<CPL, 5, D, true>;
+    }
+    return nullptr;
+}
+pass1_fn pick_pass1_fold(int cpl, int planes) {
+    return cpl == 1 ? pick_fold_planes<1>(planes) : (cpl == 2 ? pick_fold_planes<2>(planes) : nullptr);
+}
+
 // P[Bin(n, p) >= m]
 double binom_tail(uint32_t n, double p, uint32_t m) {
     if (m == 0) return 1.0;
@@ -214,6 +230,10 @@ struct bmf_ctx {
     uint32_t n_slices = 1;           // > 1 when NB > 65 536: one wave per (item, 65 536-bucket slice)
     vote_fn vote = nullptr;
     TwoPass two_pass;                // used instead of `vote` when dp.pass1_rows > 0
+    // folded first pass (bmf_fold4_kernel): one bit per group of 4 buckets, a quarter of the row bytes
+    uint8_t *d_fold = nullptr;       // (n_rows + 1) x dpf.pitch
+    bmf::DevParams dpf{};            // the folded geometry + rows per sample the folded pass reads
+    pass1_fn pass1_fold = nullptr;   // non-null: pass 1 streams d_fold instead of d_rows
     size_t sample_lds = 0;
     bmf::SampleGeom sample_geom{};
     bool sample_bitmap_lds = false;
@@ -426,6 +446,9 @@ static void free_index(bmf_ctx *c) {
     (void)hipFree(c->d_k2i);
     (void)hipFree(c->d_zeros);
     (void)hipFree(c->d_qgram_ok);
+    (void)hipFree(c->d_fold);
+    c->d_fold = nullptr;
+    c->pass1_fold = nullptr;
     c->d_rows = nullptr;
     c->d_k2i = nullptr;
     c->d_zeros = nullptr;
@@ -467,7 +490,8 @@ static int select_pruned_variant(bmf_ctx *c) {
     // The same holds for very short rows (NB <= 2 048): the step is latency-bound and the plain kernel is the
     // fastest (E. coli-sized index: 177 M reads/s plain, 160 M with single-pass pruning; from NB ~ 3 800 on,
     // pruning wins again: 102 M plain, 129 M single-pass).
-    if ((kept < 0.6 || d.n_chunks <= 16u) && !getenv("BMF_PASS1_ROWS")) {
+    const bool fold_forced = getenv("BMF_FOLD") && atoi(getenv("BMF_FOLD")) == 4;
+    if ((kept < 0.6 || d.n_chunks <= 16u) && !getenv("BMF_PASS1_ROWS") && !fold_forced) {
         c->vote = pick_vote(c->cpl, c->planes, false);
         return BMF_OK;
     }
@@ -490,6 +514,42 @@ static int select_pruned_variant(bmf_ctx *c) {
         best_r = v > 0 && (uint32_t)v < d.G ? (uint32_t)v : 0u;
         if (best_r) best_live = (double)d.nb * binom_tail(d.S, pow(hit1, (double)best_r), d.S - d.F + 1u);
     }
+    // The folded first pass: a row of the folded index (one bit per group of 4 buckets) is a quarter of the bytes and
+    // leaves a group's bit set with probability 1 - (1 - d)^4, so r rows of it per sample cost what r/4 rows cost
+    // now and let an unrelated group through with probability (1 - (1 - d)^4)^r: at d = 0.22, three folded rows
+    // beat one full row on both counts.  Same cost model, groups instead of buckets.  BMF_FOLD=0|4 and
+    // BMF_FOLD_ROWS=r override (the sweeps force both forms).
+    uint32_t fold_r = 0;
+    double fold_live = 0.0;
+    {
+        const double dens4 = 1.0 - pow(1.0 - dens, 4.0), hit4 = 1.0 - kept + kept * dens4;
+        const double groups = ((double)d.nb + 3.0) / 4.0, row4 = row_bytes / 4.0;
+        double best4 = best;
+        for (uint32_t r = 1; r <= d.G; r++) {
+            const double live = groups * binom_tail(d.S, pow(hit4, (double)r), d.S - d.F + 1u);
+            if (live > 20.0) continue;
+            const double cost = (double)d.S * r * row4 + live * d.S * sector + 1.0 * d.S * d.G * sector;
+            if (cost < best4) {
+                best4 = cost;
+                fold_r = r;
+                fold_live = live;
+            }
+        }
+        const char *ef = getenv("BMF_FOLD");
+        if (ef && atoi(ef) == 0) fold_r = 0;
+        if (getenv("BMF_PASS1_ROWS") && !(ef && atoi(ef) == 4)) fold_r = 0;   // an experiment asked for the unfolded passes
+        if (ef && atoi(ef) == 4) {
+            long v = getenv("BMF_FOLD_ROWS") ? strtol(getenv("BMF_FOLD_ROWS"), nullptr, 10) : (fold_r ? (long)fold_r : (long)d.G);
+            fold_r = (uint32_t)std::max<long>(1, std::min<long>(v, (long)d.G));
+            fold_live = groups * binom_tail(d.S, pow(hit4, (double)fold_r), d.S - d.F + 1u);
+        }
+        const uint32_t row_bytes_f = (uint32_t)((groups + 7.0) / 8.0), chunks_f = (row_bytes_f + 15u) / 16u;
+        if (chunks_f > 128u) fold_r = 0;                 // (cannot happen for NB <= 65 536)
+        if (fold_r) {
+            best_r = best_r ? best_r : 1u;               // what the recount and the slow kernel call "pass 1's rows"
+            best_live = fold_live;
+        }
+    }
     if (best_r) {
         // Lanes per item in the recount kernel: 16 (four items per wave) while items with more than 16 live chunks stay
         // rare -- the by-chance survivors are Poisson around best_live, plus the read's own chunk -- else 32.
@@ -500,6 +560,30 @@ static int select_pruned_variant(bmf_ctx *c) {
         if (c->two_pass.pass1) {
             c->dp.pass1_rows = best_r;
             c->dp.max_live = (uint32_t)max_live;
+        }
+    }
+    if (fold_r && c->dp.pass1_rows) {
+        bmf::DevParams &f = c->dpf;
+        f = c->dp;
+        f.nb = (d.nb + 3u) / 4u;
+        const uint32_t row_bytes_f = (f.nb + 7u) >> 3;
+        f.n_chunks = (row_bytes_f + 15u) / 16u;
+        f.pitch = (row_bytes_f + 127u) & ~127u;
+        f.pass1_rows = fold_r;
+        const int cpl_f = (int)((f.n_chunks + 63u) / 64u);
+        c->pass1_fold = pick_pass1_fold(cpl_f, c->planes);
+        if (c->pass1_fold) {
+            HIP_TRY(dev_alloc(&c->d_fold, (size_t)(c->n_rows + 1) * f.pitch));
+            // whole rows per launch, grid.x * 256 threads below 2^32
+            const uint64_t rows_per_launch = std::max<uint64_t>(1, ((uint64_t)1 << 30) / (f.pitch >> 2));
+            for (uint64_t r0 = 0; r0 <= c->n_rows; r0 += rows_per_launch) {
+                const uint64_t nr = std::min<uint64_t>(rows_per_launch, c->n_rows + 1 - r0);
+                const uint64_t w = nr * (f.pitch >> 2);
+                hipLaunchKernelGGL(bmf::bmf_fold4_kernel, dim3((unsigned)((w + 255) / 256)), dim3(256), 0, c->stream,
+                                   c->d_rows + (size_t)r0 * c->dp.pitch, nr, c->dp.pitch, c->d_fold + (size_t)r0 * f.pitch, f.pitch);
+            }
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipStreamSynchronize(c->stream));
         }
     }
     return BMF_OK;
@@ -989,8 +1073,15 @@ static int launch_filter(bmf_ctx *c, bmf_batch *b, const uint8_t *d_bases, const
             const size_t count = std::min(per_slice, n_items - first);
             bmf::DevParams dp = c->dp;
             dp.item_base = (uint32_t)first;
-            hipLaunchKernelGGL(c->two_pass.pass1, dim3((unsigned)count), dim3(bmf::kWave), 0, c->stream, dp, c->d_rows, b->lists.p,
-                               b->list_n.p, b->counts.p, q);
+            if (c->pass1_fold) {
+                bmf::DevParams df = c->dpf;
+                df.item_base = dp.item_base;
+                hipLaunchKernelGGL(c->pass1_fold, dim3((unsigned)count), dim3(bmf::kWave), 0, c->stream, df, c->d_fold, b->lists.p,
+                                   b->list_n.p, b->counts.p, q);
+            } else {
+                hipLaunchKernelGGL(c->two_pass.pass1, dim3((unsigned)count), dim3(bmf::kWave), 0, c->stream, dp, c->d_rows, b->lists.p,
+                                   b->list_n.p, b->counts.p, q);
+            }
             hipStream_t rs = c->stream;
             if (n_sl > 1) {
                 HIP_TRY(hipEventRecord(c->slice_done[sl], c->stream));
@@ -1388,6 +1479,13 @@ int bmf_batch_recount_loads(bmf_ctx *c, bmf_batch *b, uint64_t *loads) {
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (c->dp.pass1_rows && b->q_counters.p) HIP_TRY(hipMemcpy(v, b->q_counters.p, sizeof v, hipMemcpyDeviceToHost));
     *loads = v[2];
+    return BMF_OK;
+}
+
+int bmf_pass1_fold(bmf_ctx *c, uint32_t *fold, uint32_t *rows) {
+    if (!c || !fold || !rows) return fail(BMF_ERR_ARG, "bmf_pass1_fold: null argument");
+    *fold = c->pass1_fold ? 4u : 1u;
+    *rows = c->pass1_fold ? c->dpf.pass1_rows : c->dp.pass1_rows;
     return BMF_OK;
 }
 

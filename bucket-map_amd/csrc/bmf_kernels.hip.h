@@ -100,6 +100,36 @@ __global__ void bmf_sanitize_rows_kernel(uint8_t *rows, uint64_t n_rows, uint32_
     rows[r * pitch + last] &= (uint8_t)(0xFFu >> (8u - (nb & 7u)));
 }
 
+// Exact pruning, folded first pass (bmf_vote2.hip.h): row g of the FOLDED index has bit i set iff any of the buckets
+// 4i .. 4i+3 is set in row g.  One thread per output word (32 groups = 128 buckets = one 16-byte chunk of the row).
+__device__ __forceinline__ uint32_t fold4_byte(uint32_t w) {     // 32 bits -> 8: bit i = OR of bits 4i .. 4i+3
+    uint32_t t = w | (w >> 1);
+    t = (t | (t >> 2)) & 0x11111111u;
+    t = (t | (t >> 3)) & 0x03030303u;
+    t = (t | (t >> 6)) & 0x000F000Fu;
+    return (t | (t >> 12)) & 0xFFu;
+}
+__device__ __forceinline__ uint32_t spread4_byte(uint32_t b) {   // 8 bits -> 32: bit i goes to bits 4i .. 4i+3
+    uint32_t x = (b | (b << 12)) & 0x000F000Fu;
+    x = (x | (x << 6)) & 0x03030303u;
+    x = (x | (x << 3)) & 0x11111111u;
+    return x * 0xFu;
+}
+__global__ void bmf_fold4_kernel(const uint8_t *__restrict__ rows, uint64_t n_rows, uint32_t pitch,
+                                 uint8_t *__restrict__ folded, uint32_t pitch_f) {
+    const uint32_t words_f = pitch_f >> 2, words = pitch >> 2;
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_rows * words_f) return;
+    const uint64_t r = i / words_f;
+    const uint32_t ow = (uint32_t)(i % words_f);
+    const uint32_t *in = reinterpret_cast<const uint32_t *>(rows + r * pitch);
+    uint32_t out = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < 4; k++)
+        if (4u * ow + k < words) out |= fold4_byte(in[4u * ow + k]) << (8u * k);
+    reinterpret_cast<uint32_t *>(folded + r * pitch_f)[ow] = out;
+}
+
 // distinguishability_filter::read (q_gram_mapper.h:171-187): zeros[row] = NB - popcount(row).
 // One wave per row, coalesced dword reads.
 __global__ __launch_bounds__(kWave) void bmf_zeros_kernel(const uint8_t *rows, uint64_t n_rows, uint32_t pitch,

@@ -227,7 +227,12 @@ __device__ __forceinline__ void full_width_slots(const DevParams &P, uint32_t la
     }
 }
 
-template <int CPL, int PLANES, int DEPTH>
+// FOLD4: `rows` is the folded index (one bit per group of 4 buckets, bmf_fold4_kernel) and P its geometry (nb =
+// groups, n_chunks, pitch).  A group's AND over folded rows is set whenever any of its buckets' ANDs is, so the
+// group's miss count is a lower bound for each of its 4 buckets: a quarter of the bytes per row buys r = 3 or 4
+// rows per sample instead of 1, and far fewer chunks survive by chance.  A 32-group word of a folded chunk is
+// exactly one 128-bucket chunk of the index; its alive bits, spread 4x, are that chunk's live-bucket mask.
+template <int CPL, int PLANES, int DEPTH, bool FOLD4>
 __device__ __forceinline__ void pass1_item(const DevParams &P, const uint8_t *__restrict__ rows,
                                            const uint32_t *__restrict__ row_lists, const uint32_t *__restrict__ list_n,
                                            uint32_t *__restrict__ out_counts, const Pass2Queue &Q) {
@@ -254,21 +259,52 @@ __device__ __forceinline__ void pass1_item(const DevParams &P, const uint8_t *__
     }
     // chunks that still hold a bucket with < F misses, in ascending chunk order
     uint32_t n_live = 0;
+    if (!FOLD4) {
 #pragma unroll
-    for (int j = 0; j < CPL; j++) {
-        uint32_t a = 0;
+        for (int j = 0; j < CPL; j++) {
+            uint32_t a = 0;
 #pragma unroll
-        for (int x = 0; x < 4; x++) a |= alive_word<CPL, PLANES>(cnt, j, x);
-        const bool live = a != 0;
-        const uint64_t m = __ballot(live);
-        const uint32_t at = n_live + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-        if (live && at < P.max_live) {
-            Q.live_chunks[(size_t)item * P.max_live + at] = (uint16_t)cidx[j];
-            Q.live_mask[(size_t)item * P.max_live + at] =
-                make_uint4(alive_word<CPL, PLANES>(cnt, j, 0), alive_word<CPL, PLANES>(cnt, j, 1),
-                           alive_word<CPL, PLANES>(cnt, j, 2), alive_word<CPL, PLANES>(cnt, j, 3));
+            for (int x = 0; x < 4; x++) a |= alive_word<CPL, PLANES>(cnt, j, x);
+            const bool live = a != 0;
+            const uint64_t m = __ballot(live);
+            const uint32_t at = n_live + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+            if (live && at < P.max_live) {
+                Q.live_chunks[(size_t)item * P.max_live + at] = (uint16_t)cidx[j];
+                Q.live_mask[(size_t)item * P.max_live + at] =
+                    make_uint4(alive_word<CPL, PLANES>(cnt, j, 0), alive_word<CPL, PLANES>(cnt, j, 1),
+                               alive_word<CPL, PLANES>(cnt, j, 2), alive_word<CPL, PLANES>(cnt, j, 3));
+            }
+            n_live += (uint32_t)__popcll(m);
         }
-        n_live += (uint32_t)__popcll(m);
+    } else {
+#pragma unroll
+        for (int j = 0; j < CPL; j++) {
+            uint32_t aw[4], mine = 0;
+#pragma unroll
+            for (int x = 0; x < 4; x++) {
+                aw[x] = alive_word<CPL, PLANES>(cnt, j, x);
+                mine += aw[x] != 0 ? 1u : 0u;
+            }
+            uint32_t incl = mine;                       // lanes in order, a lane's words in order: ascending chunk ids
+#pragma unroll
+            for (int o = 1; o < kWave; o <<= 1) {
+                const uint32_t t = __shfl_up(incl, o, kWave);
+                if (lane >= (uint32_t)o) incl += t;
+            }
+            uint32_t at = n_live + incl - mine;
+#pragma unroll
+            for (int x = 0; x < 4; x++)
+                if (aw[x] != 0) {
+                    if (at < P.max_live) {
+                        Q.live_chunks[(size_t)item * P.max_live + at] = (uint16_t)(cidx[j] * 4u + (uint32_t)x);
+                        Q.live_mask[(size_t)item * P.max_live + at] =
+                            make_uint4(spread4_byte(aw[x] & 0xFFu), spread4_byte((aw[x] >> 8) & 0xFFu),
+                                       spread4_byte((aw[x] >> 16) & 0xFFu), spread4_byte(aw[x] >> 24));
+                    }
+                    at++;
+                }
+            n_live += (uint32_t)__shfl((int)incl, kWave - 1, kWave);
+        }
     }
     if (lane == 0) {
         if (n_live == 0) out_counts[item] = 0;
@@ -280,12 +316,12 @@ __device__ __forceinline__ void pass1_item(const DevParams &P, const uint8_t *__
     }
 }
 
-template <int CPL, int PLANES, int DEPTH>
+template <int CPL, int PLANES, int DEPTH, bool FOLD4 = false>
 __global__ __launch_bounds__(kWave) void bmf_pass1_kernel(DevParams P, const uint8_t *__restrict__ rows,
                                                          const uint32_t *__restrict__ row_lists,
                                                          const uint32_t *__restrict__ list_n,
                                                          uint32_t *__restrict__ out_counts, Pass2Queue Q) {
-    pass1_item<CPL, PLANES, DEPTH>(P, rows, row_lists, list_n, out_counts, Q);
+    pass1_item<CPL, PLANES, DEPTH, FOLD4>(P, rows, row_lists, list_n, out_counts, Q);
 }
 
 // best_results (q_gram_mapper.h:90-102,471-476) over the kMaxLive lanes of one item: lane i holds the exact

@@ -73,6 +73,7 @@ SYMBOLS = {
     "bmf_pinned_free": (None, [C.c_void_p]),
     "bmf_info": (C.c_int, [C.c_void_p, _u32p, _u32p, _u32p, _u32p]),
     "bmf_pass1_rows": (C.c_int, [C.c_void_p, _u32p]),
+    "bmf_pass1_fold": (C.c_int, [C.c_void_p, _u32p, _u32p]),
     "bmf_batch_pass2_counts": (C.c_int, [C.c_void_p, C.c_void_p, _u32p, _u32p]),
     "bmf_batch_recount_loads": (C.c_int, [C.c_void_p, C.c_void_p, _u64p]),
 }
@@ -374,10 +375,11 @@ class Filter:
     def info(self) -> dict:
         v = [C.c_uint32() for _ in range(4)]
         _check(lib().bmf_info(self._h, *[C.byref(x) for x in v]))
-        r = C.c_uint32()
+        r, fold, frows = C.c_uint32(), C.c_uint32(), C.c_uint32()
         _check(lib().bmf_pass1_rows(self._h, C.byref(r)))
+        _check(lib().bmf_pass1_fold(self._h, C.byref(fold), C.byref(frows)))
         return {"row_pitch_bytes": v[0].value, "chunks_per_lane": v[1].value, "planes": v[2].value,
-                "rows_in_flight": v[3].value, "pass1_rows": r.value}
+                "rows_in_flight": v[3].value, "pass1_rows": r.value, "pass1_fold": fold.value, "pass1_fold_rows": frows.value}
 
     def close(self) -> None:
         if self._h:
