@@ -468,6 +468,31 @@ static int select_pruned_variant(bmf_ctx *c) {
     c->dp.pass1_rows = 0;
     c->dp.max_live = bmf::kMaxLive;
     c->dp.item_base = 0;
+    {   // farthest-point order of a sample's G rows: 0, G-1, then whatever is farthest from those taken (bmf_vote2.hip.h
+        // row_of); BMF_ROW_ORDER=linear keeps 0, 1, 2, ... for comparison
+        uint32_t order[8], n = 0;
+        bool taken[8] = {};
+        const bool linear = getenv("BMF_ROW_ORDER") && !strcmp(getenv("BMF_ROW_ORDER"), "linear");
+        while (n < d.G) {
+            uint32_t pick = 0;
+            int best_dist = -1;
+            for (uint32_t g = 0; g < d.G; g++) {
+                if (taken[g]) continue;
+                int dist = 99;
+                for (uint32_t t = 0; t < n; t++) dist = std::min(dist, abs((int)g - (int)order[t]));
+                if (linear) dist = -(int)g;
+                if (dist > best_dist || (dist == best_dist && g > pick && !linear)) {
+                    best_dist = dist;
+                    pick = g;
+                }
+            }
+            if (n == 0 && !linear) pick = 0;
+            taken[pick] = true;
+            order[n++] = pick;
+        }
+        c->dp.row_order = 0;
+        for (uint32_t i = 0; i < d.G; i++) c->dp.row_order |= order[i] << (4u * i);
+    }
     if (!(c->p.flags & BMF_FLAG_EARLY_EXIT) || c->n_slices > 1) return BMF_OK;
     c->vote = pick_vote(c->cpl, c->planes, true);
     if (d.G < 2 || c->n_rows == 0) return BMF_OK;

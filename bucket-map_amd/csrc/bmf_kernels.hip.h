@@ -43,6 +43,7 @@ struct DevParams {
     uint32_t pass1_rows; // two-pass variant: q-gram rows of each sample read at full width in pass 1 (1..G)
     uint32_t max_live;   // two-pass variant: live chunks (= lanes) an item may bring to the recount kernel (16 or 32)
     uint32_t item_base;  // two-pass variant: first (window, orientation) item of this launch (the batch goes out in slices)
+    uint32_t row_order;  // two-pass variant: the order in which a sample's G q-gram rows are taken, 4 bits each (see row_of)
 };
 
 __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
