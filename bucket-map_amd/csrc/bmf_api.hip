@@ -375,6 +375,31 @@ int bmf_create(const bmf_params *params, bmf_ctx **out) {
     d.ones_row = 0;
     d.n_kmers = 0;
     d.early_exit = (p.flags & BMF_FLAG_EARLY_EXIT) ? 1u : 0u;
+    {   // Order of a sample's G row ids in the lists the sample kernel writes: farthest-point order of the q-gram
+        // numbers -- 0, G-1, then whatever lies farthest from those taken (bmf_vote2.hip.h says why).  A permutation:
+        // the vote kernel ANDs all G and does not care.  BMF_ROW_ORDER=linear keeps 0, 1, 2, ... for comparison.
+        uint32_t order[8] = {0, 1, 2, 3, 4, 5, 6, 7}, n = 0;
+        const bool linear = getenv("BMF_ROW_ORDER") && !strcmp(getenv("BMF_ROW_ORDER"), "linear");
+        bool taken[8] = {};
+        while (!linear && n < d.G) {
+            uint32_t pick = 0;
+            int best_dist = -1;
+            for (uint32_t g = 0; g < d.G; g++) {
+                if (taken[g]) continue;
+                int dist = 99;
+                for (uint32_t t = 0; t < n; t++) dist = std::min(dist, abs((int)g - (int)order[t]));
+                if (n == 0) dist = g == 0 ? 99 : 0;
+                if (dist > best_dist || (dist == best_dist && g > pick)) {
+                    best_dist = dist;
+                    pick = g;
+                }
+            }
+            taken[pick] = true;
+            order[n++] = pick;
+        }
+        d.row_order = 0;
+        for (uint32_t i = 0; i < d.G; i++) d.row_order |= order[i] << (4u * i);
+    }
     // Sample kernel geometry: waves (= windows in flight) per workgroup and whether the 4^q-bit q-gram bitmap is
     // staged in LDS.  Two workgroups per CU (80 KiB each) where the buffers allow it: 32 waves per CU.
     {
@@ -468,31 +493,6 @@ static int select_pruned_variant(bmf_ctx *c) {
     c->dp.pass1_rows = 0;
     c->dp.max_live = bmf::kMaxLive;
     c->dp.item_base = 0;
-    {   // farthest-point order of a sample's G rows: 0, G-1, then whatever is farthest from those taken (bmf_vote2.hip.h
-        // row_of); BMF_ROW_ORDER=linear keeps 0, 1, 2, ... for comparison
-        uint32_t order[8], n = 0;
-        bool taken[8] = {};
-        const bool linear = getenv("BMF_ROW_ORDER") && !strcmp(getenv("BMF_ROW_ORDER"), "linear");
-        while (n < d.G) {
-            uint32_t pick = 0;
-            int best_dist = -1;
-            for (uint32_t g = 0; g < d.G; g++) {
-                if (taken[g]) continue;
-                int dist = 99;
-                for (uint32_t t = 0; t < n; t++) dist = std::min(dist, abs((int)g - (int)order[t]));
-                if (linear) dist = -(int)g;
-                if (dist > best_dist || (dist == best_dist && g > pick && !linear)) {
-                    best_dist = dist;
-                    pick = g;
-                }
-            }
-            if (n == 0 && !linear) pick = 0;
-            taken[pick] = true;
-            order[n++] = pick;
-        }
-        c->dp.row_order = 0;
-        for (uint32_t i = 0; i < d.G; i++) c->dp.row_order |= order[i] << (4u * i);
-    }
     if (!(c->p.flags & BMF_FLAG_EARLY_EXIT) || c->n_slices > 1) return BMF_OK;
     c->vote = pick_vote(c->cpl, c->planes, true);
     if (d.G < 2 || c->n_rows == 0) return BMF_OK;

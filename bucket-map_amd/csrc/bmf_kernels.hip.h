@@ -43,7 +43,7 @@ struct DevParams {
     uint32_t pass1_rows; // two-pass variant: q-gram rows of each sample read at full width in pass 1 (1..G)
     uint32_t max_live;   // two-pass variant: live chunks (= lanes) an item may bring to the recount kernel (16 or 32)
     uint32_t item_base;  // two-pass variant: first (window, orientation) item of this launch (the batch goes out in slices)
-    uint32_t row_order;  // two-pass variant: the order in which a sample's G q-gram rows are taken, 4 bits each (see row_of)
+    uint32_t row_order;  // entry i of a sample's G row ids is the row of q-gram (row_order >> 4i) & 15: a permutation of 0..G-1
 };
 
 __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
@@ -362,7 +362,10 @@ __global__ __launch_bounds__(1024, 8) void bmf_sample_kernel(   // 8 waves per S
             const uint32_t h = goodh[p];
             const uint32_t hr = revcomp_fast(h, P.k);
             for (uint32_t g = 0; g < P.G; g++) {
-                const uint32_t g1 = (h >> (2 * g)) & P.qbits, g2 = (hr >> (2 * g)) & P.qbits;
+                // entry g of the sample = its q-gram number row_order[g] (a permutation: the vote ANDs all G of them;
+                // the pruning passes that read only the first few want them far apart, bmf_vote2.hip.h)
+                const uint32_t gi = (P.row_order >> (4u * g)) & 15u;
+                const uint32_t g1 = (h >> (2 * gi)) & P.qbits, g2 = (hr >> (2 * gi)) & P.qbits;
                 const int32_t i1 = g1 < P.n_kmers ? k2i[g1] : -1;   // index_of_kmer, q_gram_mapper.h:374-377
                 const int32_t i2 = g2 < P.n_kmers ? k2i[g2] : -1;
                 list_fwd[s * P.G + g] = i1 >= 0 ? (uint32_t)i1 : P.ones_row;

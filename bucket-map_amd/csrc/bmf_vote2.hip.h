@@ -48,12 +48,11 @@ struct Pass2Queue {
     uint4 *live_mask;           // per live chunk: which of its 128 buckets were still below F misses after pass 1
 };
 
-// Which of a sample's G q-gram rows comes i-th.  The q-grams of a k-mer overlap: q-gram g and g+1 share q-1 bases,
-// so a bucket that holds one holds the other far more often than chance (an occurrence of the first continues into
-// the second with probability 1/4) and the rows of NEIGHBOURING q-grams AND to much less of a filter than
-// independent rows would.  The passes that read only some of the rows therefore take them far apart: 0, G-1, then the
-// middles (farthest-point order, bmf_api.hip).  The exact recount reads all G: the order does not matter there.
-__device__ __forceinline__ uint32_t row_of(const DevParams &P, uint32_t i) { return (P.row_order >> (4u * i)) & 15u; }
+// The row-id list of an item holds each sample's G rows in the order DevParams::row_order gives (the sample kernel
+// writes them so): 0, G-1, then the middles.  The q-grams of a k-mer overlap -- q-gram g and g+1 share q-1 bases, so a
+// bucket that holds one holds the other far more often than chance (an occurrence of the first continues into the
+// second with probability 1/4) -- and the rows of NEIGHBOURING q-grams AND to much less of a filter than independent
+// rows would.  The passes that read only the first few entries of a sample therefore get rows that lie far apart.
 
 // Counters in this file are BIASED: a bucket starts at 2^PLANES-1-F instead of 0, so that "F misses or more"
 // is exactly "the saturating counter is all ones" -- one AND per plane instead of a bit-sliced comparison
@@ -97,7 +96,7 @@ __device__ __forceinline__ bool stream_rows(const DevParams &P, const uint8_t *_
     }
     uint32_t ps = 0, pg = 0;   // prefetch cursor: sample, q-gram
     auto next_row = [&]() -> const uint8_t * {
-        const uint8_t *rp = rows + (size_t)list[ps * P.G + row_of(P, pg)] * P.pitch;
+        const uint8_t *rp = rows + (size_t)list[ps * P.G + pg] * P.pitch;
         if (++pg == r) {
             pg = 0;
             ++ps;
@@ -169,7 +168,7 @@ __device__ __forceinline__ bool stream_pass1(const DevParams &P, const uint8_t *
     u128 ring[DEPTH][CPL];
     uint32_t ps = 0, pg = 0;
     auto next_row = [&]() -> const uint8_t * {
-        const uint32_t id = ps < P.S ? list[ps * P.G + row_of(P, pg)] : P.ones_row;
+        const uint32_t id = ps < P.S ? list[ps * P.G + pg] : P.ones_row;
         if (++pg == r) {
             pg = 0;
             ++ps;
@@ -392,7 +391,7 @@ __device__ __forceinline__ uint32_t stream_column(const DevParams &P, const uint
         for (int x = 0; x < 4; x++) ring[d].v[x] = 0;
     uint32_t ps = s0, pg = 0;
     auto fetch = [&](u128 &dst) {
-        if (act) dst = load_chunk(rows + (size_t)list[ps * P.G + row_of(P, g0 + pg)] * P.pitch + off);
+        if (act) dst = load_chunk(rows + (size_t)list[ps * P.G + g0 + pg] * P.pitch + off);
         if (++pg == r) {
             pg = 0;
             ++ps;
