@@ -146,20 +146,29 @@ TwoPass pick_vote2(int cpl, int planes, int max_live) {
     return {};
 }
 
-// first pass over the folded index: NB <= 65 536 folds to at most 128 chunks per row, CPL 1 or 2
-template <int CPL>
+// first pass over a folded index: NB <= 65 536 folds by 4 to at most 128 chunks per row (CPL 1, 2), by 2 to 256 (1..4)
+template <int CPL, int FOLD>
 pass1_fn pick_fold_planes(int planes) {
     constexpr int D = depth_for(CPL);
     switch (planes) {
-    case 2: return bmf::bmf_pass1_kernel<CPL, 2, D, true>;
-    case 3: return bmf::bmf_pass1_kernel<CPL, 3, D, true>;
-    case 4: return bmf::bmf_pass1_kernel<CPL, 4, D, true>;
-    case 5: return bmf::bmf_pass1_kernel<CPL, 5, D, true>;
+    case 2: return bmf::bmf_pass1_kernel<CPL, 2, D, FOLD>;
+    case 3: return bmf::bmf_pass1_kernel<CPL, 3, D, FOLD>;
+    case 4: return bmf::bmf_pass1_kernel<CPL, 4, D, FOLD>;
+    case 5: return bmf::bmf_pass1_kernel<CPL, 5, D, FOLD>;
     }
     return nullptr;
 }
-pass1_fn pick_pass1_fold(int cpl, int planes) {
-    return cpl == 1 ? pick_fold_planes<1>(planes) : (cpl == 2 ? pick_fold_planes<2>(planes) : nullptr);
+pass1_fn pick_pass1_fold(int fold, int cpl, int planes) {
+    if (fold == 4) return cpl == 1 ? pick_fold_planes<1, 4>(planes) : (cpl == 2 ? pick_fold_planes<2, 4>(planes) : nullptr);
+    if (fold == 2) {
+        switch (cpl) {
+        case 1: return pick_fold_planes<1, 2>(planes);
+        case 2: return pick_fold_planes<2, 2>(planes);
+        case 3: return pick_fold_planes<3, 2>(planes);
+        case 4: return pick_fold_planes<4, 2>(planes);
+        }
+    }
+    return nullptr;
 }
 
 // P[Bin(n, p) >= m]
@@ -233,6 +242,16 @@ struct bmf_ctx {
     // folded first pass (bmf_fold4_kernel): one bit per group of 4 buckets, a quarter of the row bytes
     uint8_t *d_fold = nullptr;       // (n_rows + 1) x dpf.pitch
     bmf::DevParams dpf{};            // the folded geometry + rows per sample the folded pass reads
+    uint32_t fold = 1;               // 2 or 4 when pass1_fold is set
+    // The folded pass is chosen by a model of how many chunks survive it by chance.  Guard: every run's slow-path
+    // count comes back asynchronously; if more than 2 % of a run's items overflowed the recount kernel's lanes the
+    // model was wrong for this index and the context falls back to the unfolded choice for the runs that follow
+    // (outputs are identical either way).
+    uint32_t unfolded_rows = 0;      // pass 1 rows of the unfolded choice (0: the single-pass pruning kernel)
+    uint32_t *h_guard = nullptr;     // pinned: [recounted, slow, loads, -] of the last folded run
+    hipEvent_t guard_ev = nullptr;
+    uint64_t guard_items = 0;
+    bool guard_pending = false;
     pass1_fn pass1_fold = nullptr;   // non-null: pass 1 streams d_fold instead of d_rows
     size_t sample_lds = 0;
     bmf::SampleGeom sample_geom{};
@@ -474,6 +493,7 @@ static void free_index(bmf_ctx *c) {
     (void)hipFree(c->d_fold);
     c->d_fold = nullptr;
     c->pass1_fold = nullptr;
+    c->guard_pending = false;
     c->d_rows = nullptr;
     c->d_k2i = nullptr;
     c->d_zeros = nullptr;
@@ -515,7 +535,7 @@ static int select_pruned_variant(bmf_ctx *c) {
     // The same holds for very short rows (NB <= 2 048): the step is latency-bound and the plain kernel is the
     // fastest (E. coli-sized index: 177 M reads/s plain, 160 M with single-pass pruning; from NB ~ 3 800 on,
     // pruning wins again: 102 M plain, 129 M single-pass).
-    const bool fold_forced = getenv("BMF_FOLD") && atoi(getenv("BMF_FOLD")) == 4;
+    const bool fold_forced = getenv("BMF_FOLD") && atoi(getenv("BMF_FOLD")) > 1;
     if ((kept < 0.6 || d.n_chunks <= 16u) && !getenv("BMF_PASS1_ROWS") && !fold_forced) {
         c->vote = pick_vote(c->cpl, c->planes, false);
         return BMF_OK;
@@ -539,37 +559,58 @@ static int select_pruned_variant(bmf_ctx *c) {
         best_r = v > 0 && (uint32_t)v < d.G ? (uint32_t)v : 0u;
         if (best_r) best_live = (double)d.nb * binom_tail(d.S, pow(hit1, (double)best_r), d.S - d.F + 1u);
     }
-    // The folded first pass: a row of the folded index (one bit per group of 4 buckets) is a quarter of the bytes and
-    // leaves a group's bit set with probability 1 - (1 - d)^4, so r rows of it per sample cost what r/4 rows cost
-    // now and let an unrelated group through with probability (1 - (1 - d)^4)^r: at d = 0.22, three folded rows
-    // beat one full row on both counts.  Same cost model, groups instead of buckets.  BMF_FOLD=0|4 and
-    // BMF_FOLD_ROWS=r override (the sweeps force both forms).
-    uint32_t fold_r = 0;
+    // The folded first pass: a row of the index folded by f (one bit per group of f buckets) is 1/f of the bytes and
+    // leaves a group's bit set with probability 1 - (1 - d)^f, so r rows of it per sample cost what r/f rows cost
+    // now.  With the rows taken far apart (bmf_vote2.hip.h) they are close to independent and r of them let an
+    // unrelated group through with probability ~ (1 - (1 - d)^f)^r: at d = 0.22, two half-width rows cost what one
+    // full row costs and leave 0.1 instead of 7.6 chunks alive by chance.  Rows closer than 3 q-gram positions are
+    // NOT independent (an occurrence of one q-gram continues into the next with probability 4^-shift); the model
+    // prices that in, roughly.  Same cost model as above, groups instead of buckets.  BMF_FOLD=0|2|4 and
+    // BMF_FOLD_ROWS=r override (the sweeps force every form).
+    uint32_t fold_f = 1, fold_r = 0;
     double fold_live = 0.0;
     {
-        const double dens4 = 1.0 - pow(1.0 - dens, 4.0), hit4 = 1.0 - kept + kept * dens4;
-        const double groups = ((double)d.nb + 3.0) / 4.0, row4 = row_bytes / 4.0;
-        double best4 = best;
-        for (uint32_t r = 1; r <= d.G; r++) {
-            const double live = groups * binom_tail(d.S, pow(hit4, (double)r), d.S - d.F + 1u);
-            if (live > 20.0) continue;
-            const double cost = (double)d.S * r * row4 + live * d.S * sector + 1.0 * d.S * d.G * sector;
-            if (cost < best4) {
-                best4 = cost;
-                fold_r = r;
-                fold_live = live;
+        uint32_t order[8];
+        for (uint32_t i = 0; i < d.G; i++) order[i] = (d.row_order >> (4u * i)) & 15u;
+        auto survivors = [&](uint32_t f, uint32_t r) {
+            const double lambda = -log(1.0 - dens) * f, df = 1.0 - exp(-lambda);      // density of a folded row
+            const double occ = lambda / std::max(1e-9, df);                             // occurrences of a q-gram in a group that holds it
+            double p = 1.0;
+            for (uint32_t i = 0; i < r; i++) {
+                int shift = 99;
+                for (uint32_t t = 0; t < i; t++) shift = std::min(shift, abs((int)order[i] - (int)order[t]));
+                const double cont = i ? 1.0 - pow(1.0 - pow(0.25, (double)shift), occ) : 0.0;   // P[a neighbour's hit continues into this q-gram]
+                const double di = df + (1.0 - df) * cont;
+                p *= 1.0 - kept + kept * di;
+            }
+            return (((double)d.nb + f - 1.0) / f) * binom_tail(d.S, p, d.S - d.F + 1u);
+        };
+        double best_cost = best;
+        for (uint32_t f : {2u, 4u}) {
+            const uint32_t row_bytes_f = (uint32_t)((((double)d.nb + f - 1.0) / f + 7.0) / 8.0), chunks_f = (row_bytes_f + 15u) / 16u;
+            if (chunks_f > (f == 2 ? 256u : 128u)) continue;
+            for (uint32_t r = 1; r <= d.G; r++) {
+                const double live = survivors(f, r);
+                if (live > 8.0) continue;            // the model is rough: stay well clear of the slow path
+                const double cost = (double)d.S * r * (row_bytes / f) + live * d.S * sector + 1.0 * d.S * d.G * sector;
+                if (cost < best_cost) {
+                    best_cost = cost;
+                    fold_f = f;
+                    fold_r = r;
+                    fold_live = live;
+                }
             }
         }
         const char *ef = getenv("BMF_FOLD");
-        if (ef && atoi(ef) == 0) fold_r = 0;
-        if (getenv("BMF_PASS1_ROWS") && !(ef && atoi(ef) == 4)) fold_r = 0;   // an experiment asked for the unfolded passes
-        if (ef && atoi(ef) == 4) {
-            long v = getenv("BMF_FOLD_ROWS") ? strtol(getenv("BMF_FOLD_ROWS"), nullptr, 10) : (fold_r ? (long)fold_r : (long)d.G);
+        const int forced = ef ? atoi(ef) : -1;
+        if (forced == 0 || (getenv("BMF_PASS1_ROWS") && forced <= 0)) fold_r = 0;   // an experiment asked for the unfolded passes
+        if (forced == 2 || forced == 4) {
+            const long v = getenv("BMF_FOLD_ROWS") ? strtol(getenv("BMF_FOLD_ROWS"), nullptr, 10) : ((uint32_t)forced == fold_f && fold_r ? (long)fold_r : (long)d.G);
+            fold_f = (uint32_t)forced;
             fold_r = (uint32_t)std::max<long>(1, std::min<long>(v, (long)d.G));
-            fold_live = groups * binom_tail(d.S, pow(hit4, (double)fold_r), d.S - d.F + 1u);
+            fold_live = survivors(fold_f, fold_r);
         }
-        const uint32_t row_bytes_f = (uint32_t)((groups + 7.0) / 8.0), chunks_f = (row_bytes_f + 15u) / 16u;
-        if (chunks_f > 128u) fold_r = 0;                 // (cannot happen for NB <= 65 536)
+        c->unfolded_rows = best_r;
         if (fold_r) {
             best_r = best_r ? best_r : 1u;               // what the recount and the slow kernel call "pass 1's rows"
             best_live = fold_live;
@@ -590,13 +631,14 @@ static int select_pruned_variant(bmf_ctx *c) {
     if (fold_r && c->dp.pass1_rows) {
         bmf::DevParams &f = c->dpf;
         f = c->dp;
-        f.nb = (d.nb + 3u) / 4u;
+        f.nb = (d.nb + fold_f - 1u) / fold_f;
         const uint32_t row_bytes_f = (f.nb + 7u) >> 3;
         f.n_chunks = (row_bytes_f + 15u) / 16u;
         f.pitch = (row_bytes_f + 127u) & ~127u;
         f.pass1_rows = fold_r;
         const int cpl_f = (int)((f.n_chunks + 63u) / 64u);
-        c->pass1_fold = pick_pass1_fold(cpl_f, c->planes);
+        c->pass1_fold = pick_pass1_fold((int)fold_f, cpl_f, c->planes);
+        c->fold = fold_f;
         if (c->pass1_fold) {
             HIP_TRY(dev_alloc(&c->d_fold, (size_t)(c->n_rows + 1) * f.pitch));
             // whole rows per launch, grid.x * 256 threads below 2^32
@@ -604,7 +646,8 @@ static int select_pruned_variant(bmf_ctx *c) {
             for (uint64_t r0 = 0; r0 <= c->n_rows; r0 += rows_per_launch) {
                 const uint64_t nr = std::min<uint64_t>(rows_per_launch, c->n_rows + 1 - r0);
                 const uint64_t w = nr * (f.pitch >> 2);
-                hipLaunchKernelGGL(bmf::bmf_fold4_kernel, dim3((unsigned)((w + 255) / 256)), dim3(256), 0, c->stream,
+                auto fk = fold_f == 4 ? bmf::bmf_fold_kernel<4> : bmf::bmf_fold_kernel<2>;
+                hipLaunchKernelGGL(fk, dim3((unsigned)((w + 255) / 256)), dim3(256), 0, c->stream,
                                    c->d_rows + (size_t)r0 * c->dp.pitch, nr, c->dp.pitch, c->d_fold + (size_t)r0 * f.pitch, f.pitch);
             }
             HIP_TRY(hipGetLastError());
@@ -641,6 +684,11 @@ static void free_map_slots(bmf_ctx *c) {
     c->h2d = c->d2h = nullptr;
     if (c->side) (void)hipStreamDestroy(c->side);
     c->side = nullptr;
+    if (c->h_guard) (void)hipHostFree(c->h_guard);
+    c->h_guard = nullptr;
+    if (c->guard_ev) (void)hipEventDestroy(c->guard_ev);
+    c->guard_ev = nullptr;
+    c->guard_pending = false;
     for (auto &e : c->slice_done) {
         if (e) (void)hipEventDestroy(e);
         e = nullptr;
@@ -1065,6 +1113,13 @@ static int launch_filter(bmf_ctx *c, bmf_batch *b, const uint8_t *d_bases, const
                            b->rows_anded.p);
     }
     if (ev) HIP_TRY(hipEventRecord(ev[1], c->stream));
+    if (c->guard_pending && hipEventQuery(c->guard_ev) == hipSuccess) {
+        c->guard_pending = false;
+        if (c->pass1_fold && (uint64_t)c->h_guard[1] * 50u > c->guard_items && !getenv("BMF_FOLD")) {
+            c->pass1_fold = nullptr;                     // the folded pass lets too much through on this index:
+            c->dp.pass1_rows = c->unfolded_rows;         // back to the unfolded choice (0 = the single-pass pruning kernel)
+        }
+    }
     if (c->dp.pass1_rows) {
         // two-pass pruning: full-width lower-bound pass, then the queued items' exact recount (bmf_vote2.hip.h)
         const size_t n_items = 2 * (size_t)b->n_windows;
@@ -1124,6 +1179,16 @@ static int launch_filter(bmf_ctx *c, bmf_batch *b, const uint8_t *d_bases, const
         const unsigned slow_blocks = (unsigned)std::min<size_t>(n_items, 2048);
         hipLaunchKernelGGL(c->two_pass.slow, dim3(slow_blocks), dim3(bmf::kWave), 0, c->stream, c->dp, c->d_rows, b->lists.p,
                            b->counts.p, b->buckets.p, q);
+        if (c->pass1_fold && !c->guard_pending && n_items >= 4096) {   // the guard's sample: this run's slow-path count
+            if (!c->h_guard) {
+                HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&c->h_guard), 4 * sizeof(uint32_t), hipHostMallocDefault));
+                HIP_TRY(hipEventCreateWithFlags(&c->guard_ev, hipEventDisableTiming));
+            }
+            HIP_TRY(hipMemcpyAsync(c->h_guard, b->q_counters.p, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipEventRecord(c->guard_ev, c->stream));
+            c->guard_items = n_items;
+            c->guard_pending = true;
+        }
     } else if (c->n_slices == 1) {
         hipLaunchKernelGGL(c->vote, dim3(2 * b->n_windows), dim3(bmf::kWave), 0, c->stream, c->dp, c->d_rows, b->lists.p,
                            b->list_n.p, b->counts.p, b->buckets.p, (uint32_t *)nullptr);
@@ -1509,7 +1574,7 @@ int bmf_batch_recount_loads(bmf_ctx *c, bmf_batch *b, uint64_t *loads) {
 
 int bmf_pass1_fold(bmf_ctx *c, uint32_t *fold, uint32_t *rows) {
     if (!c || !fold || !rows) return fail(BMF_ERR_ARG, "bmf_pass1_fold: null argument");
-    *fold = c->pass1_fold ? 4u : 1u;
+    *fold = c->pass1_fold ? c->fold : 1u;
     *rows = c->pass1_fold ? c->dpf.pass1_rows : c->dp.pass1_rows;
     return BMF_OK;
 }

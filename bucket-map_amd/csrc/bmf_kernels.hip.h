@@ -101,8 +101,8 @@ __global__ void bmf_sanitize_rows_kernel(uint8_t *rows, uint64_t n_rows, uint32_
     rows[r * pitch + last] &= (uint8_t)(0xFFu >> (8u - (nb & 7u)));
 }
 
-// Exact pruning, folded first pass (bmf_vote2.hip.h): row g of the FOLDED index has bit i set iff any of the buckets
-// 4i .. 4i+3 is set in row g.  One thread per output word (32 groups = 128 buckets = one 16-byte chunk of the row).
+// Exact pruning, folded first pass (bmf_vote2.hip.h): row g of the index FOLDED by f (2 or 4) has bit i set iff any of
+// the buckets f*i .. f*i+f-1 is set in row g.  One thread per output word (32 groups).
 __device__ __forceinline__ uint32_t fold4_byte(uint32_t w) {     // 32 bits -> 8: bit i = OR of bits 4i .. 4i+3
     uint32_t t = w | (w >> 1);
     t = (t | (t >> 2)) & 0x11111111u;
@@ -116,8 +116,23 @@ __device__ __forceinline__ uint32_t spread4_byte(uint32_t b) {   // 8 bits -> 32
     x = (x | (x << 3)) & 0x11111111u;
     return x * 0xFu;
 }
-__global__ void bmf_fold4_kernel(const uint8_t *__restrict__ rows, uint64_t n_rows, uint32_t pitch,
-                                 uint8_t *__restrict__ folded, uint32_t pitch_f) {
+__device__ __forceinline__ uint32_t fold2_half(uint32_t w) {     // 32 bits -> 16: bit i = OR of bits 2i, 2i+1
+    uint32_t t = (w | (w >> 1)) & 0x55555555u;
+    t = (t | (t >> 1)) & 0x33333333u;
+    t = (t | (t >> 2)) & 0x0F0F0F0Fu;
+    t = (t | (t >> 4)) & 0x00FF00FFu;
+    return (t | (t >> 8)) & 0xFFFFu;
+}
+__device__ __forceinline__ uint32_t spread2_half(uint32_t b) {   // 16 bits -> 32: bit i goes to bits 2i, 2i+1
+    uint32_t x = (b | (b << 8)) & 0x00FF00FFu;
+    x = (x | (x << 4)) & 0x0F0F0F0Fu;
+    x = (x | (x << 2)) & 0x33333333u;
+    x = (x | (x << 1)) & 0x55555555u;
+    return x * 3u;
+}
+template <int FOLD>
+__global__ void bmf_fold_kernel(const uint8_t *__restrict__ rows, uint64_t n_rows, uint32_t pitch,
+                                uint8_t *__restrict__ folded, uint32_t pitch_f) {
     const uint32_t words_f = pitch_f >> 2, words = pitch >> 2;
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_rows * words_f) return;
@@ -126,8 +141,11 @@ __global__ void bmf_fold4_kernel(const uint8_t *__restrict__ rows, uint64_t n_ro
     const uint32_t *in = reinterpret_cast<const uint32_t *>(rows + r * pitch);
     uint32_t out = 0;
 #pragma unroll
-    for (uint32_t k = 0; k < 4; k++)
-        if (4u * ow + k < words) out |= fold4_byte(in[4u * ow + k]) << (8u * k);
+    for (uint32_t k = 0; k < (uint32_t)FOLD; k++)
+        if ((uint32_t)FOLD * ow + k < words) {
+            const uint32_t w = in[(uint32_t)FOLD * ow + k];
+            out |= FOLD == 4 ? fold4_byte(w) << (8u * k) : fold2_half(w) << (16u * k);
+        }
     reinterpret_cast<uint32_t *>(folded + r * pitch_f)[ow] = out;
 }
 

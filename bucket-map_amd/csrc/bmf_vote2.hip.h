@@ -233,12 +233,13 @@ __device__ __forceinline__ void full_width_slots(const DevParams &P, uint32_t la
     }
 }
 
-// FOLD4: `rows` is the folded index (one bit per group of 4 buckets, bmf_fold4_kernel) and P its geometry (nb =
-// groups, n_chunks, pitch).  A group's AND over folded rows is set whenever any of its buckets' ANDs is, so the
-// group's miss count is a lower bound for each of its 4 buckets: a quarter of the bytes per row buys r = 3 or 4
-// rows per sample instead of 1, and far fewer chunks survive by chance.  A 32-group word of a folded chunk is
-// exactly one 128-bucket chunk of the index; its alive bits, spread 4x, are that chunk's live-bucket mask.
-template <int CPL, int PLANES, int DEPTH, bool FOLD4>
+// FOLD = 2 or 4: `rows` is the folded index (one bit per group of FOLD buckets, bmf_fold_kernel) and P its geometry (nb
+// = groups, n_chunks, pitch).  A group's AND over folded rows is set whenever any of its buckets' ANDs is, so the
+// group's miss count is a lower bound for each of its buckets: 1/FOLD of the bytes per row buys more rows per sample
+// -- taken far apart, see above -- and far fewer chunks survive by chance.  A folded 16-byte chunk covers FOLD chunks
+// of the index: FOLD = 4, each of its 32-group words is one 128-bucket chunk; FOLD = 2, each pair of words is; the
+// alive bits, spread FOLD-fold, are that chunk's live-bucket mask.
+template <int CPL, int PLANES, int DEPTH, int FOLD>
 __device__ __forceinline__ void pass1_item(const DevParams &P, const uint8_t *__restrict__ rows,
                                            const uint32_t *__restrict__ row_lists, const uint32_t *__restrict__ list_n,
                                            uint32_t *__restrict__ out_counts, const Pass2Queue &Q) {
@@ -265,7 +266,7 @@ __device__ __forceinline__ void pass1_item(const DevParams &P, const uint8_t *__
     }
     // chunks that still hold a bucket with < F misses, in ascending chunk order
     uint32_t n_live = 0;
-    if (!FOLD4) {
+    if (FOLD == 1) {
 #pragma unroll
         for (int j = 0; j < CPL; j++) {
             uint32_t a = 0;
@@ -283,15 +284,19 @@ __device__ __forceinline__ void pass1_item(const DevParams &P, const uint8_t *__
             n_live += (uint32_t)__popcll(m);
         }
     } else {
+        constexpr int kSub = FOLD == 4 ? 4 : 2;         // chunks of the index under one folded chunk
 #pragma unroll
         for (int j = 0; j < CPL; j++) {
             uint32_t aw[4], mine = 0;
 #pragma unroll
-            for (int x = 0; x < 4; x++) {
-                aw[x] = alive_word<CPL, PLANES>(cnt, j, x);
-                mine += aw[x] != 0 ? 1u : 0u;
+            for (int x = 0; x < 4; x++) aw[x] = alive_word<CPL, PLANES>(cnt, j, x);
+            bool live[kSub];
+#pragma unroll
+            for (int h = 0; h < kSub; h++) {
+                live[h] = FOLD == 4 ? aw[h] != 0 : (aw[2 * h] | aw[2 * h + 1]) != 0;
+                mine += live[h] ? 1u : 0u;
             }
-            uint32_t incl = mine;                       // lanes in order, a lane's words in order: ascending chunk ids
+            uint32_t incl = mine;                       // lanes in order, a lane's chunks in order: ascending chunk ids
 #pragma unroll
             for (int o = 1; o < kWave; o <<= 1) {
                 const uint32_t t = __shfl_up(incl, o, kWave);
@@ -299,13 +304,15 @@ __device__ __forceinline__ void pass1_item(const DevParams &P, const uint8_t *__
             }
             uint32_t at = n_live + incl - mine;
 #pragma unroll
-            for (int x = 0; x < 4; x++)
-                if (aw[x] != 0) {
+            for (int h = 0; h < kSub; h++)
+                if (live[h]) {
                     if (at < P.max_live) {
-                        Q.live_chunks[(size_t)item * P.max_live + at] = (uint16_t)(cidx[j] * 4u + (uint32_t)x);
+                        Q.live_chunks[(size_t)item * P.max_live + at] = (uint16_t)(cidx[j] * (uint32_t)kSub + (uint32_t)h);
                         Q.live_mask[(size_t)item * P.max_live + at] =
-                            make_uint4(spread4_byte(aw[x] & 0xFFu), spread4_byte((aw[x] >> 8) & 0xFFu),
-                                       spread4_byte((aw[x] >> 16) & 0xFFu), spread4_byte(aw[x] >> 24));
+                            FOLD == 4 ? make_uint4(spread4_byte(aw[h] & 0xFFu), spread4_byte((aw[h] >> 8) & 0xFFu),
+                                                   spread4_byte((aw[h] >> 16) & 0xFFu), spread4_byte(aw[h] >> 24))
+                                      : make_uint4(spread2_half(aw[2 * h] & 0xFFFFu), spread2_half(aw[2 * h] >> 16),
+                                                   spread2_half(aw[2 * h + 1] & 0xFFFFu), spread2_half(aw[2 * h + 1] >> 16));
                     }
                     at++;
                 }
@@ -322,12 +329,12 @@ __device__ __forceinline__ void pass1_item(const DevParams &P, const uint8_t *__
     }
 }
 
-template <int CPL, int PLANES, int DEPTH, bool FOLD4 = false>
+template <int CPL, int PLANES, int DEPTH, int FOLD = 1>
 __global__ __launch_bounds__(kWave) void bmf_pass1_kernel(DevParams P, const uint8_t *__restrict__ rows,
                                                          const uint32_t *__restrict__ row_lists,
                                                          const uint32_t *__restrict__ list_n,
                                                          uint32_t *__restrict__ out_counts, Pass2Queue Q) {
-    pass1_item<CPL, PLANES, DEPTH, FOLD4>(P, rows, row_lists, list_n, out_counts, Q);
+    pass1_item<CPL, PLANES, DEPTH, FOLD>(P, rows, row_lists, list_n, out_counts, Q);
 }
 
 // best_results (q_gram_mapper.h:90-102,471-476) over the kMaxLive lanes of one item: lane i holds the exact

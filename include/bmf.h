@@ -167,9 +167,9 @@ int  bmf_info(bmf_ctx *ctx, uint32_t *row_pitch_bytes, uint32_t *chunks_per_lane
 /* BMF_FLAG_EARLY_EXIT only: index rows per sample the first pass of the two-pass pruning kernel streams
  * for the loaded index; 0 = the single-pass pruning kernel (or no pruning) serves it. */
 int  bmf_pass1_rows(bmf_ctx *ctx, uint32_t *out);
-/* Same flag: the form of that first pass.  fold = 4: it streams a FOLDED copy of the index (one bit per group of 4
- * buckets, a quarter of the bytes per row, built at load time) and reads `rows` of its rows per sample; fold = 1: it
- * streams `rows` rows of the index itself (0 when another kernel serves the index). */
+/* Same flag: the form of that first pass.  fold = 2 or 4: it streams a FOLDED copy of the index (one bit per group of
+ * `fold` buckets, 1/fold of the bytes per row, built at load time) and reads `rows` of its rows per sample; fold = 1:
+ * it streams `rows` rows of the index itself (0 when another kernel serves the index). */
 int  bmf_pass1_fold(bmf_ctx *ctx, uint32_t *fold, uint32_t *rows);
 /* Two-pass pruning, after a run of `batch`: how many (window, orientation) items still had a live bucket after
  * the first pass and went to the packed recount kernel, and how many took the slow full-width path.  Both 0

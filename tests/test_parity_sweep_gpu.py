@@ -53,11 +53,11 @@ def random_case(rng, *, nb, q, k, S, F, max_cand, kmer_frac, density, read_len, 
     if k > q:
         # the two-pass pruning kernel, forced (the library only picks it for sparse indexes), r rows in pass 1
         # and either form of the recount kernel (16 or 32 lanes per item), whatever the density model would pick
-        # and either form of its first pass: r rows of the index itself, or r rows of the index folded 4 buckets to a bit
-        fold = bool(rng.integers(0, 2))
+        # and either form of its first pass: r rows of the index itself, or r rows of the index folded 2 or 4 buckets to a bit
+        fold = int(rng.choice([0, 2, 4]))
         os.environ["BMF_PASS1_ROWS"] = str(int(rng.integers(1, k - q + 1)))
         os.environ["BMF_MAX_LIVE"] = str(int(rng.choice([16, 32])))
-        os.environ["BMF_FOLD"] = "4" if fold else "0"
+        os.environ["BMF_FOLD"] = str(fold)
         os.environ["BMF_FOLD_ROWS"] = str(int(rng.integers(1, k - q + 2)))
         try:
             f2 = bma.Filter(bma.Params(num_buckets=nb, flags=bma.BMF_FLAG_EARLY_EXIT, **kw))
@@ -65,7 +65,7 @@ def random_case(rng, *, nb, q, k, S, F, max_cand, kmer_frac, density, read_len, 
         finally:
             for name in ("BMF_PASS1_ROWS", "BMF_MAX_LIVE", "BMF_FOLD", "BMF_FOLD_ROWS"):
                 del os.environ[name]
-        assert f2.info()["pass1_rows"] >= 1 and f2.info()["pass1_fold"] == (4 if fold else 1)
+        assert f2.info()["pass1_rows"] >= 1 and f2.info()["pass1_fold"] == (fold if fold else 1)
         # ... in one piece, or in slices whose recounts run on a second stream under the next slice's first pass
         os.environ["BMF_SLICES"] = str(int(rng.choice([1, 3, 8])))
         try:
