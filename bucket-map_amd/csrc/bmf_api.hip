@@ -1115,7 +1115,8 @@ static int launch_filter(bmf_ctx *c, bmf_batch *b, const uint8_t *d_bases, const
     if (ev) HIP_TRY(hipEventRecord(ev[1], c->stream));
     if (c->guard_pending && hipEventQuery(c->guard_ev) == hipSuccess) {
         c->guard_pending = false;
-        if (c->pass1_fold && (uint64_t)c->h_guard[1] * 50u > c->guard_items && !getenv("BMF_FOLD")) {
+        const bool trip = (uint64_t)c->h_guard[1] * 50u > c->guard_items || getenv("BMF_GUARD_TRIP");   // (the env: tests)
+        if (c->pass1_fold && trip && !getenv("BMF_FOLD")) {
             c->pass1_fold = nullptr;                     // the folded pass lets too much through on this index:
             c->dp.pass1_rows = c->unfolded_rows;         // back to the unfolded choice (0 = the single-pass pruning kernel)
         }

@@ -162,6 +162,31 @@ def test_sample_kernel_lds_regimes(read_len, expect_bitmap_lds):
     assert (32768 + per_wave <= 159 * 1024) == expect_bitmap_lds
 
 
+def test_folded_first_pass_and_its_fallback_guard():
+    """The pruning kernels' first pass normally streams a folded copy of the index (one bit per 2 or 4 buckets), chosen
+    by a model of how many chunks survive it by chance; a measured guard switches a context back to the unfolded
+    passes when the model turns out wrong.  Both forms, and the switch itself, give the oracle's outputs."""
+    import bucket_map_amd as bma
+    case = Case(record_lengths=[26507 * 256 - 17], bucket_len=256, read_len=100, n_reads=6000, q=7, k=10, sub=0.01, seed=20240200)
+    rd = case.reads
+    ws, wl, _ = _windows(case)
+    c_ref, b_ref, _ = oracle_map_windows(case.oracle_index(), rd.bases, rd.quals, ws, wl)
+    flt = case.gpu_filter(flags=bma.BMF_FLAG_EARLY_EXIT)
+    assert flt.info()["pass1_fold"] in (2, 4) and flt.info()["pass1_fold_rows"] >= 1
+    c, b = flt.map_windows(rd.bases, rd.quals, ws, wl)
+    assert_same_candidates(c_ref, b_ref, c, b, "folded first pass")
+    os.environ["BMF_GUARD_TRIP"] = "1"                  # pretend the last run overflowed the recount kernel's lanes
+    try:
+        c, b = flt.map_windows(rd.bases, rd.quals, ws, wl)   # this call notices and falls back ...
+    finally:
+        del os.environ["BMF_GUARD_TRIP"]
+    assert_same_candidates(c_ref, b_ref, c, b, "the call that falls back")
+    assert flt.info()["pass1_fold"] == 1                    # ... for good
+    c, b = flt.map_windows(rd.bases, rd.quals, ws, wl)
+    assert_same_candidates(c_ref, b_ref, c, b, "after the fallback")
+    flt.close()
+
+
 def test_repeats_overflow_max_candidates():
     # 40 identical records -> a read matches > 30 buckets equally well -> list cleared (q_gram_mapper.h:471-476)
     from bucket_map_amd import host
