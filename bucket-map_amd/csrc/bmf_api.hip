@@ -248,7 +248,6 @@ struct bmf_ctx {
     // model was wrong for this index and the context falls back to the unfolded choice for the runs that follow
     // (outputs are identical either way).
     uint32_t unfolded_rows = 0;      // pass 1 rows of the unfolded choice (0: the single-pass pruning kernel)
-    uint32_t tail_of = 0xFFFFFFFFu, tail_unfolded = 0xFFFFFFFFu;   // DevParams::tail_rows of the folded / unfolded pass 1
     uint32_t *h_guard = nullptr;     // pinned: [recounted, slow, loads, -] of the last folded run
     hipEvent_t guard_ev = nullptr;
     uint64_t guard_items = 0;
@@ -395,7 +394,6 @@ int bmf_create(const bmf_params *params, bmf_ctx **out) {
     d.ones_row = 0;
     d.n_kmers = 0;
     d.early_exit = (p.flags & BMF_FLAG_EARLY_EXIT) ? 1u : 0u;
-    d.tail_rows = 0xFFFFFFFFu;
     {   // Order of a sample's G row ids in the lists the sample kernel writes: farthest-point order of the q-gram
         // numbers -- 0, G-1, then whatever lies farthest from those taken (bmf_vote2.hip.h says why).  A permutation:
         // the vote kernel ANDs all G and does not care.  BMF_ROW_ORDER=linear keeps 0, 1, 2, ... for comparison.
@@ -574,7 +572,7 @@ static int select_pruned_variant(bmf_ctx *c) {
     {
         uint32_t order[8];
         for (uint32_t i = 0; i < d.G; i++) order[i] = (d.row_order >> (4u * i)) & 15u;
-        auto hit_prob = [&](uint32_t f, uint32_t r) {
+        auto survivors = [&](uint32_t f, uint32_t r) {
             const double lambda = -log(1.0 - dens) * f, df = 1.0 - exp(-lambda);      // density of a folded row
             const double occ = lambda / std::max(1e-9, df);                             // occurrences of a q-gram in a group that holds it
             double p = 1.0;
@@ -585,27 +583,8 @@ static int select_pruned_variant(bmf_ctx *c) {
                 const double di = df + (1.0 - df) * cont;
                 p *= 1.0 - kept + kept * di;
             }
-            return p;                                                                   // P[an unrelated group hits a sample]
+            return (((double)d.nb + f - 1.0) / f) * binom_tail(d.S, p, d.S - d.F + 1u);
         };
-        auto survivors = [&](uint32_t f, uint32_t r) {
-            return (((double)d.nb + f - 1.0) / f) * binom_tail(d.S, hit_prob(f, r), d.S - d.F + 1u);
-        };
-        // Pass 1's tail: the first sample count after which at most half of the 128-group chunks still hold a group
-        // below F misses; from there on lanes load only chunks with a live group (bmf_vote2.hip.h stream_pass1).
-        auto tail_rows_of = [&](uint32_t f, uint32_t r) -> uint32_t {
-            if (const char *env = getenv("BMF_TAIL")) {
-                if (!strcmp(env, "off")) return 0xFFFFFFFFu;
-                const long v = strtol(env, nullptr, 10);
-                return v >= (long)d.S ? 0xFFFFFFFFu : (uint32_t)std::max<long>(v, 1) * r;
-            }
-            const double p = hit_prob(f, r);
-            for (uint32_t n = d.F; n + 1 < d.S; n++) {
-                const double alive = binom_tail(n, p, n - d.F + 1u);
-                if (1.0 - pow(1.0 - alive, 128.0) <= 0.5) return n * r;
-            }
-            return 0xFFFFFFFFu;
-        };
-        c->tail_of = 0xFFFFFFFFu;
         double best_cost = best;
         for (uint32_t f : {2u, 4u}) {
             const uint32_t row_bytes_f = (uint32_t)((((double)d.nb + f - 1.0) / f + 7.0) / 8.0), chunks_f = (row_bytes_f + 15u) / 16u;
@@ -632,9 +611,7 @@ static int select_pruned_variant(bmf_ctx *c) {
             fold_live = survivors(fold_f, fold_r);
         }
         c->unfolded_rows = best_r;
-        c->tail_unfolded = best_r ? tail_rows_of(1, best_r) : 0xFFFFFFFFu;
         if (fold_r) {
-            c->tail_of = tail_rows_of(fold_f, fold_r);
             best_r = best_r ? best_r : 1u;               // what the recount and the slow kernel call "pass 1's rows"
             best_live = fold_live;
         }
@@ -649,7 +626,6 @@ static int select_pruned_variant(bmf_ctx *c) {
         if (c->two_pass.pass1) {
             c->dp.pass1_rows = best_r;
             c->dp.max_live = (uint32_t)max_live;
-            c->dp.tail_rows = c->tail_unfolded;
         }
     }
     if (fold_r && c->dp.pass1_rows) {
@@ -660,7 +636,6 @@ static int select_pruned_variant(bmf_ctx *c) {
         f.n_chunks = (row_bytes_f + 15u) / 16u;
         f.pitch = (row_bytes_f + 127u) & ~127u;
         f.pass1_rows = fold_r;
-        f.tail_rows = c->tail_of;
         const int cpl_f = (int)((f.n_chunks + 63u) / 64u);
         c->pass1_fold = pick_pass1_fold((int)fold_f, cpl_f, c->planes);
         c->fold = fold_f;

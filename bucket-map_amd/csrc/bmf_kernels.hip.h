@@ -43,7 +43,6 @@ struct DevParams {
     uint32_t pass1_rows; // two-pass variant: q-gram rows of each sample read at full width in pass 1 (1..G)
     uint32_t max_live;   // two-pass variant: live chunks (= lanes) an item may bring to the recount kernel (16 or 32)
     uint32_t item_base;  // two-pass variant: first (window, orientation) item of this launch (the batch goes out in slices)
-    uint32_t tail_rows;  // two-pass variant: rows of pass 1 read unconditionally; from there on only chunks with a live bucket
     uint32_t row_order;  // entry i of a sample's G row ids is the row of q-gram (row_order >> 4i) & 15: a permutation of 0..G-1
 };
 

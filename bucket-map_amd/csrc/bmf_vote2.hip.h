@@ -159,18 +159,12 @@ __device__ __forceinline__ bool stream_rows(const DevParams &P, const uint8_t *_
 // row ids past the last one are the all-ones row, so the compiler can wait for exactly the oldest row in
 // flight and the kernel needs fewer registers than the predicated form.  The all-dead test runs once per
 // ring round (one copy of that code instead of DEPTH).
-// The TAIL (P.tail_rows < S*r): by then most 128-group chunks hold no group below F misses any more -- an unrelated
-// group needs S-F+1 hits and has had most of its chances -- so from row P.tail_rows on a lane loads a chunk only
-// while it holds a live group (typically the lanes of the read's own chunk and a few lucky ones; a skipped load
-// ANDs stale data into counters that are at F already, which changes nothing).  A second loop, so that the first
-// keeps its unconditional loads and counted waits.
 template <int CPL, int PLANES, int DEPTH>
 __device__ __forceinline__ bool stream_pass1(const DevParams &P, const uint8_t *__restrict__ rows,
                                              const uint32_t *__restrict__ list, uint32_t r, const uint32_t (&coff)[CPL],
-                                             const bool (&in_row)[CPL], u128 (&cnt)[PLANES][CPL]) {
+                                             u128 (&cnt)[PLANES][CPL]) {
     const uint32_t n_rows = P.S * r;
     const uint32_t n_iter = (n_rows + DEPTH - 1) / DEPTH * DEPTH;
-    const uint32_t n_head = P.tail_rows < n_iter ? P.tail_rows / DEPTH * DEPTH : n_iter;   // whole ring rounds
     u128 ring[DEPTH][CPL];
     uint32_t ps = 0, pg = 0;
     auto next_row = [&]() -> const uint8_t * {
@@ -193,15 +187,7 @@ __device__ __forceinline__ bool stream_pass1(const DevParams &P, const uint8_t *
 #pragma unroll
         for (int x = 0; x < 4; x++) bf[j].v[x] = 0xFFFFFFFFu;
     uint32_t g = 0, samples_done = 0;
-    auto all_dead = [&]() {
-        uint32_t alive = 0;
-#pragma unroll
-        for (int j = 0; j < CPL; j++)
-#pragma unroll
-            for (int x = 0; x < 4; x++) alive |= alive_word<CPL, PLANES>(cnt, j, x);
-        return __ballot(alive != 0) == 0;
-    };
-    for (uint32_t t = 0; t < n_head; t += DEPTH) {
+    for (uint32_t t = 0; t < n_iter; t += DEPTH) {
 #pragma unroll
         for (int d = 0; d < DEPTH; d++) {
 #pragma unroll
@@ -217,38 +203,14 @@ __device__ __forceinline__ bool stream_pass1(const DevParams &P, const uint8_t *
                 ++samples_done;
             }
         }
-        if (samples_done >= P.F && samples_done < P.S && all_dead()) return false;
-    }
-    if (n_head == n_iter) return true;
-    bool act[CPL];
-    auto refresh = [&]() {
-#pragma unroll
-        for (int j = 0; j < CPL; j++)
-            act[j] = in_row[j] && (alive_word<CPL, PLANES>(cnt, j, 0) | alive_word<CPL, PLANES>(cnt, j, 1) |
-                                   alive_word<CPL, PLANES>(cnt, j, 2) | alive_word<CPL, PLANES>(cnt, j, 3)) != 0;
-    };
-#pragma unroll
-    for (int j = 0; j < CPL; j++) act[j] = in_row[j];
-    if (samples_done >= P.F) refresh();
-    for (uint32_t t = n_head; t < n_iter; t += DEPTH) {
-#pragma unroll
-        for (int d = 0; d < DEPTH; d++) {
+        if (samples_done >= P.F && samples_done < P.S) {
+            uint32_t alive = 0;
 #pragma unroll
             for (int j = 0; j < CPL; j++)
 #pragma unroll
-                for (int x = 0; x < 4; x++) bf[j].v[x] &= ring[d][j].v[x];
-            const uint8_t *rp = next_row();
-#pragma unroll
-            for (int j = 0; j < CPL; j++)
-                if (act[j]) ring[d][j] = load_chunk(rp + coff[j]);
-            if (++g == r) {
-                g = 0;
-                count_misses<CPL, PLANES>(bf, cnt);
-                ++samples_done;
-                if (samples_done >= P.F) refresh();
-            }
+                for (int x = 0; x < 4; x++) alive |= alive_word<CPL, PLANES>(cnt, j, x);
+            if (__ballot(alive != 0) == 0) return false;
         }
-        if (samples_done >= P.F && samples_done < P.S && all_dead()) return false;
     }
     return true;
 }
@@ -295,7 +257,7 @@ __device__ __forceinline__ void pass1_item(const DevParams &P, const uint8_t *__
     bool act[CPL];
     u128 cnt[PLANES][CPL];
     full_width_slots<CPL, PLANES>(P, lane, cidx, coff, act, cnt);
-    if (!stream_pass1<CPL, PLANES, DEPTH>(P, rows, list, P.pass1_rows, coff, act, cnt)) {
+    if (!stream_pass1<CPL, PLANES, DEPTH>(P, rows, list, P.pass1_rows, coff, cnt)) {
         if (lane == 0) {
             out_counts[item] = 0;
             Q.live_n[item] = 0;

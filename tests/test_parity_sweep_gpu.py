@@ -59,13 +59,11 @@ def random_case(rng, *, nb, q, k, S, F, max_cand, kmer_frac, density, read_len, 
         os.environ["BMF_MAX_LIVE"] = str(int(rng.choice([16, 32])))
         os.environ["BMF_FOLD"] = str(fold)
         os.environ["BMF_FOLD_ROWS"] = str(int(rng.integers(1, k - q + 2)))
-        # ... with its tail (loads only for chunks that still hold a live bucket) starting anywhere, or never
-        os.environ["BMF_TAIL"] = str(rng.choice(["off", str(int(rng.integers(1, S + 1)))]))
         try:
             f2 = bma.Filter(bma.Params(num_buckets=nb, flags=bma.BMF_FLAG_EARLY_EXIT, **kw))
             f2.load_index(rows, k2i)
         finally:
-            for name in ("BMF_PASS1_ROWS", "BMF_MAX_LIVE", "BMF_FOLD", "BMF_FOLD_ROWS", "BMF_TAIL"):
+            for name in ("BMF_PASS1_ROWS", "BMF_MAX_LIVE", "BMF_FOLD", "BMF_FOLD_ROWS"):
                 del os.environ[name]
         assert f2.info()["pass1_rows"] >= 1 and f2.info()["pass1_fold"] == (fold if fold else 1)
         # ... in one piece, or in slices whose recounts run on a second stream under the next slice's first pass
