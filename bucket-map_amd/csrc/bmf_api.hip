@@ -117,9 +117,7 @@ TwoPass two_pass_of(int max_live) {
         const char *env = getenv("BMF_PASS1_SHALLOW");
         if (env && env[0] == '1') p1 = bmf::bmf_pass1_kernel<CPL, PLANES, D - 1>;
     }
-    recount_fn rc = max_live <= 4 ? bmf::bmf_recount_kernel<PLANES, 4>
-                    : (max_live <= 8 ? bmf::bmf_recount_kernel<PLANES, 8>
-                                     : (max_live <= 16 ? bmf::bmf_recount_kernel<PLANES, 16> : bmf::bmf_recount_kernel<PLANES, 32>));
+    recount_fn rc = max_live <= 16 ? bmf::bmf_recount_kernel<PLANES, 16> : bmf::bmf_recount_kernel<PLANES, 32>;
     return {p1, rc, bmf::bmf_vote2_slow_kernel<CPL, PLANES, D>};
 }
 
@@ -619,16 +617,11 @@ static int select_pruned_variant(bmf_ctx *c) {
         }
     }
     if (best_r) {
-        // Lanes per item in the recount kernel -- its instruction stream is per wave, and only the lanes with a live
-        // chunk do useful work: as few as keep items with more live chunks than lanes rare.  The by-chance survivors
-        // are Poisson around best_live, plus the read's own chunk: 4 lanes (16 items per wave) after a folded first
-        // pass that leaves next to nothing alive by chance, then 8, 16, 32.  BMF_MAX_LIVE=4|8|16|32 overrides (the
-        // sweeps force all of them).
-        int max_live = best_live <= 0.35 ? 4 : (best_live <= 2.0 ? 8 : (best_live + 1.0 <= 9.0 ? 16 : 32));
-        if (const char *env = getenv("BMF_MAX_LIVE")) {
-            const int v = atoi(env);
-            max_live = v == 4 || v == 8 || v == 16 ? v : 32;
-        }
+        // Lanes per item in the recount kernel: 16 (four items per wave) while items with more than 16 live chunks stay
+        // rare -- the by-chance survivors are Poisson around best_live, plus the read's own chunk -- else 32.
+        // BMF_MAX_LIVE=16|32 overrides (the sweeps force both).
+        int max_live = best_live + 1.0 <= 9.0 ? 16 : 32;
+        if (const char *env = getenv("BMF_MAX_LIVE")) max_live = atoi(env) == 16 ? 16 : 32;
         c->two_pass = pick_vote2(c->cpl, c->planes, max_live);
         if (c->two_pass.pass1) {
             c->dp.pass1_rows = best_r;

@@ -52,11 +52,11 @@ def random_case(rng, *, nb, q, k, S, F, max_cand, kmer_frac, density, read_len, 
     assert_same_candidates(c_ref, b_ref, c_1, b_1, "single-pass pruning forced")
     if k > q:
         # the two-pass pruning kernel, forced (the library only picks it for sparse indexes), r rows in pass 1
-        # and either form of the recount kernel (4, 8, 16 or 32 lanes per item), whatever the density model would pick
+        # and either form of the recount kernel (16 or 32 lanes per item), whatever the density model would pick
         # and either form of its first pass: r rows of the index itself, or r rows of the index folded 2 or 4 buckets to a bit
         fold = int(rng.choice([0, 2, 4]))
         os.environ["BMF_PASS1_ROWS"] = str(int(rng.integers(1, k - q + 1)))
-        os.environ["BMF_MAX_LIVE"] = str(int(rng.choice([4, 8, 16, 32])))
+        os.environ["BMF_MAX_LIVE"] = str(int(rng.choice([16, 32])))
         os.environ["BMF_FOLD"] = str(fold)
         os.environ["BMF_FOLD_ROWS"] = str(int(rng.integers(1, k - q + 2)))
         try:
