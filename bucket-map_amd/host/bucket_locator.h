@@ -284,8 +284,9 @@ public:
     // _locate (:613-705)
     std::vector<std::vector<locate_t>> locate_reads(const std::string &sequence_file) {
         // _initialize_kmer_index (:151-160): the bucket sequences, here as views into one byte string that goes to
-        // the scanner's (and the verifier's) devices.  Nothing in it depends on the mapper, so it runs on its own
-        // thread while _m->map() parses the reads and drives the filter.
+        // the scanner's (and the verifier's) devices, and then _prepare_read_query (:292-347), the locator's own pass
+        // over the FASTQ file.  Neither depends on the mapper's results, so both run on their own thread while
+        // _m->map() parses the reads and drives the filter.
         buckets_ = cut_buckets(*genome_, static_cast<int>(bucket_length), static_cast<int>(read_length));
         auto upload_genome = [&]() {
             std::vector<uint64_t> rec_off(genome_->seqs.size() + 1, 0);
@@ -318,6 +319,7 @@ public:
         std::thread uploader([&]() {
             try {
                 upload_genome();
+                prepare_read_query(sequence_file);
             } catch (...) {
                 upload_error = std::current_exception();
             }
@@ -333,7 +335,6 @@ public:
         auto t0 = std::chrono::steady_clock::now();
         uploader.join();
         if (upload_error) std::rethrow_exception(upload_error);
-        prepare_read_query(sequence_file);
 
         // Candidates in the order of the reference's bucket loop (:651-693): buckets ascending; inside a
         // bucket the reads as-is in list order, then the reverse complements in REVERSE list order.
