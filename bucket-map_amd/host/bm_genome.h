@@ -173,10 +173,16 @@ struct FastqRecord {
     std::string_view qual;    // phred+33
 };
 
-// Calls op for every record of a 4-line FASTQ file.  Block reader: the file is read in 32 MiB pieces
-// and lines are found with memchr (the mapper, the locator's sampling pass and the SAM pass each walk
-// the whole FASTQ, as the reference does, so this loop is the host-side bottleneck of the tool).
-inline void for_each_fastq(const std::string &path, const std::function<void(const FastqRecord &)> &op) {
+// Calls op for every record of a 4-line FASTQ file, in file order.  The mapper, the locator's sampling pass and
+// the SAM pass each walk the whole FASTQ, as the reference does, so this is the host-side bottleneck of the tool.
+//
+// for_each_fastq_stream: the portable form -- the file is read in blocks and lines are found with memchr.
+// for_each_fastq:        the file is mapped and cut into chunks of io_block_bytes(); a few threads find and check the
+//                        records that START in each chunk (a record start is a line that begins with '@' whose line
+//                        after next begins with '+': a quality line may begin with '@', but then the line after
+//                        next is a sequence, and sequences do not begin with '+'), a group of chunks ahead of the one
+//                        whose records are being handed to op; op itself runs on the calling thread only.
+inline void for_each_fastq_stream(const std::string &path, const std::function<void(const FastqRecord &)> &op) {
     // closed on every way out, the callback's exceptions included
     std::unique_ptr<FILE, int (*)(FILE *)> file(std::fopen(path.c_str(), "rb"), &std::fclose);
     if (!file) throw std::runtime_error("cannot open FASTQ file " + path);
@@ -232,6 +238,168 @@ inline void for_each_fastq(const std::string &path, const std::function<void(con
         have -= pos;
         if (have == buf.size()) buf.resize(buf.size() * 2);
     }
+}
+
+namespace fastq_detail {
+
+// [p, line end) of the line that starts at p; next = start of the following line (or end)
+inline const char *line_end(const char *p, const char *end, const char *&next) {
+    const char *nl = p < end ? static_cast<const char *>(std::memchr(p, '\n', static_cast<size_t>(end - p))) : nullptr;
+    next = nl ? nl + 1 : end;
+    const char *e = nl ? nl : end;
+    if (e > p && e[-1] == '\r') e--;
+    return e;
+}
+
+// First record start at or after `from` (a line start): nullptr if there is none before `limit`.
+inline const char *find_record(const char *from, const char *limit, const char *end) {
+    for (const char *p = from; p < limit;) {
+        const char *n1, *n2;
+        line_end(p, end, n1);
+        if (*p == '@' && n1 < end) {
+            line_end(n1, end, n2);
+            if (n2 < end && *n2 == '+') return p;
+        }
+        p = n1;
+    }
+    return nullptr;
+}
+
+struct Chunk {
+    std::vector<FastqRecord> recs;
+    const char *first = nullptr, *stop = nullptr;   // where its first record starts / where parsing stopped
+    std::string error;
+};
+
+// Records that start in [begin, limit).  `begin` is a line start (or the start of the file).
+inline void parse_chunk(const char *begin, const char *limit, const char *end, bool is_first, Chunk &out) {
+    const char *p = begin;
+    if (is_first) {
+        while (p < end && (*p == '\n' || *p == '\r')) p++;          // leading blank lines
+    } else {
+        p = find_record(begin, limit, end);
+        if (!p) return;
+    }
+    out.first = p;
+    while (p < limit && p < end) {
+        const char *n0, *n1, *n2, *n3;
+        const char *e0 = line_end(p, end, n0);
+        if (e0 == p) {                                               // blank line between records
+            p = n0;
+            continue;
+        }
+        if (*p != '@') {
+            out.error = "FASTQ record does not start with '@'";
+            return;
+        }
+        if (n0 >= end) {
+            out.error = "truncated FASTQ record";
+            return;
+        }
+        const char *e1 = line_end(n0, end, n1);
+        if (n1 >= end) {
+            out.error = "truncated FASTQ record";
+            return;
+        }
+        line_end(n1, end, n2);
+        if (n2 >= end) {                                             // no quality line
+            out.error = "truncated FASTQ record";
+            return;
+        }
+        const char *e3 = line_end(n2, end, n3);
+        if (static_cast<size_t>(e1 - n0) != static_cast<size_t>(e3 - n2)) {
+            out.error = "sequence and quality lengths differ";
+            return;
+        }
+        out.recs.push_back(FastqRecord{std::string_view(p + 1, static_cast<size_t>(e0 - p - 1)),
+                                       std::string_view(n0, static_cast<size_t>(e1 - n0)),
+                                       std::string_view(n2, static_cast<size_t>(e3 - n2))});
+        p = n3;
+    }
+    out.stop = p;
+}
+
+}  // namespace fastq_detail
+
+inline void for_each_fastq(const std::string &path, const std::function<void(const FastqRecord &)> &op) {
+    const int fd = ::open(path.c_str(), O_RDONLY);
+    if (fd < 0) throw std::runtime_error("cannot open FASTQ file " + path);
+    struct stat st {};
+    const bool ok = ::fstat(fd, &st) == 0 && S_ISREG(st.st_mode);
+    const size_t size = ok ? static_cast<size_t>(st.st_size) : 0;
+    void *map = ok && size ? ::mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0) : MAP_FAILED;
+    ::close(fd);
+    if (map == MAP_FAILED) {
+        if (ok && size == 0) return;
+        for_each_fastq_stream(path, op);                             // a pipe, or no address space: the block reader
+        return;
+    }
+    struct Unmap {
+        void *p;
+        size_t n;
+        ~Unmap() { ::munmap(p, n); }
+    } unmap{map, size};
+    ::madvise(map, size, MADV_SEQUENTIAL);
+    const char *data = static_cast<const char *>(map), *end = data + size;
+    const size_t chunk = io_block_bytes(), n_chunks = (size + chunk - 1) / chunk;
+    const unsigned threads = std::min<unsigned>(8, std::max(1u, std::thread::hardware_concurrency()));
+    const size_t group = std::max<size_t>(1, std::min<size_t>(threads, n_chunks));
+    using fastq_detail::Chunk;
+    // chunk c covers [c * chunk, (c + 1) * chunk), moved forward to the next line start
+    auto parse_group = [&](size_t g0, std::vector<Chunk> &out) {
+        const size_t n = std::min(group, n_chunks - g0);
+        out.assign(n, Chunk());
+        std::atomic<size_t> next{0};
+        auto work = [&]() {
+            for (size_t i = next.fetch_add(1); i < n; i = next.fetch_add(1)) {
+                const size_t c = g0 + i;
+                const char *b = data + c * chunk, *limit = std::min(end, data + (c + 1) * chunk);
+                if (c > 0 && b[-1] != '\n') {                        // inside a line: this chunk starts at the next one
+                    const char *nl = static_cast<const char *>(std::memchr(b, '\n', static_cast<size_t>(end - b)));
+                    b = nl ? nl + 1 : end;
+                }
+                if (b < limit || c == 0) fastq_detail::parse_chunk(b, limit, end, c == 0, out[i]);
+            }
+        };
+        std::vector<std::thread> pool;
+        for (size_t t = 1; t < std::min<size_t>(threads, n); t++) pool.emplace_back(work);
+        work();
+        for (auto &t : pool) t.join();
+    };
+    std::vector<Chunk> cur, ahead;
+    std::thread prefetch;
+    struct Joiner {
+        std::thread &t;
+        ~Joiner() {
+            if (t.joinable()) t.join();
+        }
+    } joiner{prefetch};
+    parse_group(0, cur);
+    const char *expect = nullptr;                                    // where the next record must start
+    for (size_t g0 = 0; g0 < n_chunks; g0 += group) {
+        const bool more = g0 + group < n_chunks;
+        if (more) prefetch = std::thread([&, g0]() { parse_group(g0 + group, ahead); });
+        for (Chunk &c : cur) {
+            if (c.first) {
+                // every byte between two records was looked at: the chunks' records join up exactly (blank lines aside)
+                if (expect) {
+                    const char *q = expect;
+                    while (q < c.first && (*q == '\n' || *q == '\r')) q++;
+                    if (q != c.first) throw std::runtime_error("malformed FASTQ record in " + path);
+                }
+                for (const FastqRecord &r : c.recs) op(r);
+                expect = c.stop;
+            }
+            if (!c.error.empty()) throw std::runtime_error(c.error + " in " + path);
+        }
+        if (more) {
+            prefetch.join();
+            cur.swap(ahead);
+        }
+    }
+    // whatever follows the last record must be blank
+    for (const char *q = expect ? expect : data; q < end; q++)
+        if (*q != '\n' && *q != '\r') throw std::runtime_error("truncated FASTQ record in " + path);
 }
 
 // One kept bucket of iterate_through_buckets (utils.h:72-97).

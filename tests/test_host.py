@@ -296,3 +296,48 @@ def test_fasta_reader_edge_cases(tmp_path):
         host.Genome.read_fasta(str(bad))
     (tmp_path / "empty.fa").write_text("")
     assert host.Genome.read_fasta(str(tmp_path / "empty.fa")).n_records == 0
+
+
+def test_fastq_reader_finds_record_starts_anywhere(tmp_path, monkeypatch):
+    """The mapped FASTQ reader resynchronises at every chunk boundary on "a line that begins with '@' whose line after
+    next begins with '+'".  Qualities that begin with '@' or '+', headers that look like anything, reads of every
+    length (empty ones included) and chunk sizes from 16 bytes up must all give the records a plain line-by-line
+    parse gives; damage anywhere must raise."""
+    rng = np.random.default_rng(17)
+    recs = []
+    for i in range(300):
+        n = int(rng.integers(0, 90))
+        seq = "".join("ACGTN"[j] for j in rng.integers(0, 5, n))
+        qual = "".join(chr(int(x)) for x in rng.integers(33, 127, n))
+        if n and i % 3 == 0:
+            qual = "@" + qual[1:]                      # a quality line that looks like a header
+        if n and i % 5 == 0:
+            qual = "+" + qual[1:]                      # ... or like the separator
+        recs.append((f"r{i} @+ {'@' * (i % 4)}", seq, qual))
+    text = "".join(f"@{i}\n{s}\n+\n{q}\n" for i, s, q in recs)
+    path = tmp_path / "adv.fastq"
+    path.write_text(text)
+
+    def stats(p):
+        return host.fastq_stats(str(p))
+
+    def fnv(parts):
+        h = 1469598103934665603
+        for v in parts:
+            for c in v.encode():
+                h = ((h ^ c) * 1099511628211) & (2 ** 64 - 1)
+            h = ((h ^ 0xFF) * 1099511628211) & (2 ** 64 - 1)
+        return h
+    want = (len(recs), sum(len(s) for _, s, _ in recs), fnv([x for r in recs for x in r]))
+    for block in (16, 17, 23, 64, 100, 333, 1024, 1 << 20):
+        monkeypatch.setenv("BM_IO_BLOCK", str(block))
+        assert stats(path) == want, block
+    # damage: a missing quality line in the middle, junk between two records, unequal lengths
+    lines = text.split("\n")
+    for what, bad in (("missing line", lines[:403] + lines[404:]), ("junk", lines[:400] + ["junk"] + lines[400:]),
+                      ("lengths", lines[:401] + [lines[401] + "A"] + lines[402:])):
+        (tmp_path / "bad.fastq").write_text("\n".join(bad))
+        for block in (16, 64, 1 << 20):
+            monkeypatch.setenv("BM_IO_BLOCK", str(block))
+            with pytest.raises(RuntimeError):
+                stats(tmp_path / "bad.fastq")
