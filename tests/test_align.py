@@ -141,7 +141,7 @@ def _random_batch(rng, genome, n, max_m, err):
             if len(q) == 0:
                 q = np.frombuffer(b"A", np.uint8)
         if kind == 1:
-            width = int(rng.integers(0, 5))             # text much shorter than the query (can be empty)
+            width = min(int(rng.integers(0, 5)), len(genome) - start)   # text much shorter than the query (can be empty)
         if kind == 2 and a > 20:
             q = q[:0]                                   # empty query
         reads.append(q)
