@@ -5,7 +5,7 @@ brute force for the score (which is unique), and against the consistency of its 
 rules it ASSUMES of SeqAn3 (last minimal end column; diagonal, then up, then left) are pinned by cases
 built so that the other choice gives a different answer.
 GPU part: the Myers bit-vector kernel (through the C ABI, include/bmv.h) against the oracle, bit-exact:
-score, begin position and CIGAR, for every kernel shape (4/8/16/64 lanes per alignment, 1/2/4 words per
+score, begin position and CIGAR, for every kernel shape (4/8/16/64 lanes per alignment, 1/2/3/4 words per
 lane), ragged and degenerate inputs, both strands, several chunks; and the `bucketmap_align` tool against
 the same tool with the oracle plugged in."""
 import os
