@@ -25,6 +25,9 @@ constexpr int kScanThreads = 1024;   // scan kernel: its loops are chains of dep
 constexpr uint32_t kTableSlots = 4096;        // LDS open-addressing table (targets of one chunk)
 constexpr uint32_t kLdsOcc = 2048;            // occurrences staged in LDS per workgroup
 constexpr uint32_t kEmpty = 0xFFFFFFFFu;
+constexpr uint32_t kFilterWords = 2048;       // 64 Kbit presence filter in front of the table: a bucket has 65 825 k-mers
+                                              // and a chunk asks for at most 2 040 of all 4^k, so 97 % of the scan's
+                                              // probes end at ONE LDS read instead of walking a half-full table
 
 struct Chunk {
     uint32_t bucket;
@@ -39,8 +42,28 @@ struct LocParams {
 };
 
 __host__ __device__ inline size_t scan_lds_bytes(uint32_t max_words) {
-    return (size_t)kLdsOcc * 8 + 16 + 256 + (size_t)kTableSlots * 8 + ((size_t)max_words + 2) * 4;
+    return (size_t)kLdsOcc * 8 + 16 + (size_t)kFilterWords * 4 + (size_t)kTableSlots * 8 + ((size_t)max_words + 4) * 4;
 }
+
+// SeqAn3 dna4 assign_char without a table (the same folding as bmf_kernels.hip.h): four ASCII bytes -> four ranks
+// packed into one byte, the first (lowest-address) base in the top two bits.
+__device__ __forceinline__ uint32_t dna4_code(uint32_t c) {
+    constexpr uint64_t kRank = (1ull << (2 * 3)) | (1ull << (2 * 25)) | (1ull << (2 * 19)) | (1ull << (2 * 2)) |
+                               (2ull << (2 * 7)) | (2ull << (2 * 11)) | (3ull << (2 * 20)) | (3ull << (2 * 21));
+    const uint32_t letter = (c & 0xDFu) - 0x41u;
+    return letter < 26u ? (uint32_t)(kRank >> (2u * (c & 31u))) & 3u : 0u;
+}
+__device__ __forceinline__ uint32_t dna4_pack4(uint32_t w) {
+    const uint32_t t = (w >> 1) & 0x03030303u;
+    uint32_t code = t ^ ((t >> 1) & 0x01010101u);                       // A C G T (a c g t) -> 0 1 2 3
+    if (__builtin_amdgcn_perm(0u, 0x54474341u, code) != (w & 0xDFDFDFDFu))    // some byte is none of those
+        code = dna4_code(w & 0xFFu) | (dna4_code((w >> 8) & 0xFFu) << 8) | (dna4_code((w >> 16) & 0xFFu) << 16) |
+               (dna4_code(w >> 24) << 24);
+    const uint32_t r = __builtin_amdgcn_perm(0u, code, 0x00010203u);
+    const uint32_t x = r | (r >> 6);
+    return (x | (x >> 12)) & 0xFFu;
+}
+__device__ __forceinline__ uint32_t filter_bit(uint32_t h) { return (h * 2246822519u) >> 16; }   // 16 bits
 
 // utils.h:291-302
 __device__ __forceinline__ uint32_t hash_reverse_complement(uint32_t h, uint32_t k) {
@@ -55,7 +78,7 @@ __device__ __forceinline__ uint32_t hash_reverse_complement(uint32_t h, uint32_t
 __device__ __forceinline__ uint32_t slot_of(uint32_t h) { return (h * 2654435761u) >> 20; }   // 12 bits
 
 // LDS layout (all dynamic, 16-byte aligned base): locc[kLdsOcc] u64 | gbase u64 | lds_cnt u32 (+pad) |
-//                       lut[256] u8 | tkey[kTableSlots] u32 | ttgt[kTableSlots] u32 | packed[max_words + 2] u32
+//                       filter[kFilterWords] u32 | tkey[kTableSlots] u32 | ttgt[kTableSlots] u32 | packed[max_words + 4] u32
 __global__ __launch_bounds__(kScanThreads) void bml_scan_kernel(
     LocParams P, const uint8_t *__restrict__ genome, const uint64_t *__restrict__ bucket_start,
     const uint32_t *__restrict__ bucket_len, const uint8_t *__restrict__ dna4_lut, const Chunk *__restrict__ chunks,
@@ -66,32 +89,37 @@ __global__ __launch_bounds__(kScanThreads) void bml_scan_kernel(
     uint64_t *locc = reinterpret_cast<uint64_t *>(smem);
     unsigned long long &gbase = *reinterpret_cast<unsigned long long *>(locc + kLdsOcc);
     uint32_t &lds_cnt = *reinterpret_cast<uint32_t *>(locc + kLdsOcc + 1);
-    uint8_t *lut = reinterpret_cast<uint8_t *>(locc + kLdsOcc + 2);
-    uint32_t *tkey = reinterpret_cast<uint32_t *>(lut + 256);
+    uint32_t *filter = reinterpret_cast<uint32_t *>(locc + kLdsOcc + 2);
+    uint32_t *tkey = filter + kFilterWords;
     uint32_t *ttgt = tkey + kTableSlots;
     uint32_t *packed = ttgt + kTableSlots;
+    (void)dna4_lut;
 
     const Chunk ch = chunks[blockIdx.x];
     const uint32_t tid = threadIdx.x;
     const uint32_t nb = bucket_len[ch.bucket];
-    const uint8_t *base = genome + bucket_start[ch.bucket];
+    const uint64_t start = bucket_start[ch.bucket];
 
-    if (tid < 256) lut[tid] = dna4_lut[tid];
     if (tid == 0) lds_cnt = 0;
     for (uint32_t s = tid; s < kTableSlots; s += kScanThreads) ttgt[s] = kEmpty;
-    __syncthreads();
+    for (uint32_t s = tid; s < kFilterWords; s += kScanThreads) filter[s] = 0;
 
-    // 2-bit packing, first base in the most significant bits of each word
-    const uint32_t n_words = (nb + 15u) / 16u;
-    for (uint32_t w = tid; w <= n_words; w += kScanThreads) {
+    // 2-bit packing, first base in the most significant bits of each word: one aligned 16-byte load per stream
+    // word (the bucket may start at any byte: the stream starts at the aligned chunk that holds its first base,
+    // base j of the bucket is stream position shift + j; the chunks before the genome buffer's first byte do not
+    // exist, and hipMalloc'd buffers are 256-byte aligned, so the aligned start is inside the buffer)
+    const uint32_t shift = (uint32_t)(start & 15u);
+    const uint8_t *abase = genome + (start - shift);
+    const uint32_t n_words = (shift + nb + 15u) / 16u;
+    for (uint32_t w = tid; w < n_words + 2u; w += kScanThreads) {
         uint32_t word = 0;
-        for (uint32_t t = 0; t < 16; t++) {
-            const uint32_t pos = w * 16u + t;
-            const uint32_t code = pos < nb ? lut[base[pos]] : 0u;
-            word |= code << (30u - 2u * t);
+        if (w < n_words) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(abase + 16u * w);
+            word = (dna4_pack4(v.x) << 24) | (dna4_pack4(v.y) << 16) | (dna4_pack4(v.z) << 8) | dna4_pack4(v.w);
         }
         packed[w] = word;
     }
+    __syncthreads();
     // the k-mers this chunk's candidates ask for: target t = (candidate, i-th processed sample)
     const uint32_t n_t = ch.pair_count * P.p;
     for (uint32_t t = tid; t < n_t; t += kScanThreads) {
@@ -104,6 +132,8 @@ __global__ __launch_bounds__(kScanThreads) void bml_scan_kernel(
         uint32_t slot = slot_of(h);
         while (atomicCAS(&ttgt[slot], kEmpty, t) != kEmpty) slot = (slot + 1u) & (kTableSlots - 1u);
         tkey[slot] = h;
+        const uint32_t fb = filter_bit(h);
+        atomicOr(&filter[fb >> 5], 1u << (fb & 31u));
     }
     __syncthreads();
 
@@ -111,16 +141,19 @@ __global__ __launch_bounds__(kScanThreads) void bml_scan_kernel(
     const uint32_t nk = nb >= P.k ? nb - P.k + 1u : 0u;
     const uint32_t kmask = P.k >= 16 ? 0xFFFFFFFFu : ((1u << (2u * P.k)) - 1u);
     for (uint32_t j = tid; j < nk; j += kScanThreads) {
-        const uint64_t two = ((uint64_t)packed[j >> 4] << 32) | packed[(j >> 4) + 1];
-        const uint32_t h = (uint32_t)(two >> (64u - 2u * (j & 15u) - 2u * P.k)) & kmask;
+        const uint32_t at = shift + j;
+        const uint64_t two = ((uint64_t)packed[at >> 4] << 32) | packed[(at >> 4) + 1];
+        const uint32_t h = (uint32_t)(two >> (64u - 2u * (at & 15u) - 2u * P.k)) & kmask;
+        const uint32_t fb = filter_bit(h);
+        if (!((filter[fb >> 5] >> (fb & 31u)) & 1u)) continue;          // nobody asked for this k-mer
         uint32_t slot = slot_of(h), t;
         while ((t = ttgt[slot]) != kEmpty) {
             if (tkey[slot] == h) {
                 const uint32_t target = (ch.pair_begin + t / P.p) * P.p + t % P.p;
                 const uint64_t key = ((uint64_t)target << 32) | (uint32_t)(0x7FFFFFFFu - j);   // offset descending
-                const uint32_t at = atomicAdd(&lds_cnt, 1u);
-                if (at < kLdsOcc) {
-                    locc[at] = key;
+                const uint32_t at_l = atomicAdd(&lds_cnt, 1u);
+                if (at_l < kLdsOcc) {
+                    locc[at_l] = key;
                 } else {   // rare (repeats): past the LDS staging area, go to HBM directly
                     const unsigned long long g = atomicAdd(occ_count, 1ull);
                     if (g < occ_cap) occ_keys[g] = key;
