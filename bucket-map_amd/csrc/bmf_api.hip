@@ -842,7 +842,7 @@ int bmf_build_index(bmf_ctx *c, const uint8_t *genome, uint64_t n_bases, const u
     ok(dev_alloc(&c->d_k2i, (size_t)n_kmers));
     ok(dev_alloc(&c->d_zeros, (size_t)n_rows));
     ok(dev_alloc(&c->d_qgram_ok, (size_t)n_words));
-    ok(dev_alloc(&d_genome, (size_t)n_bases));
+    ok(dev_alloc(&d_genome, (size_t)n_bases + 64));   // + slack: the presence kernel loads whole aligned 16-byte chunks
     ok(dev_alloc(&d_bstart, n_buckets));
     ok(dev_alloc(&d_blen, n_buckets));
     ok(dev_alloc(&d_presence, (size_t)n_buckets * n_words));
@@ -854,13 +854,19 @@ int bmf_build_index(bmf_ctx *c, const uint8_t *genome, uint64_t n_bases, const u
         ok(hipMemcpy(d_blen, bucket_len, (size_t)n_buckets * sizeof(uint32_t), hipMemcpyHostToDevice));
         ok(hipMemcpy(c->d_k2i, kmer_to_index, (size_t)n_kmers * sizeof(int32_t), hipMemcpyHostToDevice));
     }
-    const size_t lds = (size_t)n_words * 4 + 256;
+    // LDS of the presence kernel: the bitmap and (a segment of) the bucket as a 2-bit stream (+ alignment shift, + the
+    // word a shift reads ahead); buckets too long for what the bitmap leaves go through in segments
+    const size_t lds_room = 159 * 1024 - (size_t)n_words * 4;
+    const uint32_t seg_cap = (uint32_t)std::min<size_t>(lds_room / 4 > 4 ? (lds_room / 4 - 4) * 16 : 0, 1u << 20);
+    const uint32_t seg_bases = std::max(std::min(max_len, seg_cap), q);
+    const uint32_t stream_words = (seg_bases + 15u + 15u) / 16u + 2u;
+    const size_t lds = (size_t)n_words * 4 + (size_t)stream_words * 4;
     if (e == hipSuccess && lds > 48 * 1024)
         ok(bmhip::raise_dynamic_lds(reinterpret_cast<const void *>(bmi::bmi_presence_kernel), lds));
     if (e == hipSuccess && n_buckets) {
         for (uint32_t b0 = 0; b0 < n_buckets; b0 += kPresenceSlice)
             hipLaunchKernelGGL(bmi::bmi_presence_kernel, dim3(std::min(kPresenceSlice, n_buckets - b0)), dim3(bmi::kThreads), lds,
-                               c->stream, d_genome, d_bstart + b0, d_blen + b0, d_lut, q, d_presence + (size_t)b0 * n_words);
+                               c->stream, d_genome, d_bstart + b0, d_blen + b0, d_lut, q, stream_words, seg_bases, d_presence + (size_t)b0 * n_words);
         hipLaunchKernelGGL(bmi::bmi_transpose_kernel, dim3(tr_blocks_x, tr_blocks_y), dim3(bmi::kThreads), 0, c->stream, reinterpret_cast<const uint64_t *>(d_presence), n_buckets, q,
                            c->d_k2i, c->d_rows, pitch);
         ok(hipGetLastError());
@@ -881,7 +887,6 @@ int bmf_build_index(bmf_ctx *c, const uint8_t *genome, uint64_t n_bases, const u
     (void)hipFree(d_bstart);
     (void)hipFree(d_blen);
     (void)hipFree(d_presence);
-    (void)max_len;
     if (e != hipSuccess) {
         free_index(c);
         return fail(BMF_ERR_HIP, "bmf_build_index: %s", hipGetErrorString(e));

@@ -20,6 +20,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "bm_dna4.hip.h"
+
 namespace bmf {
 
 constexpr int kWave = 64;
@@ -213,27 +215,8 @@ struct SampleGeom {
     uint32_t wave_stride;    // LDS bytes per wave
 };
 
-// SeqAn3 dna4 assign_char without a table: letters fold by their low five bits (either case),
-// C Y S B -> 1, G K -> 2, T U -> 3, every other byte -> 0 (A).
-__device__ __forceinline__ uint32_t dna4_code(uint32_t c) {
-    constexpr uint64_t kRank = (1ull << (2 * 3)) | (1ull << (2 * 25)) | (1ull << (2 * 19)) | (1ull << (2 * 2)) |
-                               (2ull << (2 * 7)) | (2ull << (2 * 11)) | (3ull << (2 * 20)) | (3ull << (2 * 21));
-    const uint32_t letter = (c & 0xDFu) - 0x41u;
-    return letter < 26u ? (uint32_t)(kRank >> (2u * (c & 31u))) & 3u : 0u;
-}
-
-// Four ASCII bytes -> their four dna4 ranks as one byte, the first (lowest-address) base in the top two bits.
-__device__ __forceinline__ uint32_t dna4_pack4(uint32_t w) {
-    const uint32_t t = (w >> 1) & 0x03030303u;
-    uint32_t code = t ^ ((t >> 1) & 0x01010101u);                       // A C G T (a c g t) -> 0 1 2 3
-    if (__builtin_amdgcn_perm(0u, 0x54474341u, code) != (w & 0xDFDFDFDFu)) {   // some byte is none of those
-        code = dna4_code(w & 0xFFu) | (dna4_code((w >> 8) & 0xFFu) << 8) | (dna4_code((w >> 16) & 0xFFu) << 16) |
-               (dna4_code(w >> 24) << 24);
-    }
-    const uint32_t r = __builtin_amdgcn_perm(0u, code, 0x00010203u);    // byte-reversed: first base in byte 3
-    const uint32_t x = r | (r >> 6);
-    return (x | (x >> 12)) & 0xFFu;
-}
+using bmdna::dna4_code;
+using bmdna::dna4_pack4;
 
 // utils.h:291-302 without the loop: reverse the bits, swap the two bits of every base back, complement
 __device__ __forceinline__ uint32_t revcomp_fast(uint32_t h, uint32_t k) {

@@ -13,41 +13,50 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "bm_dna4.hip.h"
+
 namespace bmi {
 
 constexpr int kThreads = 1024;
 
-// LDS (dynamic): bitmap[4^q / 32] u32 | lut[256] u8
+// LDS (dynamic): bitmap[4^q / 32] u32 | packed[stream_words] u32 (a segment of the bucket as a 2-bit stream, 16 bases
+// per word, the first base in the top bits: aligned 16-byte loads and register folding instead of a byte load and a table
+// look-up per base; a segment may start at any byte, its base j sits at stream position shift + j).  A bucket that does
+// not fit beside the bitmap goes through in segments of seg_bases bases that overlap by q - 1.
 __global__ __launch_bounds__(kThreads) void bmi_presence_kernel(const uint8_t *__restrict__ genome,
                                                                const uint64_t *__restrict__ bucket_start,
                                                                const uint32_t *__restrict__ bucket_len,
                                                                const uint8_t *__restrict__ dna4_lut, uint32_t q,
+                                                               uint32_t stream_words, uint32_t seg_bases,
                                                                uint32_t *__restrict__ presence /* n_buckets x 4^q/32 */) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t n_words = (1u << (2 * q)) >> 5;
     uint32_t *bitmap = reinterpret_cast<uint32_t *>(smem);
-    uint8_t *lut = smem + (size_t)n_words * 4;
+    uint32_t *packed = bitmap + n_words;
+    (void)dna4_lut;
     const uint32_t tid = threadIdx.x;
     const uint32_t b = blockIdx.x;
-    if (tid < 256) lut[tid] = dna4_lut[tid];
-    for (uint32_t w = tid; w < n_words; w += kThreads) bitmap[w] = 0;
-    __syncthreads();
     const uint32_t len = bucket_len[b];
-    const uint8_t *s = genome + bucket_start[b];
-    if (len >= q) {
-        // every thread owns a contiguous run of q-gram start positions and rolls the hash along it
-        const uint32_t nq = len - q + 1;
-        const uint32_t per = (nq + kThreads - 1) / kThreads;
-        const uint32_t j0 = tid * per, j1 = (j0 + per < nq) ? j0 + per : nq;
-        if (j0 < j1) {
-            const uint32_t mask = (uint32_t)((1ull << (2 * q)) - 1ull);
-            uint32_t h = 0;
-            for (uint32_t t = 0; t + 1 < q; t++) h = (h << 2) | lut[s[j0 + t]];
-            for (uint32_t j = j0; j < j1; j++) {
-                h = ((h << 2) | lut[s[j + q - 1]]) & mask;
-                atomicOr(&bitmap[h >> 5], 1u << (h & 31u));
-            }
+    const uint32_t mask = (uint32_t)((1ull << (2 * q)) - 1ull);
+    for (uint32_t w = tid; w < n_words; w += kThreads) bitmap[w] = 0;
+    for (uint32_t s0 = 0; s0 + q <= len; s0 += seg_bases - (q - 1u)) {
+        const uint32_t seg = len - s0 < seg_bases ? len - s0 : seg_bases;       // bases of this segment
+        const uint64_t start = bucket_start[b] + s0;
+        const uint32_t shift = (uint32_t)(start & 15u);
+        const uint8_t *abase = genome + (start - shift);
+        const uint32_t nw = (shift + seg + 15u) / 16u;
+        __syncthreads();                                                         // the previous segment has been read
+        for (uint32_t w = tid; w < stream_words; w += kThreads)
+            packed[w] = w < nw ? bmdna::dna4_pack16(*reinterpret_cast<const uint4 *>(abase + 16u * w)) : 0u;
+        __syncthreads();
+        const uint32_t nq = seg - q + 1;
+        for (uint32_t j = tid; j < nq; j += kThreads) {
+            const uint32_t at = shift + j;
+            const uint64_t two = ((uint64_t)packed[at >> 4] << 32) | packed[(at >> 4) + 1];
+            const uint32_t h = (uint32_t)(two >> (64u - 2u * (at & 15u) - 2u * q)) & mask;
+            atomicOr(&bitmap[h >> 5], 1u << (h & 31u));
         }
+        if (seg < seg_bases) break;                                              // that was the bucket's last base
     }
     __syncthreads();
     uint32_t *out = presence + (size_t)b * n_words;

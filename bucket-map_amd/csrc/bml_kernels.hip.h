@@ -16,6 +16,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "bm_dna4.hip.h"
+
 namespace bml {
 
 constexpr int kThreads = 256;        // replay kernel
@@ -45,24 +47,6 @@ __host__ __device__ inline size_t scan_lds_bytes(uint32_t max_words) {
     return (size_t)kLdsOcc * 8 + 16 + (size_t)kFilterWords * 4 + (size_t)kTableSlots * 8 + ((size_t)max_words + 4) * 4;
 }
 
-// SeqAn3 dna4 assign_char without a table (the same folding as bmf_kernels.hip.h): four ASCII bytes -> four ranks
-// packed into one byte, the first (lowest-address) base in the top two bits.
-__device__ __forceinline__ uint32_t dna4_code(uint32_t c) {
-    constexpr uint64_t kRank = (1ull << (2 * 3)) | (1ull << (2 * 25)) | (1ull << (2 * 19)) | (1ull << (2 * 2)) |
-                               (2ull << (2 * 7)) | (2ull << (2 * 11)) | (3ull << (2 * 20)) | (3ull << (2 * 21));
-    const uint32_t letter = (c & 0xDFu) - 0x41u;
-    return letter < 26u ? (uint32_t)(kRank >> (2u * (c & 31u))) & 3u : 0u;
-}
-__device__ __forceinline__ uint32_t dna4_pack4(uint32_t w) {
-    const uint32_t t = (w >> 1) & 0x03030303u;
-    uint32_t code = t ^ ((t >> 1) & 0x01010101u);                       // A C G T (a c g t) -> 0 1 2 3
-    if (__builtin_amdgcn_perm(0u, 0x54474341u, code) != (w & 0xDFDFDFDFu))    // some byte is none of those
-        code = dna4_code(w & 0xFFu) | (dna4_code((w >> 8) & 0xFFu) << 8) | (dna4_code((w >> 16) & 0xFFu) << 16) |
-               (dna4_code(w >> 24) << 24);
-    const uint32_t r = __builtin_amdgcn_perm(0u, code, 0x00010203u);
-    const uint32_t x = r | (r >> 6);
-    return (x | (x >> 12)) & 0xFFu;
-}
 __device__ __forceinline__ uint32_t filter_bit(uint32_t h) { return (h * 2246822519u) >> 16; }   // 16 bits
 
 // utils.h:291-302
@@ -115,7 +99,7 @@ __global__ __launch_bounds__(kScanThreads) void bml_scan_kernel(
         uint32_t word = 0;
         if (w < n_words) {
             const uint4 v = *reinterpret_cast<const uint4 *>(abase + 16u * w);
-            word = (dna4_pack4(v.x) << 24) | (dna4_pack4(v.y) << 16) | (dna4_pack4(v.z) << 8) | dna4_pack4(v.w);
+            word = bmdna::dna4_pack16(v);
         }
         packed[w] = word;
     }
