@@ -236,7 +236,9 @@ int bmv_align(bmv_ctx *c, const uint8_t *reads, uint64_t n_read_bytes, const uin
     const uint32_t ops_stride = max_m + max_n + 1u;
     const uint32_t lds_stride = (max_n + 15u) & ~15u;
     const uint32_t qry_stride = std::max(64u, std::min((max_m + 63u) & ~63u, sh.group * (uint32_t)sh.cw * 64u));   // one strip
-    const size_t lds = 256 + (size_t)gpw * (lds_stride + qry_stride);
+    // (the query lends its LDS to the text once its match masks are built, unless the kernel works in strips)
+    const bool strips = words > 256u;
+    const size_t lds = 256 + (size_t)gpw * (strips ? lds_stride + qry_stride : std::max(lds_stride, qry_stride));
     if (lds > 160 * 1024) return fail(BMV_ERR_UNSUPPORTED, "text windows of %u bases need %zu B of LDS", max_n, lds);
     if (lds > 48 * 1024)
         HIP_TRY(bmhip::raise_dynamic_lds(reinterpret_cast<const void *>(sh.fn), lds));

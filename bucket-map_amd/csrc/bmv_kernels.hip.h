@@ -90,6 +90,16 @@ __device__ __forceinline__ int myers_step(uint64_t eq0, int hin, uint64_t &pv, u
     return hout;
 }
 
+// The match mask of text base ch (a rank, 0..3) out of the four of a word.  Bit arithmetic on values already in
+// registers: written as a chain of ?: over array elements the compiler merged the loads into one load through a selected
+// POINTER, which kept the masks of the CW >= 2 kernels in scratch memory and put a scratch load, waited for, into every
+// column step of every word.
+__device__ __forceinline__ uint64_t pick_mask(uint64_t p0, uint64_t p1, uint64_t p2, uint64_t p3, uint32_t ch) {
+    const bool odd = (ch & 1u) != 0, high = (ch & 2u) != 0;
+    const uint64_t lo = odd ? p1 : p0, hi = odd ? p3 : p2;
+    return high ? hi : lo;
+}
+
 // SLOTS: trace-word pairs a lane keeps during the traceback (16 / SLOTS lanes of a group hold a block's 16
 // columns; needs group >= 16 / SLOTS).  CW: 64-row words per lane.  STRIPS: queries of more than 64 * CW
 // words are allowed (the group is then the whole wave).
@@ -105,33 +115,45 @@ __global__ __launch_bounds__(kWave) void bmv_align_kernel(Job J) {
     const uint32_t W = (m + 63u) >> 6;                         // words of the query
     const uint32_t strip_words = GROUP * CW;                    // words one pass over the text carries
     const uint32_t n_strips = (STRIPS && W) ? (W + strip_words - 1u) / strip_words : 1u;
-    // LDS: the dna4 folding table, then per group the text window and (one strip of) the query, both as ranks
+    // LDS: the dna4 folding table, then per group the text window and (one strip of) the query, both as ranks.  The query
+    // is only read to build the match masks: unless there are strips to come it lends its place to the text afterwards
+    // (half the LDS, twice the waves per CU).
     uint8_t *lut = lds_text;
-    uint8_t *text = lds_text + 256 + (size_t)grp * (J.text_lds_stride + J.query_lds_stride);
-    uint8_t *qry = text + J.text_lds_stride;
+    const uint32_t group_lds = STRIPS ? J.text_lds_stride + J.query_lds_stride
+                                      : (J.text_lds_stride > J.query_lds_stride ? J.text_lds_stride : J.query_lds_stride);
+    uint8_t *text = lds_text + 256 + (size_t)grp * group_lds;
+    uint8_t *qry = STRIPS ? text + J.text_lds_stride : text;
     reinterpret_cast<uint32_t *>(lut)[lane] = reinterpret_cast<const uint32_t *>(J.lut)[lane];
     __syncthreads();
-    if (have) {
-        // text window, reverse-complemented if asked (bucket_locator.h:562-567)
-        const uint8_t *src = J.genome + J.text_start[a];
-        const bool rc = J.text_rc[a] != 0;
+    auto load_text = [&]() {
+        if (have) {
+            // text window, reverse-complemented if asked (bucket_locator.h:562-567)
+            const uint8_t *src = J.genome + J.text_start[a];
+            const bool rc = J.text_rc[a] != 0;
 #pragma unroll 4
-        for (uint32_t j = gl; j < n; j += GROUP) {
-            const uint8_t r = lut[rc ? src[n - 1u - j] : src[j]];
-            text[j] = rc ? (uint8_t)(3u - r) : r;
+            for (uint32_t j = gl; j < n; j += GROUP) {
+                const uint8_t r = lut[rc ? src[n - 1u - j] : src[j]];
+                text[j] = rc ? (uint8_t)(3u - r) : r;
+            }
         }
-    }
+    };
+    if (STRIPS) load_text();
     // checkpoint entry of (block b, this group, word w of the query): (b * GPW + grp) * TW + w
     const uint32_t TW = J.trace_words;
     uint64_t *ckpt = J.trace + (size_t)blockIdx.x * J.trace_stride;
     uint32_t *hbuf = reinterpret_cast<uint32_t *>(ckpt + (size_t)J.trace_blocks * GPW * TW * 2u);
-    auto entry = [&](uint32_t b, uint32_t w) { return ((size_t)b * GPW + grp) * TW + w; };
+    // (32-bit: bmv_create's limits keep a wave's entries below 2^23)
+    auto entry = [&](uint32_t b, uint32_t w) { return (b * GPW + grp) * TW + w; };
 
     uint64_t peq[4][CW];
     int32_t score = (int32_t)m, best = (int32_t)m;              // tracked by the lane that holds row m
     uint32_t best_j = 0;
     const uint32_t last_word = W ? W - 1u : 0u, last_bit = (m - 1u) & 63u;
     const uint32_t last_lane = (last_word % strip_words) / CW;
+    // which of a lane's CW words can be the query's last: with CW > 1 the group is more than half the wave, the wave
+    // carries one alignment and the answer is the same in every lane -- a scalar branch skips the bottom-row bookkeeping
+    // in the other words' steps
+    const uint32_t last_c = CW > 1 ? (uint32_t)__builtin_amdgcn_readfirstlane((int)(last_word % CW)) : 0u;
     // the wave's groups run the same number of strips and steps (shuffles and barriers need the whole wave)
     uint32_t wave_strips = n_strips;
     if (STRIPS) {
@@ -176,6 +198,11 @@ __global__ __launch_bounds__(kWave) void bmv_align_kernel(Job J) {
                 }
             }
         }
+        if (!STRIPS) {                                          // the query's rows are in registers now
+            __syncthreads();
+            load_text();
+            __syncthreads();
+        }
         uint64_t pv[CW], mv[CW];
         uint32_t hacc[CW];                                      // horizontal deltas of the current block, 2 bits each
 #pragma unroll
@@ -209,10 +236,11 @@ __global__ __launch_bounds__(kWave) void bmv_align_kernel(Job J) {
                 for (int c = 0; c < CW; c++) {
                     const uint32_t w = gl * CW + c;
                     if (w < Ws) {
-                        const uint64_t eq0 = ch == 0 ? peq[0][c] : (ch == 1 ? peq[1][c] : (ch == 2 ? peq[2][c] : peq[3][c]));
+                        const uint64_t eq0 = pick_mask(peq[0][c], peq[1][c], peq[2][c], peq[3][c], ch);
                         uint64_t ph, mh, d0;
                         const int hout = myers_step(eq0, hin, pv[c], mv[c], ph, mh, d0);
-                        if (w0 + w == last_word) {
+                        if ((uint32_t)c == last_c && w0 + w == last_word) {
+                            if (CW > 1) asm volatile("" ::: "memory");   // keeps this a branch: not to be if-converted
                             score += (int32_t)((ph >> last_bit) & 1ull) - (int32_t)((mh >> last_bit) & 1ull);
                             if (score <= best) {                // the LAST minimum of the bottom row
                                 best = score;
@@ -222,10 +250,11 @@ __global__ __launch_bounds__(kWave) void bmv_align_kernel(Job J) {
                         hin = hout;
                         hacc[c] |= (uint32_t)(hout + 1) << (2u * x);
                         if (block_end) {
-                            hbuf[entry((j - 1u) / kBlock, w0 + w)] = hacc[c];
+                            const uint32_t e = entry((j - 1u) / kBlock, w0 + w);
+                            hbuf[e] = hacc[c];
                             hacc[c] = 0;
-                            if (j < n) {                        // state the next block starts from
-                                uint64_t *ck = ckpt + entry(j / kBlock, w0 + w) * 2u;
+                            if (j < n) {                        // state the next block starts from (j is a multiple of 16)
+                                uint64_t *ck = ckpt + (size_t)(e + GPW * TW) * 2u;
                                 ck[0] = pv[c];
                                 ck[1] = mv[c];
                             }
@@ -267,7 +296,7 @@ __global__ __launch_bounds__(kWave) void bmv_align_kernel(Job J) {
     auto load_checkpoint = [&](uint32_t w, uint32_t b) {
         Checkpoint k{~0ull, 0ull, 0x55555555u};                 // block 0 starts from column 0: H[i][0] = i
         if (b) {
-            const uint64_t *ck = ckpt + entry(b, w) * 2u;
+            const uint64_t *ck = ckpt + (size_t)entry(b, w) * 2u;
             k.pv = ck[0];
             k.mv = ck[1];
         }
@@ -297,7 +326,7 @@ __global__ __launch_bounds__(kWave) void bmv_align_kernel(Job J) {
             const uint32_t col = b * kBlock + 1u + (uint32_t)x;
             if (col <= n) {
                 const uint8_t ch = text[col - 1u];
-                const uint64_t eq0 = ch == 0 ? pm[0] : (ch == 1 ? pm[1] : (ch == 2 ? pm[2] : pm[3]));
+                const uint64_t eq0 = pick_mask(pm[0], pm[1], pm[2], pm[3], ch);
                 uint64_t ph, mh, d0;
                 myers_step(eq0, (int)((k.hw >> (2 * x)) & 3u) - 1, k.pv, k.mv, ph, mh, d0);
                 if (gl == (uint32_t)x % kHold) {
