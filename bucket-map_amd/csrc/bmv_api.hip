@@ -71,17 +71,35 @@ struct Shape {
     align_fn fn;
 };
 
-// A group is exactly as many lanes as the longest query has words (CW words per lane beyond 64 words); the
-// kernel variant only fixes how many of the group's lanes hold the traceback's 16 pairs of trace words.
-Shape pick_shape(uint32_t words) {
-    // the fewest words per lane that fit the query into one wave: every lane the group leaves idle is a lane's worth
-    // of the instruction stream wasted (a 10-kbp read is 157 words: 53 lanes x 3 words, not 40 x 4)
-    const int cw = words <= 64 ? 1 : (words <= 128 ? 2 : (words <= 192 ? 3 : 4));
-    // beyond 256 words the whole wave carries strips of 256 words, one after the other
-    const uint32_t g = std::min(64u, std::max(1u, (words + (uint32_t)cw - 1u) / (uint32_t)cw));
+// A group is as many lanes as the longest query has words, over CW words per lane; the kernel variant fixes CW and how many
+// of the group's lanes hold the traceback's 16 pairs of trace words.  CW is chosen by what a wave then spends per
+// alignment: a column step costs about 0.45 + CW in units of one word's recurrence (the shuffle, the text base and the
+// loop are paid once per step), there are n + group - 1 steps (the skew), and 64 / group alignments share them.  A
+// 5-kbp read (79 words) is 3 alignments of 20 lanes x 4 words per wave, not one of 40 x 2; a 10-kbp read (157 words) is
+// 53 x 3, not 40 x 4.
+Shape pick_shape(uint32_t words, uint32_t max_n) {
+    if (words > 256u) return {64u, 4, bmv::bmv_align_kernel<1, 4, true>};      // strips of 256 words, one after the other
+    int cw = 1;
+    double best = 0;
+    const char *env = getenv("BMV_CW");                          // experiment / test knob: force CW where it is possible
+    const int forced = env ? atoi(env) : 0;
+    for (int c = 1; c <= 4; c++) {
+        const uint32_t g = (words + (uint32_t)c - 1u) / (uint32_t)c;
+        if (g > 64u || (c > 1 && g < 16u)) continue;             // (the CW > 1 variants keep one trace pair per lane)
+        if (forced == c) {
+            cw = c;
+            break;
+        }
+        const double cost = (0.45 + c) * (double)(max_n + g - 1u) / (double)(64u / g);
+        if (best == 0 || cost < best * 0.98) {
+            best = cost;
+            cw = c;
+        }
+    }
+    const uint32_t g = std::max(1u, (words + (uint32_t)cw - 1u) / (uint32_t)cw);
     if (cw == 2) return {g, 2, bmv::bmv_align_kernel<1, 2, false>};
     if (cw == 3) return {g, 3, bmv::bmv_align_kernel<1, 3, false>};
-    if (cw == 4) return {g, 4, words <= 256 ? bmv::bmv_align_kernel<1, 4, false> : bmv::bmv_align_kernel<1, 4, true>};
+    if (cw == 4) return {g, 4, bmv::bmv_align_kernel<1, 4, false>};
     if (g >= 16) return {g, 1, bmv::bmv_align_kernel<1, 1, false>};
     if (g >= 8) return {g, 1, bmv::bmv_align_kernel<2, 1, false>};
     if (g >= 4) return {g, 1, bmv::bmv_align_kernel<4, 1, false>};
@@ -226,7 +244,7 @@ int bmv_align(bmv_ctx *c, const uint8_t *reads, uint64_t n_read_bytes, const uin
 
     // kernel shape for the longest query; scratch per alignment slot
     const uint32_t words = (max_m + 63u) / 64u;
-    const Shape sh = pick_shape(words ? words : 1u);
+    const Shape sh = pick_shape(words ? words : 1u, max_n);
     const uint32_t trace_words = std::max(words, 1u);           // >= sh.group * sh.cw only when strips are needed
     const uint32_t gpw = 64u / sh.group;
     // checkpoints every 16 columns: (Pv, Mv) per word, plus one 32-bit word of horizontal deltas per word and block

@@ -150,10 +150,9 @@ __global__ __launch_bounds__(kWave) void bmv_align_kernel(Job J) {
     uint32_t best_j = 0;
     const uint32_t last_word = W ? W - 1u : 0u, last_bit = (m - 1u) & 63u;
     const uint32_t last_lane = (last_word % strip_words) / CW;
-    // which of a lane's CW words can be the query's last: with CW > 1 the group is more than half the wave, the wave
-    // carries one alignment and the answer is the same in every lane -- a scalar branch skips the bottom-row bookkeeping
-    // in the other words' steps
-    const uint32_t last_c = CW > 1 ? (uint32_t)__builtin_amdgcn_readfirstlane((int)(last_word % CW)) : 0u;
+    // which of a lane's CW words can be the query's last: a wave that carries one alignment has the same answer in every
+    // lane, and a branch skips the bottom-row bookkeeping in the other words' steps
+    const uint32_t last_c = CW == 1 ? 0u : (GPW == 1 ? (uint32_t)__builtin_amdgcn_readfirstlane((int)(last_word % CW)) : last_word % CW);
     // the wave's groups run the same number of strips and steps (shuffles and barriers need the whole wave)
     uint32_t wave_strips = n_strips;
     if (STRIPS) {

@@ -216,6 +216,31 @@ def test_gpu_verifier_long_reads(m, n_align):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("max_m,n", [(1100, 40), (2100, 30), (4000, 16), (5000, 14), (8000, 8)])
+def test_gpu_verifier_every_words_per_lane(max_m, n, monkeypatch):
+    """The library picks the words per lane (1..4) by a cost model; BMV_CW forces each choice the batch allows.  With more
+    than one word per lane AND several alignments per wave (33..128-word queries) the groups of a wave differ in which
+    of a lane's words is the query's last."""
+    from bucket_map_amd import verify
+    rng = np.random.default_rng(max_m)
+    genome = rng.choice(list(b"ACGT"), 60_000).astype(np.uint8)
+    batch = _random_batch(rng, genome, n, max_m, (0.03, 0.02, 0.02))
+    q = genome[100:100 + max_m].copy()                 # one query of exactly max_m bases, so the shape is max_m's
+    batch = (np.concatenate([q, batch[0]]), np.concatenate([[99], batch[1]]).astype(np.uint64),
+             np.concatenate([[max_m + 1 + max_m // 10], batch[2]]).astype(np.uint32), np.concatenate([[0], batch[3]]).astype(np.uint8),
+             np.concatenate([[0], batch[4] + max_m]).astype(np.uint64), np.concatenate([[max_m], batch[5]]).astype(np.uint32))
+    v = verify.Verifier()
+    v.load_genome(genome)
+    for cw in ("1", "2", "3", "4", ""):
+        if cw:
+            monkeypatch.setenv("BMV_CW", cw)
+        else:
+            monkeypatch.delenv("BMV_CW")
+        _compare(v, genome, batch, f"max_m={max_m} BMV_CW={cw or 'model'}")
+    v.close()
+
+
+@pytest.mark.gpu
 def test_gpu_verifier_chunked_equals_one_pass():
     from bucket_map_amd import verify
     rng = np.random.default_rng(77)
@@ -339,7 +364,12 @@ def test_gpu_verifier_random_sweep(seed):
     err = (float(rng.choice([0.0, 0.01, 0.05, 0.2])), float(rng.choice([0.0, 0.005, 0.03])), float(rng.choice([0.0, 0.005, 0.03])))
     genome = rng.choice(list(b"ACGT"), max(4 * max_m, 2000)).astype(np.uint8)
     n = int(np.clip(60000 // max_m, 3, 150))
+    cw = int(rng.integers(0, 5))                       # 0: the library's own choice
     v = verify.Verifier()
     v.load_genome(genome)
-    _compare(v, genome, _random_batch(rng, genome, n, max_m, err), f"seed={seed} max_m={max_m} err={err}")
+    os.environ["BMV_CW"] = str(cw)
+    try:
+        _compare(v, genome, _random_batch(rng, genome, n, max_m, err), f"seed={seed} max_m={max_m} err={err} BMV_CW={cw}")
+    finally:
+        del os.environ["BMV_CW"]
     v.close()
