@@ -3,6 +3,29 @@
 // that the traceback bits of one chunk fit the scratch budget, offsets of the packed CIGAR output
 // (hipCUB exclusive sum, a library primitive).
 #include "bmv_kernels.hip.h"
+
+namespace bmv {
+// instantiated in bmv_variants.hip
+extern template __global__ void bmv_align_kernel<1, 5, false>(Job);
+extern template __global__ void bmv_align_kernel<1, 6, false>(Job);
+extern template __global__ void bmv_align_kernel<1, 7, false>(Job);
+extern template __global__ void bmv_align_kernel<1, 8, false>(Job);
+extern template __global__ void bmv_align_kernel<1, 6, true>(Job);
+extern template __global__ void bmv_align_kernel<1, 8, true>(Job);
+
+// CIGAR entries of one chunk, reversed into reading order at their final offsets.
+__global__ void bmv_gather_kernel(const uint32_t *__restrict__ ops_rev, uint32_t ops_stride,
+                                  const uint32_t *__restrict__ nops, const uint32_t *__restrict__ offsets,
+                                  uint32_t count, uint32_t *__restrict__ out) {
+    const uint32_t slot = blockIdx.x * (blockDim.x / 8u) + threadIdx.x / 8u, t = threadIdx.x % 8u;
+    if (slot >= count) return;
+    const uint32_t c = nops[slot];
+    const uint32_t *src = ops_rev + (size_t)slot * ops_stride;
+    uint32_t *dst = out + offsets[slot];
+    for (uint32_t x = t; x < c; x += 8u) dst[x] = src[c - 1u - x];
+}
+
+}  // namespace bmv
 #include "bm_hip_util.h"
 
 #include "../../include/bmv.h"
@@ -73,34 +96,45 @@ struct Shape {
 
 // A group is as many lanes as the longest query has words, over CW words per lane; the kernel variant fixes CW and how many
 // of the group's lanes hold the traceback's 16 pairs of trace words.  CW is chosen by what a wave then spends per
-// alignment: a column step costs about 0.45 + CW in units of one word's recurrence (the shuffle, the text base and the
-// loop are paid once per step), there are n + group - 1 steps (the skew), and 64 / group alignments share them.  A
-// 5-kbp read (79 words) is 3 alignments of 20 lanes x 4 words per wave, not one of 40 x 2; a 10-kbp read (157 words) is
-// 53 x 3, not 40 x 4.
+// alignment: the cost of a column step at that CW (the table below: what a step pays once -- the neighbour lane's delta,
+// the text base, the loop -- is worth about 1.6 words' recurrences), times n + group - 1 steps (the skew), over the
+// 64 / group alignments that share them.  A 5-kbp read (79 words) is 4 alignments of 16 lanes x 5 words per wave, not
+// one of 40 x 2; a 10-kbp read (157 words) is 2 of 32 x 5, not one of 40 x 4.
+constexpr int kMaxCw = 8;
+// what one column step of a wave costs at CW words per lane, measured (ns of the whole card per wave and step,
+// tools/bench_verify_cw.sh; only the ratios matter): about 1.6 + CW words' recurrences up to CW = 4, more beyond, where
+// the registers a lane holds (13 per word) begin to cost waves per SIMD
+constexpr double kStepCost[kMaxCw + 1] = {0, 0.221, 0.300, 0.390, 0.475, 0.600, 0.660, 0.800, 0.950};
+constexpr uint32_t kStripsBeyond = 64u * kMaxCw;                 // words: longer queries go through in strips
+
 Shape pick_shape(uint32_t words, uint32_t max_n) {
-    if (words > 256u) return {64u, 4, bmv::bmv_align_kernel<1, 4, true>};      // strips of 256 words, one after the other
-    int cw = 1;
+    // strips of 64 * CW words, one after the other (max_query_len = 65 536 bases: two of them)
+    if (words > kStripsBeyond)
+        return words <= 2u * 64u * 6u ? Shape{64u, 6, bmv::bmv_align_kernel<1, 6, true>} : Shape{64u, 8, bmv::bmv_align_kernel<1, 8, true>};
+    static const align_fn one_pass[kMaxCw + 1] = {nullptr,
+                                                  bmv::bmv_align_kernel<1, 1, false>, bmv::bmv_align_kernel<1, 2, false>,
+                                                  bmv::bmv_align_kernel<1, 3, false>, bmv::bmv_align_kernel<1, 4, false>,
+                                                  bmv::bmv_align_kernel<1, 5, false>, bmv::bmv_align_kernel<1, 6, false>,
+                                                  bmv::bmv_align_kernel<1, 7, false>, bmv::bmv_align_kernel<1, 8, false>};
+    int cw = 0;
     double best = 0;
     const char *env = getenv("BMV_CW");                          // experiment / test knob: force CW where it is possible
     const int forced = env ? atoi(env) : 0;
-    for (int c = 1; c <= 4; c++) {
+    for (int c = 1; c <= kMaxCw; c++) {
         const uint32_t g = (words + (uint32_t)c - 1u) / (uint32_t)c;
         if (g > 64u || (c > 1 && g < 16u)) continue;             // (the CW > 1 variants keep one trace pair per lane)
         if (forced == c) {
             cw = c;
             break;
         }
-        const double cost = (0.45 + c) * (double)(max_n + g - 1u) / (double)(64u / g);
-        if (best == 0 || cost < best * 0.98) {
+        const double cost = kStepCost[c] * (double)(max_n + g - 1u) / (double)(64u / g);
+        if (cw == 0 || cost < best * 0.98) {
             best = cost;
             cw = c;
         }
     }
     const uint32_t g = std::max(1u, (words + (uint32_t)cw - 1u) / (uint32_t)cw);
-    if (cw == 2) return {g, 2, bmv::bmv_align_kernel<1, 2, false>};
-    if (cw == 3) return {g, 3, bmv::bmv_align_kernel<1, 3, false>};
-    if (cw == 4) return {g, 4, bmv::bmv_align_kernel<1, 4, false>};
-    if (g >= 16) return {g, 1, bmv::bmv_align_kernel<1, 1, false>};
+    if (cw > 1 || g >= 16) return {g, cw, one_pass[cw]};
     if (g >= 8) return {g, 1, bmv::bmv_align_kernel<2, 1, false>};
     if (g >= 4) return {g, 1, bmv::bmv_align_kernel<4, 1, false>};
     if (g >= 2) return {g, 1, bmv::bmv_align_kernel<8, 1, false>};
@@ -252,11 +286,8 @@ int bmv_align(bmv_ctx *c, const uint8_t *reads, uint64_t n_read_bytes, const uin
     const uint64_t n_entries = (uint64_t)n_blocks * gpw * std::max(trace_words, sh.group * (uint32_t)sh.cw);
     const uint64_t trace_stride = n_entries * 2u + (n_entries + 1u) / 2u;   // 64-bit words per wave
     const uint32_t ops_stride = max_m + max_n + 1u;
-    const uint32_t lds_stride = (max_n + 15u) & ~15u;
-    const uint32_t qry_stride = std::max(64u, std::min((max_m + 63u) & ~63u, sh.group * (uint32_t)sh.cw * 64u));   // one strip
-    // (the query lends its LDS to the text once its match masks are built, unless the kernel works in strips)
-    const bool strips = words > 256u;
-    const size_t lds = 256 + (size_t)gpw * (strips ? lds_stride + qry_stride : std::max(lds_stride, qry_stride));
+    const uint32_t lds_stride = (max_n + 15u) / 16u * 4u + 4u;          // the text as a 2-bit stream
+    const size_t lds = 256 + (size_t)gpw * lds_stride;
     if (lds > 160 * 1024) return fail(BMV_ERR_UNSUPPORTED, "text windows of %u bases need %zu B of LDS", max_n, lds);
     if (lds > 48 * 1024)
         HIP_TRY(bmhip::raise_dynamic_lds(reinterpret_cast<const void *>(sh.fn), lds));
@@ -298,7 +329,6 @@ int bmv_align(bmv_ctx *c, const uint8_t *reads, uint64_t n_read_bytes, const uin
         j.ops_rev = c->ops_rev.p;
         j.ops_stride = ops_stride;
         j.text_lds_stride = lds_stride;
-        j.query_lds_stride = qry_stride;
         j.out_score = c->out_score.p;
         j.out_begin = c->out_begin.p;
         j.out_nops = c->nops.p;

@@ -7,12 +7,15 @@
 //
 // Myers' bit-vector recurrence (Hyyro's block form): one 64-bit word carries 64 query rows of one text
 // column as +1/-1 vertical deltas (Pv, Mv); a column step is ~20 word operations.  A query of m bases is
-// ceil(m/64) words; they are laid over the lanes of a GROUP (CW consecutive words per lane) and the lanes
+// ceil(m/64) words; they are laid over the lanes of a GROUP (CW consecutive words per lane, 1..8) and the lanes
 // are skewed along the text: at step t lane l works on column t-l and takes the horizontal delta that
 // leaves lane l-1's last row (computed one step earlier) through a shuffle.  A group is exactly as many lanes
-// as the longest query of the batch has words (any size, not a power of two: lanes are addressed explicitly),
-// so a wave verifies 64/G candidates at once: 21 for 150-bp reads, 12 for 300-bp reads, 1 for 10-kbp reads.
-// A query of more than 64 * CW words (16 384 bases at CW = 4) is processed in STRIPS of that many words, one
+// as the longest query of the batch has words over CW (any size, not a power of two: lanes are addressed explicitly),
+// so a wave verifies 64/G candidates at once: 12 for 300-bp reads (5 lanes x 1 word), 3 for 5-kbp reads (20 x 4),
+// 2 for 10-kbp reads (32 x 5).  The host picks CW (bmv_api.hip, pick_shape): what a step pays once -- the shuffle and
+// the wait for it, the text base, the loop -- is worth about 1.5 words' recurrences, so more words per lane and more
+// alignments per wave win until the group would fall below 16 lanes.
+// A query of more than 512 words (32 768 bases) is processed in STRIPS of 64 * CW words, one
 // after the other over the whole text: the horizontal deltas entering a strip's first word are the stored
 // ones that left the last word of the strip above.
 //
@@ -54,8 +57,7 @@ struct Job {
     uint32_t group;                 // lanes per alignment (1..64); 64 / group alignments per wave
     uint32_t *ops_rev;              // count x ops_stride reversed CIGAR entries
     uint32_t ops_stride;
-    uint32_t text_lds_stride;       // bytes of LDS per group for the text window ...
-    uint32_t query_lds_stride;      // ... and for the query (a multiple of 64)
+    uint32_t text_lds_stride;       // bytes of LDS per group for the text window (2 bits per base, a multiple of 4)
     int32_t *out_score;             // per alignment of the batch
     uint32_t *out_begin;
     uint32_t *out_nops;             // per slot
@@ -115,29 +117,31 @@ __global__ __launch_bounds__(kWave) void bmv_align_kernel(Job J) {
     const uint32_t W = (m + 63u) >> 6;                         // words of the query
     const uint32_t strip_words = GROUP * CW;                    // words one pass over the text carries
     const uint32_t n_strips = (STRIPS && W) ? (W + strip_words - 1u) / strip_words : 1u;
-    // LDS: the dna4 folding table, then per group the text window and (one strip of) the query, both as ranks.  The query
-    // is only read to build the match masks: unless there are strips to come it lends its place to the text afterwards
-    // (half the LDS, twice the waves per CU).
+    // LDS: the dna4 folding table, then per group the text window as a 2-bit stream (16 columns per 32-bit word, column
+    // 16 i + x in bits 2x.. of word i).  Nothing else: the LDS a wave holds decides how many waves a CU runs, and this
+    // kernel is a chain of dependent steps that needs them.
     uint8_t *lut = lds_text;
-    const uint32_t group_lds = STRIPS ? J.text_lds_stride + J.query_lds_stride
-                                      : (J.text_lds_stride > J.query_lds_stride ? J.text_lds_stride : J.query_lds_stride);
-    uint8_t *text = lds_text + 256 + (size_t)grp * group_lds;
-    uint8_t *qry = STRIPS ? text + J.text_lds_stride : text;
+    uint32_t *text = reinterpret_cast<uint32_t *>(lds_text + 256 + (size_t)grp * J.text_lds_stride);
     reinterpret_cast<uint32_t *>(lut)[lane] = reinterpret_cast<const uint32_t *>(J.lut)[lane];
     __syncthreads();
-    auto load_text = [&]() {
-        if (have) {
-            // text window, reverse-complemented if asked (bucket_locator.h:562-567)
-            const uint8_t *src = J.genome + J.text_start[a];
-            const bool rc = J.text_rc[a] != 0;
-#pragma unroll 4
-            for (uint32_t j = gl; j < n; j += GROUP) {
-                const uint8_t r = lut[rc ? src[n - 1u - j] : src[j]];
-                text[j] = rc ? (uint8_t)(3u - r) : r;
+    if (have) {
+        // text window, reverse-complemented if asked (bucket_locator.h:562-567)
+        const uint8_t *src = J.genome + J.text_start[a];
+        const bool rc = J.text_rc[a] != 0;
+        for (uint32_t i = gl; i * kBlock < n; i += GROUP) {
+            uint32_t v = 0;
+#pragma unroll
+            for (uint32_t x = 0; x < kBlock; x++) {
+                const uint32_t j = i * kBlock + x;
+                if (j < n) {
+                    const uint32_t r = lut[rc ? src[n - 1u - j] : src[j]];
+                    v |= (rc ? 3u - r : r) << (2u * x);
+                }
             }
+            text[i] = v;
         }
-    };
-    if (STRIPS) load_text();
+    }
+    __syncthreads();
     // checkpoint entry of (block b, this group, word w of the query): (b * GPW + grp) * TW + w
     const uint32_t TW = J.trace_words;
     uint64_t *ckpt = J.trace + (size_t)blockIdx.x * J.trace_stride;
@@ -167,40 +171,28 @@ __global__ __launch_bounds__(kWave) void bmv_align_kernel(Job J) {
         const bool live = have && strip < n_strips;
         const uint32_t Ws = live ? (W - w0 < strip_words ? W - w0 : strip_words) : 0u;   // words in this strip
         const uint32_t L = (Ws + CW - 1u) / CW;                 // lanes of the group that hold rows of it
-        __syncthreads();                                        // the previous strip's query rows are no longer read
-        if (live) {
-            const uint8_t *q = J.reads + J.query_start[a] + (size_t)w0 * 64u;
-            const uint32_t rows = m - w0 * 64u, padded = Ws * 64u;      // rows past the query match nothing
-#pragma unroll 4
-            for (uint32_t i = gl; i < padded; i += GROUP) qry[i] = i < rows ? lut[q[i]] : (uint8_t)0xFF;
-        }
-        __syncthreads();
-        // match masks of this lane's words, one per base
+        // match masks of this lane's words, one per base, straight from the read (rows past the query match nothing)
 #pragma unroll
         for (int c = 0; c < CW; c++) {
-            peq[0][c] = peq[1][c] = peq[2][c] = peq[3][c] = 0;
+            uint64_t p0 = 0, p1 = 0, p2 = 0, p3 = 0;
             const uint32_t w = gl * CW + c;
             if (live && w < Ws) {
-                const uint64_t *q8 = reinterpret_cast<const uint64_t *>(qry + (size_t)w * 64u);
-#pragma unroll
-                for (int k = 0; k < 8; k++) {
-                    const uint64_t v = q8[k];
-#pragma unroll
-                    for (int t = 0; t < 8; t++) {
-                        const uint32_t r = (uint32_t)(v >> (8 * t)) & 0xFFu;
-                        const uint64_t bit = 1ull << (8 * k + t);
-                        peq[0][c] |= r == 0 ? bit : 0;
-                        peq[1][c] |= r == 1 ? bit : 0;
-                        peq[2][c] |= r == 2 ? bit : 0;
-                        peq[3][c] |= r == 3 ? bit : 0;
-                    }
+                const uint32_t row0 = (w0 + w) * 64u, rows = m - row0 < 64u ? m - row0 : 64u;
+                const uint8_t *q = J.reads + J.query_start[a] + row0;
+#pragma unroll 8
+                for (uint32_t k = 0; k < 64u; k++) {
+                    const uint32_t r = k < rows ? lut[q[k]] : 0xFFu;
+                    const uint64_t bit = 1ull << k;
+                    p0 |= r == 0 ? bit : 0;
+                    p1 |= r == 1 ? bit : 0;
+                    p2 |= r == 2 ? bit : 0;
+                    p3 |= r == 3 ? bit : 0;
                 }
             }
-        }
-        if (!STRIPS) {                                          // the query's rows are in registers now
-            __syncthreads();
-            load_text();
-            __syncthreads();
+            peq[0][c] = p0;
+            peq[1][c] = p1;
+            peq[2][c] = p2;
+            peq[3][c] = p3;
         }
         uint64_t pv[CW], mv[CW];
         uint32_t hacc[CW];                                      // horizontal deltas of the current block, 2 bits each
@@ -219,11 +211,13 @@ __global__ __launch_bounds__(kWave) void bmv_align_kernel(Job J) {
         int hout_prev = 0;
         uint32_t habove = 0x55555555u;                          // deltas leaving the strip above, 16 columns at a time
         for (uint32_t t = 1; t <= steps; t++) {
-            int hin = __shfl_up(hout_prev, 1, kWave);
+            // the delta that left lane l-1's last row a step ago: a DPP move down the whole wave by one lane (wave_shr:1), a
+            // VALU operation -- __shfl_up is a round trip through the LDS crossbar, waited for at the head of every step
+            int hin = __builtin_amdgcn_update_dpp(0, hout_prev, 0x138, 0xF, 0xF, false);
             const uint32_t j = t - gl;                          // 1-based text column of this lane
             if (gl < L && j >= 1u && j <= n && t >= gl + 1u) {
-                const uint8_t ch = text[j - 1u];
                 const uint32_t x = (j - 1u) % kBlock;
+                const uint32_t ch = (text[(j - 1u) / kBlock] >> (2u * x)) & 3u;
                 const bool block_end = x == kBlock - 1u || j == n;
                 if (gl == 0) {
                     // row 0 is all zeros (free leading text gaps); below the first strip the deltas come from
@@ -308,9 +302,9 @@ __global__ __launch_bounds__(kWave) void bmv_align_kernel(Job J) {
             const uint32_t owner = w / CW, c = w % CW;
 #pragma unroll
             for (int r = 0; r < 4; r++) {
-                uint64_t v = peq[r][0];
-#pragma unroll
-                for (int cc = 1; cc < CW; cc++) v = c == (uint32_t)cc ? peq[r][cc] : v;
+                uint64_t v = 0;                                 // (masks, not ?: -- a select chain over the array becomes a
+#pragma unroll                                                  //  dynamic index, and the array then lives in scratch memory)
+                for (int cc = 0; cc < CW; cc++) v |= peq[r][cc] & (0ull - (uint64_t)(c == (uint32_t)cc));
                 pm[r] = shfl64(v, (int)(lane0 + owner));
             }
         } else {                                                // ... rebuilt: the registers hold the last strip only.
@@ -320,11 +314,12 @@ __global__ __launch_bounds__(kWave) void bmv_align_kernel(Job J) {
 #pragma unroll
             for (int r = 0; r < 4; r++) pm[r] = __ballot(rk == (uint32_t)r);
         }
+        const uint32_t tw = text[b];                            // the block's 16 text bases
 #pragma unroll
         for (int x = 0; x < (int)kBlock; x++) {
             const uint32_t col = b * kBlock + 1u + (uint32_t)x;
             if (col <= n) {
-                const uint8_t ch = text[col - 1u];
+                const uint32_t ch = (tw >> (2 * x)) & 3u;
                 const uint64_t eq0 = pick_mask(pm[0], pm[1], pm[2], pm[3], ch);
                 uint64_t ph, mh, d0;
                 myers_step(eq0, (int)((k.hw >> (2 * x)) & 3u) - 1, k.pv, k.mv, ph, mh, d0);
@@ -403,18 +398,6 @@ __global__ __launch_bounds__(kWave) void bmv_align_kernel(Job J) {
         J.out_begin[a] = j;
         J.out_nops[slot] = n_rev;
     }
-}
-
-// CIGAR entries of one chunk, reversed into reading order at their final offsets.
-__global__ void bmv_gather_kernel(const uint32_t *__restrict__ ops_rev, uint32_t ops_stride,
-                                  const uint32_t *__restrict__ nops, const uint32_t *__restrict__ offsets,
-                                  uint32_t count, uint32_t *__restrict__ out) {
-    const uint32_t slot = blockIdx.x * (blockDim.x / 8u) + threadIdx.x / 8u, t = threadIdx.x % 8u;
-    if (slot >= count) return;
-    const uint32_t c = nops[slot];
-    const uint32_t *src = ops_rev + (size_t)slot * ops_stride;
-    uint32_t *dst = out + offsets[slot];
-    for (uint32_t x = t; x < c; x += 8u) dst[x] = src[c - 1u - x];
 }
 
 }  // namespace bmv

@@ -186,9 +186,11 @@ def test_gpu_verifier_matches_oracle(max_m, n, err):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("m,n_align", [(6000, 3), (10000, 2), (12288, 1), (12289, 1), (16384, 1), (16385, 1), (20000, 2), (33000, 1)])
-# 2, 3 (up to 192 words = 12 288 bases) and 4 words per lane; beyond 16 384 bases the query is processed in strips
-# (2, 2 and 3 of them)
+@pytest.mark.parametrize("m,n_align", [(6000, 3), (10000, 2), (12288, 1), (12289, 1), (16385, 1), (20000, 2), (25000, 1), (30000, 1),
+                                       (32768, 1), (32769, 1), (33000, 1)])
+# 5 to 8 words per lane (the cost model's choice: 6 000 -> 6 x 16 lanes, 10 000 -> 5 x 32, 12 288 -> 6 x 32, 12 289 -> 7 x 28,
+# 16 385 -> 5 x 52, 20 000 -> 5 x 63, 25 000 -> 7 x 56, 30 000 -> 8 x 59, 32 768 -> 8 x 64); beyond 32 768 bases the query
+# is processed in two strips of 6 x 64 words
 def test_gpu_verifier_long_reads(m, n_align):
     from bucket_map_amd import verify
     rng = np.random.default_rng(m)
@@ -218,7 +220,7 @@ def test_gpu_verifier_long_reads(m, n_align):
 @pytest.mark.gpu
 @pytest.mark.parametrize("max_m,n", [(1100, 40), (2100, 30), (4000, 16), (5000, 14), (8000, 8)])
 def test_gpu_verifier_every_words_per_lane(max_m, n, monkeypatch):
-    """The library picks the words per lane (1..4) by a cost model; BMV_CW forces each choice the batch allows.  With more
+    """The library picks the words per lane (1..8) by a cost model; BMV_CW forces each choice the batch allows.  With more
     than one word per lane AND several alignments per wave (33..128-word queries) the groups of a wave differ in which
     of a lane's words is the query's last."""
     from bucket_map_amd import verify
@@ -231,7 +233,7 @@ def test_gpu_verifier_every_words_per_lane(max_m, n, monkeypatch):
              np.concatenate([[0], batch[4] + max_m]).astype(np.uint64), np.concatenate([[max_m], batch[5]]).astype(np.uint32))
     v = verify.Verifier()
     v.load_genome(genome)
-    for cw in ("1", "2", "3", "4", ""):
+    for cw in ("1", "2", "3", "4", "5", "6", "7", "8", ""):
         if cw:
             monkeypatch.setenv("BMV_CW", cw)
         else:
@@ -364,7 +366,7 @@ def test_gpu_verifier_random_sweep(seed):
     err = (float(rng.choice([0.0, 0.01, 0.05, 0.2])), float(rng.choice([0.0, 0.005, 0.03])), float(rng.choice([0.0, 0.005, 0.03])))
     genome = rng.choice(list(b"ACGT"), max(4 * max_m, 2000)).astype(np.uint8)
     n = int(np.clip(60000 // max_m, 3, 150))
-    cw = int(rng.integers(0, 5))                       # 0: the library's own choice
+    cw = int(rng.integers(0, 9))                       # 0: the library's own choice
     v = verify.Verifier()
     v.load_genome(genome)
     os.environ["BMV_CW"] = str(cw)
