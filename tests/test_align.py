@@ -218,6 +218,26 @@ def test_gpu_verifier_long_reads(m, n_align):
 
 
 @pytest.mark.gpu
+def test_gpu_verifier_longest_strips():
+    """Beyond 49 152 bases the two strips are of 8 x 64 words.  The oracle's full matrix for this one is 9.7 GB."""
+    import psutil
+    if psutil.virtual_memory().available < 24 << 30:
+        pytest.skip("needs 10 GB for the oracle's matrix")
+    from bucket_map_amd import verify
+    m = 49_200
+    rng = np.random.default_rng(m)
+    genome = rng.choice(list(b"ACGT"), 52_000).astype(np.uint8)
+    q = _mutate(rng, genome[500:500 + m], 0.03, 0.025, 0.025)[:m]
+    batch = (q, np.array([350], np.uint64), np.array([m + 300], np.uint32), np.array([0], np.uint8), np.array([0], np.uint64),
+             np.array([len(q)], np.uint32))
+    v = verify.Verifier()
+    v.load_genome(genome)
+    s = _compare(v, genome, batch, f"m={m}")
+    assert (s > -0.15 * m).all()
+    v.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("max_m,n", [(1100, 40), (2100, 30), (4000, 16), (5000, 14), (8000, 8)])
 def test_gpu_verifier_every_words_per_lane(max_m, n, monkeypatch):
     """The library picks the words per lane (1..8) by a cost model; BMV_CW forces each choice the batch allows.  With more
