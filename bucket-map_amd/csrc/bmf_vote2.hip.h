@@ -433,9 +433,14 @@ __device__ __forceinline__ uint32_t stream_column(const DevParams &P, const uint
     return act ? n_rows : 0u;
 }
 
-// (4 waves per SIMD asked for: at most 128 VGPRs, the latency of the short dependent streams needs the waves)
+// (4 waves per SIMD asked for: at most 128 VGPRs, the latency of the short dependent streams needs the waves.  The 16
+//  registers this spills cost less than the waves they buy: pruned Egu step 16.96 ms; 17.35 ms at 3 waves and no spill,
+//  21.3 ms at 5 waves -- tools/try_libs.sh over builds with -DBMF_RECOUNT_OCC=3 / 5.)
+#ifndef BMF_RECOUNT_OCC
+#define BMF_RECOUNT_OCC 4
+#endif
 template <int PLANES, int LIVE>
-__global__ __launch_bounds__(kWave, 4) void bmf_recount_kernel(DevParams P, const uint8_t *__restrict__ rows,
+__global__ __launch_bounds__(kWave, BMF_RECOUNT_OCC) void bmf_recount_kernel(DevParams P, const uint8_t *__restrict__ rows,
                                                            const uint32_t *__restrict__ row_lists, uint32_t n_items,
                                                            uint32_t *__restrict__ out_counts,
                                                            uint32_t *__restrict__ out_buckets, Pass2Queue Q) {
