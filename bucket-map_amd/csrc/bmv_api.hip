@@ -143,16 +143,20 @@ Shape pick_shape(uint32_t words, uint32_t max_n) {
 
 }  // namespace
 
+constexpr uint32_t kSideStreams = 4;
+
 struct bmv_ctx {
     bmv_params p{};
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipStream_t side[kSideStreams] = {};       // length classes of one batch run side by side on these
+    hipEvent_t side_done[kSideStreams] = {};
     bool loaded = false;
     uint64_t n_genome = 0;
     size_t scratch_bytes = 0;
     DevBuf<uint8_t> genome, lut, reads, text_rc, scan_tmp;
     DevBuf<uint64_t> text_start, query_start, trace;
-    DevBuf<uint32_t> text_len, query_len, ops_rev, nops, offsets, packed, out_begin;
+    DevBuf<uint32_t> text_len, query_len, ops_rev, nops, offsets, packed, out_begin, order;
     DevBuf<int32_t> out_score;
     // results of the last bmv_align, host side
     uint32_t n_last = 0;
@@ -194,7 +198,11 @@ int bmv_create(const bmv_params *params, bmv_ctx **out) {
     }
     uint8_t lut[256];
     build_dna4_lut(lut);
-    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
+    bool side_ok = true;
+    for (uint32_t k = 0; k < kSideStreams; k++)
+        side_ok = side_ok && hipStreamCreateWithFlags(&c->side[k], hipStreamNonBlocking) == hipSuccess &&
+                  hipEventCreateWithFlags(&c->side_done[k], hipEventDisableTiming) == hipSuccess;
+    if (!side_ok || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
         c->lut.need(256) != hipSuccess || hipMemcpy(c->lut.p, lut, 256, hipMemcpyHostToDevice) != hipSuccess) {
         bmv_destroy(c);
@@ -208,10 +216,17 @@ void bmv_destroy(bmv_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->p.device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (uint32_t k = 0; k < kSideStreams; k++) {
+        if (c->side[k]) {
+            (void)hipStreamSynchronize(c->side[k]);
+            (void)hipStreamDestroy(c->side[k]);
+        }
+        if (c->side_done[k]) (void)hipEventDestroy(c->side_done[k]);
+    }
     c->genome.release(); c->lut.release(); c->reads.release(); c->text_rc.release(); c->scan_tmp.release();
     c->text_start.release(); c->query_start.release(); c->trace.release();
     c->text_len.release(); c->query_len.release(); c->ops_rev.release(); c->nops.release(); c->offsets.release();
-    c->packed.release(); c->out_begin.release(); c->out_score.release();
+    c->packed.release(); c->out_begin.release(); c->out_score.release(); c->order.release();
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -235,7 +250,6 @@ int bmv_align(bmv_ctx *c, const uint8_t *reads, uint64_t n_read_bytes, const uin
     if (!c->loaded) return fail(BMV_ERR_STATE, "bmv_align before bmv_load_genome");
     if (n && (!text_start || !text_len || !text_rc || !query_start || !query_len || (n_read_bytes && !reads)))
         return fail(BMV_ERR_ARG, "bmv_align: null argument");
-    uint32_t max_m = 0, max_n = 0;
     uint64_t cells = 0;
     for (uint32_t a = 0; a < n; a++) {
         if (query_len[a] > c->p.max_query_len)
@@ -246,8 +260,6 @@ int bmv_align(bmv_ctx *c, const uint8_t *reads, uint64_t n_read_bytes, const uin
             return fail(BMV_ERR_ARG, "alignment %u: query lies outside the read buffer", a);
         if (text_start[a] > c->n_genome || text_len[a] > c->n_genome - text_start[a])
             return fail(BMV_ERR_ARG, "alignment %u: text lies outside the genome", a);
-        max_m = std::max(max_m, query_len[a]);
-        max_n = std::max(max_n, text_len[a]);
         cells += (uint64_t)query_len[a] * text_len[a];
     }
     c->n_last = n;
@@ -276,40 +288,92 @@ int bmv_align(bmv_ctx *c, const uint8_t *reads, uint64_t n_read_bytes, const uin
     HIP_TRY(hipMemcpyAsync(c->query_start.p, query_start, (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemcpyAsync(c->query_len.p, query_len, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
 
-    // kernel shape for the longest query; scratch per alignment slot
-    const uint32_t words = (max_m + 63u) / 64u;
-    const Shape sh = pick_shape(words ? words : 1u, max_n);
-    const uint32_t trace_words = std::max(words, 1u);           // >= sh.group * sh.cw only when strips are needed
-    const uint32_t gpw = 64u / sh.group;
-    // checkpoints every 16 columns: (Pv, Mv) per word, plus one 32-bit word of horizontal deltas per word and block
-    const uint32_t n_blocks = (max_n + 15u) / 16u + 1u;
-    const uint64_t n_entries = (uint64_t)n_blocks * gpw * std::max(trace_words, sh.group * (uint32_t)sh.cw);
-    const uint64_t trace_stride = n_entries * 2u + (n_entries + 1u) / 2u;   // 64-bit words per wave
-    const uint32_t ops_stride = max_m + max_n + 1u;
-    const uint32_t lds_stride = (max_n + 15u) / 16u * 4u + 4u;          // the text as a 2-bit stream
-    const size_t lds = 256 + (size_t)gpw * lds_stride;
-    if (lds > 160 * 1024) return fail(BMV_ERR_UNSUPPORTED, "text windows of %u bases need %zu B of LDS", max_n, lds);
-    if (lds > 48 * 1024)
-        HIP_TRY(bmhip::raise_dynamic_lds(reinterpret_cast<const void *>(sh.fn), lds));
-    const uint64_t per_slot = trace_stride / gpw * 8u + (uint64_t)ops_stride * 4u;
-    uint64_t chunk = std::max<uint64_t>(gpw, c->scratch_bytes / per_slot);
-    chunk = std::min<uint64_t>(chunk, (uint64_t)gpw << 25);   // one wave per gpw alignments: waves * 64 threads < 2^32
-    chunk = std::min<uint64_t>(chunk / gpw * gpw, (uint64_t)n);
-    if (chunk == 0) chunk = n;
+    // Length classes.  The kernel's shape -- lanes per alignment, words per lane -- is fixed per launch by the longest query
+    // it holds, and a 5-kbp read run in the shape of a 30-kbp one costs six times what it should: the batch is cut into
+    // classes of similar query length (in 64-row words; everything up to 16 words -- 1 024 bases -- is one class, so a
+    // short-read batch stays one launch), each class is a launch series of its own over an index list, and the
+    // results find their way back through that list.
+    static const uint32_t kClassUpTo[] = {16, 20, 24, 32, 40, 48, 64, 80, 96, 128, 160, 192, 256, 320, 384, 512, 640, 768, 1024};
+    constexpr uint32_t kClasses = sizeof kClassUpTo / sizeof kClassUpTo[0];
+    const bool classes_off = getenv("BMV_ONE_CLASS") != nullptr;    // experiment knob: the whole batch in the longest query's shape
+    auto class_of = [&](uint32_t m) {
+        const uint32_t words = classes_off ? 0u : (m + 63u) / 64u;
+        uint32_t k = 0;
+        while (k + 1u < kClasses && words > kClassUpTo[k]) k++;
+        return k;
+    };
+    uint32_t class_lo[kClasses + 1] = {0};
+    for (uint32_t a = 0; a < n; a++) class_lo[class_of(query_len[a]) + 1u]++;
+    uint32_t n_classes = 0;
+    for (uint32_t k = 0; k < kClasses; k++) {
+        n_classes += class_lo[k + 1] ? 1u : 0u;
+        class_lo[k + 1] += class_lo[k];
+    }
+    std::vector<uint32_t> order(n);
+    {
+        uint32_t at[kClasses];
+        for (uint32_t k = 0; k < kClasses; k++) at[k] = class_lo[k];
+        for (uint32_t a = 0; a < n; a++) order[at[class_of(query_len[a])]++] = a;      // stable: file order within a class
+    }
+    const bool one_class = n_classes == 1;                      // then order is the identity and the CIGARs arrive in place
+    HIP_TRY(c->order.need(n));
+    HIP_TRY(hipMemcpyAsync(c->order.p, order.data(), (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+    std::vector<uint32_t> h_nops, h_packed, cigar_len, stash;
+    std::vector<uint64_t> stash_at;
+    if (!one_class) {
+        cigar_len.assign(n, 0);
+        stash_at.assign(n, 0);
+    }
     // Grow these with headroom: the longest read differs a little from call to call, and reallocating tens of
     // gigabytes every time it grows costs seconds.
     auto with_headroom = [](size_t need, size_t have) { return need <= have ? have : need + need / 4; };
-    HIP_TRY(c->trace.need(with_headroom((size_t)((chunk + gpw - 1u) / gpw * trace_stride), c->trace.cap)));
-    HIP_TRY(c->ops_rev.need(with_headroom((size_t)(chunk * ops_stride), c->ops_rev.cap)));
-    HIP_TRY(c->nops.need((size_t)chunk));
-    HIP_TRY(c->offsets.need((size_t)chunk));
-    size_t tmp_bytes = 0;
-    HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, c->nops.p, c->offsets.p, (int)chunk, c->stream));
-    HIP_TRY(c->scan_tmp.need(tmp_bytes));
 
-    std::vector<uint32_t> h_nops, h_packed;
-    for (uint64_t first = 0; first < n; first += chunk) {
-        const uint32_t count = (uint32_t)std::min<uint64_t>(chunk, n - first);
+    // what each class needs, then one allocation for the largest of them
+    struct Plan {
+        uint32_t lo, members, max_m, trace_words, gpw, n_blocks, ops_stride, lds_stride;
+        Shape sh;
+        uint64_t trace_stride, chunk;
+        size_t lds;
+    };
+    std::vector<Plan> plans;
+    size_t need_trace = 0, need_ops = 0, need_slots = 0;
+    for (uint32_t k = 0; k < kClasses; k++) {
+        Plan pl{};
+        pl.lo = class_lo[k];
+        pl.members = class_lo[k + 1] - pl.lo;
+        if (pl.members == 0) continue;
+        uint32_t max_m = 0, max_n = 0;
+        for (uint32_t s0 = pl.lo; s0 < pl.lo + pl.members; s0++) {
+            max_m = std::max(max_m, query_len[order[s0]]);
+            max_n = std::max(max_n, text_len[order[s0]]);
+        }
+        pl.max_m = max_m;
+        // kernel shape for the longest query of the class; scratch per alignment slot
+        const uint32_t words = (max_m + 63u) / 64u;
+        pl.sh = pick_shape(words ? words : 1u, max_n);
+        pl.trace_words = std::max(std::max(words, 1u), pl.sh.group * (uint32_t)pl.sh.cw);   // (more than the words only for strips)
+        pl.gpw = 64u / pl.sh.group;
+        // checkpoints every 16 columns: (Pv, Mv) per word, plus one 32-bit word of horizontal deltas per word and block
+        pl.n_blocks = (max_n + 15u) / 16u + 1u;
+        const uint64_t n_entries = (uint64_t)pl.n_blocks * pl.gpw * pl.trace_words;
+        pl.trace_stride = n_entries * 2u + (n_entries + 1u) / 2u;               // 64-bit words per wave
+        pl.ops_stride = max_m + max_n + 1u;
+        pl.lds_stride = (max_n + 15u) / 16u * 4u + 4u;                          // the text as a 2-bit stream
+        pl.lds = 256 + (size_t)pl.gpw * pl.lds_stride;
+        if (pl.lds > 160 * 1024) return fail(BMV_ERR_UNSUPPORTED, "text windows of %u bases need %zu B of LDS", max_n, pl.lds);
+        if (pl.lds > 48 * 1024) HIP_TRY(bmhip::raise_dynamic_lds(reinterpret_cast<const void *>(pl.sh.fn), pl.lds));
+        const uint64_t per_slot = pl.trace_stride / pl.gpw * 8u + (uint64_t)pl.ops_stride * 4u;
+        uint64_t chunk = std::max<uint64_t>(pl.gpw, c->scratch_bytes / per_slot);
+        chunk = std::min<uint64_t>(chunk, (uint64_t)pl.gpw << 25);   // one wave per gpw alignments: waves * 64 threads < 2^32
+        chunk = std::min<uint64_t>(chunk / pl.gpw * pl.gpw, (uint64_t)pl.members);
+        pl.chunk = chunk ? chunk : pl.members;
+        need_trace = std::max(need_trace, (size_t)((pl.chunk + pl.gpw - 1u) / pl.gpw * pl.trace_stride));
+        need_ops = std::max(need_ops, (size_t)(pl.chunk * pl.ops_stride));
+        need_slots = std::max(need_slots, (size_t)pl.chunk);
+        plans.push_back(pl);
+    }
+    auto launch = [&](const Plan &pl, uint64_t first, uint32_t count, hipStream_t stream, uint64_t *trace, uint32_t *ops_rev,
+                      uint32_t *nops) {
         bmv::Job j{};
         j.genome = c->genome.p;
         j.reads = c->reads.p;
@@ -319,48 +383,137 @@ int bmv_align(bmv_ctx *c, const uint8_t *reads, uint64_t n_read_bytes, const uin
         j.text_rc = c->text_rc.p;
         j.query_start = c->query_start.p;
         j.query_len = c->query_len.p;
-        j.first = (uint32_t)first;
+        j.order = c->order.p + pl.lo + first;
         j.count = count;
-        j.trace = c->trace.p;
-        j.trace_stride = trace_stride;
-        j.trace_words = std::max(trace_words, sh.group * (uint32_t)sh.cw);
-        j.trace_blocks = n_blocks;
-        j.group = sh.group;
-        j.ops_rev = c->ops_rev.p;
-        j.ops_stride = ops_stride;
-        j.text_lds_stride = lds_stride;
+        j.trace = trace;
+        j.trace_stride = pl.trace_stride;
+        j.trace_words = pl.trace_words;
+        j.trace_blocks = pl.n_blocks;
+        j.group = pl.sh.group;
+        j.ops_rev = ops_rev;
+        j.ops_stride = pl.ops_stride;
+        j.text_lds_stride = pl.lds_stride;
         j.out_score = c->out_score.p;
         j.out_begin = c->out_begin.p;
-        j.out_nops = c->nops.p;
-        HIP_TRY(hipEventRecord(c->ev0, c->stream));
-        hipLaunchKernelGGL(sh.fn, dim3((count + gpw - 1u) / gpw), dim3(bmv::kWave), lds, c->stream, j);
-        HIP_TRY(hipGetLastError());
-        HIP_TRY(hipEventRecord(c->ev1, c->stream));
-        HIP_TRY(hipcub::DeviceScan::ExclusiveSum(c->scan_tmp.p, tmp_bytes, c->nops.p, c->offsets.p, (int)count, c->stream));
-        // total of the chunk = last offset + last count
-        uint32_t last_off = 0, last_n = 0;
-        HIP_TRY(hipMemcpyAsync(&last_off, c->offsets.p + (count - 1u), 4, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipMemcpyAsync(&last_n, c->nops.p + (count - 1u), 4, hipMemcpyDeviceToHost, c->stream));
+        j.out_nops = nops;
+        hipLaunchKernelGGL(pl.sh.fn, dim3((count + pl.gpw - 1u) / pl.gpw), dim3(bmv::kWave), pl.lds, stream, j);
+        return hipGetLastError();
+    };
+    // CIGARs of `count` slots (launch order) -> the host, through one exclusive sum and one gather per ops_stride
+    struct Piece {
+        const Plan *pl;
+        uint64_t first;         // within the class
+        uint32_t count, slot0;  // slots [slot0, slot0 + count) of nops / offsets
+        uint32_t *ops_rev;
+    };
+    auto collect = [&](const std::vector<Piece> &pieces, uint32_t slots) -> int {
+        size_t tmp_bytes = 0;
+        HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, c->nops.p, c->offsets.p, (int)slots, c->stream));
+        HIP_TRY(c->scan_tmp.need(tmp_bytes));
+        HIP_TRY(hipcub::DeviceScan::ExclusiveSum(c->scan_tmp.p, tmp_bytes, c->nops.p, c->offsets.p, (int)slots, c->stream));
+        uint32_t last_off = 0, last_n = 0;                      // total = last offset + last count
+        HIP_TRY(hipMemcpyAsync(&last_off, c->offsets.p + (slots - 1u), 4, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemcpyAsync(&last_n, c->nops.p + (slots - 1u), 4, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
         const uint32_t total = last_off + last_n;
         HIP_TRY(c->packed.need(with_headroom(total, c->packed.cap)));
-        hipLaunchKernelGGL(bmv::bmv_gather_kernel, dim3((count + 31u) / 32u), dim3(256), 0, c->stream, c->ops_rev.p, ops_stride,
-                           c->nops.p, c->offsets.p, count, c->packed.p);
-        HIP_TRY(hipGetLastError());
-        h_nops.resize(count);
+        for (const Piece &pc : pieces) {
+            hipLaunchKernelGGL(bmv::bmv_gather_kernel, dim3((pc.count + 31u) / 32u), dim3(256), 0, c->stream, pc.ops_rev,
+                               pc.pl->ops_stride, c->nops.p + pc.slot0, c->offsets.p + pc.slot0, pc.count, c->packed.p);
+            HIP_TRY(hipGetLastError());
+        }
+        h_nops.resize(slots);
         h_packed.resize(total);
-        HIP_TRY(hipMemcpyAsync(h_nops.data(), c->nops.p, (size_t)count * 4, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemcpyAsync(h_nops.data(), c->nops.p, (size_t)slots * 4, hipMemcpyDeviceToHost, c->stream));
         if (total) HIP_TRY(hipMemcpyAsync(h_packed.data(), c->packed.p, (size_t)total * 4, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
+        std::vector<uint32_t> &dst = one_class ? c->h_cigar : stash;
+        uint64_t at = dst.size();
+        for (const Piece &pc : pieces) {                        // in slot order, and the slots are theirs back to back
+            for (uint32_t s0 = 0; s0 < pc.count; s0++) {
+                const uint32_t len = h_nops[pc.slot0 + s0];
+                if (one_class) {                                // order is the identity: the CIGARs arrive in place
+                    c->h_offset[pc.first + s0] = at;
+                } else {                                        // kept aside in launch order until every length is known
+                    const uint32_t a = order[pc.pl->lo + pc.first + s0];
+                    cigar_len[a] = len;
+                    stash_at[a] = at;
+                }
+                at += len;
+            }
+        }
+        dst.insert(dst.end(), h_packed.begin(), h_packed.end());
+        return BMV_OK;
+    };
+
+    // Several classes that each fit the scratch budget in one piece, and together too: their kernels run side by side on a
+    // few streams -- a class of long reads is few waves that each run for tens of milliseconds, and the card is theirs
+    // alone otherwise.
+    size_t sum_trace = 0, sum_ops = 0;
+    bool whole = plans.size() > 1;
+    for (const Plan &pl : plans) {
+        whole = whole && pl.chunk == pl.members;
+        sum_trace += (size_t)((pl.members + pl.gpw - 1u) / pl.gpw * pl.trace_stride);
+        sum_ops += (size_t)pl.members * pl.ops_stride;
+    }
+    whole = whole && sum_trace * 8u + sum_ops * 4u <= c->scratch_bytes && !getenv("BMV_SERIAL_CLASSES");
+    if (whole) {
+        HIP_TRY(c->trace.need(with_headroom(sum_trace, c->trace.cap)));
+        HIP_TRY(c->ops_rev.need(with_headroom(sum_ops, c->ops_rev.cap)));
+        HIP_TRY(c->nops.need(with_headroom(n, c->nops.cap)));
+        HIP_TRY(c->offsets.need(with_headroom(n, c->offsets.cap)));
+        HIP_TRY(hipEventRecord(c->ev0, c->stream));             // the uploads above
+        std::vector<Piece> pieces;
+        size_t trace_at = 0, ops_at = 0;
+        for (size_t i = plans.size(); i-- > 0;) {               // the longest first: they take the longest
+            const Plan &pl = plans[i];
+            hipStream_t side = c->side[i % kSideStreams];
+            HIP_TRY(hipStreamWaitEvent(side, c->ev0, 0));
+            HIP_TRY(launch(pl, 0, pl.members, side, c->trace.p + trace_at, c->ops_rev.p + ops_at, c->nops.p + pl.lo));
+            pieces.push_back({&pl, 0, pl.members, pl.lo, c->ops_rev.p + ops_at});
+            trace_at += (size_t)((pl.members + pl.gpw - 1u) / pl.gpw * pl.trace_stride);
+            ops_at += (size_t)pl.members * pl.ops_stride;
+        }
+        for (uint32_t k = 0; k < kSideStreams; k++) {           // and the main stream goes on when all of them are done
+            HIP_TRY(hipEventRecord(c->side_done[k], c->side[k]));
+            HIP_TRY(hipStreamWaitEvent(c->stream, c->side_done[k], 0));
+        }
+        HIP_TRY(hipEventRecord(c->ev1, c->stream));
+        std::sort(pieces.begin(), pieces.end(), [](const Piece &x, const Piece &y) { return x.slot0 < y.slot0; });
+        if (int rc = collect(pieces, n)) return rc;
         float ms = 0.f;
         HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
         c->ms_kernels += ms;
-        uint64_t at = c->h_cigar.size();
-        for (uint32_t s = 0; s < count; s++) {
-            c->h_offset[first + s] = at;
-            at += h_nops[s];
+    } else {
+        HIP_TRY(c->trace.need(with_headroom(need_trace, c->trace.cap)));
+        HIP_TRY(c->ops_rev.need(with_headroom(need_ops, c->ops_rev.cap)));
+        HIP_TRY(c->nops.need(with_headroom(need_slots, c->nops.cap)));
+        HIP_TRY(c->offsets.need(with_headroom(need_slots, c->offsets.cap)));
+        for (const Plan &pl : plans) {
+            for (uint64_t first = 0; first < pl.members; first += pl.chunk) {
+                const uint32_t count = (uint32_t)std::min<uint64_t>(pl.chunk, pl.members - first);
+                HIP_TRY(hipEventRecord(c->ev0, c->stream));
+                HIP_TRY(launch(pl, first, count, c->stream, c->trace.p, c->ops_rev.p, c->nops.p));
+                HIP_TRY(hipEventRecord(c->ev1, c->stream));
+                if (int rc = collect({Piece{&pl, first, count, 0u, c->ops_rev.p}}, count)) return rc;
+                float ms = 0.f;
+                HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+                c->ms_kernels += ms;
+                if (getenv("BMV_LOG_CLASSES"))
+                    fprintf(stderr, "[bmv] class up to %u bases: %u of %u alignments, %u lanes x %d words, %.2f ms\n",
+                            pl.max_m, count, pl.members, pl.sh.group, pl.sh.cw, ms);
+            }
         }
-        c->h_cigar.insert(c->h_cigar.end(), h_packed.begin(), h_packed.end());
+    }
+    if (!one_class) {
+        uint64_t at = 0;
+        for (uint32_t a = 0; a < n; a++) {
+            c->h_offset[a] = at;
+            at += cigar_len[a];
+        }
+        c->h_cigar.resize(at);
+        for (uint32_t a = 0; a < n; a++)
+            std::copy_n(stash.data() + stash_at[a], cigar_len[a], c->h_cigar.data() + c->h_offset[a]);
     }
     c->h_offset[n] = c->h_cigar.size();
     HIP_TRY(hipMemcpy(c->h_score.data(), c->out_score.p, (size_t)n * 4, hipMemcpyDeviceToHost));

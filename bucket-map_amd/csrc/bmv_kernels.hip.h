@@ -49,7 +49,8 @@ struct Job {
     const uint8_t *text_rc;
     const uint64_t *query_start;
     const uint32_t *query_len;
-    uint32_t first, count;          // this launch handles alignments [first, first + count); slot = a - first
+    const uint32_t *order;          // this launch handles alignments order[0 .. count): the host's length classes
+    uint32_t count;
     uint64_t *trace;                // one region of trace_stride words per wave (64/GROUP alignments):
     uint64_t trace_stride;          //   checkpoints (Pv, Mv) [block][group][lane][c], then horizontal deltas
     uint32_t trace_words;           // words reserved per alignment and block in this batch (>= every W)
@@ -112,7 +113,7 @@ __global__ __launch_bounds__(kWave) void bmv_align_kernel(Job J) {
     const uint32_t lane = threadIdx.x, grp = lane / GROUP, gl = lane - grp * GROUP, lane0 = grp * GROUP;
     const uint32_t slot = blockIdx.x * GPW + grp;
     const bool have = grp < GPW && slot < J.count;              // (lanes past the last whole group are spare)
-    const uint32_t a = J.first + (have ? slot : 0u);
+    const uint32_t a = J.order[have ? slot : 0u];
     const uint32_t n = have ? J.text_len[a] : 0u, m = have ? J.query_len[a] : 0u;
     const uint32_t W = (m + 63u) >> 6;                         // words of the query
     const uint32_t strip_words = GROUP * CW;                    // words one pass over the text carries

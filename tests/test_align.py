@@ -263,11 +263,32 @@ def test_gpu_verifier_every_words_per_lane(max_m, n, monkeypatch):
 
 
 @pytest.mark.gpu
-def test_gpu_verifier_chunked_equals_one_pass():
+def test_gpu_verifier_length_classes(monkeypatch):
+    """A batch of mixed lengths is cut into length classes, each with its own kernel shape, run side by side on a few
+    streams when they fit the scratch budget together (BMV_SERIAL_CLASSES: one after the other; BMV_ONE_CLASS: no
+    classes, the longest query's shape for all): same results, and in the caller's order."""
+    from bucket_map_amd import verify
+    rng = np.random.default_rng(4242)
+    genome = rng.choice(list(b"ACGT"), 80_000).astype(np.uint8)
+    batch = _random_batch(rng, genome, 120, 6000, (0.03, 0.02, 0.02))      # 1 .. 94 words: eight classes
+    v = verify.Verifier()
+    v.load_genome(genome)
+    _compare(v, genome, batch, "classes side by side")
+    monkeypatch.setenv("BMV_SERIAL_CLASSES", "1")
+    _compare(v, genome, batch, "classes one after the other")
+    monkeypatch.delenv("BMV_SERIAL_CLASSES")
+    monkeypatch.setenv("BMV_ONE_CLASS", "1")
+    _compare(v, genome, batch, "one class")
+    v.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("max_m,n", [(300, 900), (3000, 150)])     # one length class; five of them
+def test_gpu_verifier_chunked_equals_one_pass(max_m, n):
     from bucket_map_amd import verify
     rng = np.random.default_rng(77)
     genome = rng.choice(list(b"ACGT"), 100_000).astype(np.uint8)
-    batch = _random_batch(rng, genome, 900, 300, (0.02, 0.005, 0.005))
+    batch = _random_batch(rng, genome, n, max_m, (0.02, 0.005, 0.005))
     os.environ["BMV_SCRATCH_MB"] = "2"               # a few dozen alignments per chunk
     try:
         small = verify.Verifier()

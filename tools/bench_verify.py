@@ -29,6 +29,8 @@ def main():
     ap.add_argument("--sub", type=float, default=0.002)
     ap.add_argument("--cpu-sample", type=int, default=2000)
     ap.add_argument("--repeat", type=int, default=3)
+    ap.add_argument("--mixed", type=int, default=0,
+                    help="query lengths log-uniform in [MIXED, --len] (forward strand only): a batch of several length classes")
     args = ap.parse_args()
 
     import torch  # noqa: F401  (HIP runtime first, as in bench.py)
@@ -40,7 +42,7 @@ def main():
     genome = rng.integers(0, 4, 64 << 20, dtype=np.uint8)
     genome = np.frombuffer(b"ACGT", np.uint8)[genome]
     start = rng.integers(0, len(genome) - width - 8, args.reads).astype(np.uint64)
-    rc = rng.integers(0, 2, args.reads).astype(np.uint8)
+    rc = rng.integers(0, 2, args.reads).astype(np.uint8) * (0 if args.mixed else 1)
     # reads: the window's bases from offset 1 (so begin = 1), substitutions only + strand flips, built vectorised
     idx = start[:, None] + 1 + np.arange(m, dtype=np.uint64)[None, :]
     reads = genome[idx]
@@ -54,6 +56,9 @@ def main():
     qs = (np.arange(args.reads, dtype=np.uint64) * m)
     ql = np.full(args.reads, m, np.uint32)
     tl = np.full(args.reads, width, np.uint32)
+    if args.mixed:                                     # each read keeps its first ql bases
+        ql = np.exp(rng.uniform(np.log(args.mixed), np.log(m), args.reads)).astype(np.uint32)
+        tl = (ql + 1 + (np.float32(args.indel_rate) * ql.astype(np.float32)).astype(np.uint32)).astype(np.uint32)
 
     v = verify.Verifier()
     v.load_genome(genome)
@@ -76,7 +81,7 @@ def main():
                 np.array_equal(off[: ns + 1], o_ref) and np.array_equal(cg[: int(o_ref[ns])], c_ref))
     print(json.dumps({
         "metric": "verified alignments/s (device kernels)", "value": args.reads / (best_ms * 1e-3), "unit": "alignments/s",
-        "config": {"alignments": args.reads, "query_len": m, "text_len": width},
+        "config": {"alignments": args.reads, "query_len": m, "text_len": width, "mixed_from": args.mixed},
         "ms_kernels": best_ms, "cell_updates_per_s": cells / (best_ms * 1e-3), "wall_s_host_buffers": best_wall,
         "mean_edits": float(-score.mean()), "cigar_entries": int(len(cg)),
         "cpu_baseline": {"value": ns / cpu_s, "unit": "alignments/s", "cores": 1, "kind": "port", "sample": f"first {ns} alignments"},
