@@ -15,6 +15,7 @@
 
 #include <iostream>
 #include <memory>
+#include <thread>
 
 // Defined per build: the product links make_mapper_gpu.cpp (MI355X filter + MI355X locator scan).
 std::unique_ptr<bm::mapper> bm_make_mapper(const bm::cmd_arguments &args, unsigned int num_buckets, unsigned int fault);
@@ -23,6 +24,9 @@ std::unique_ptr<bm::offset_scanner> bm_make_scanner(const bm::cmd_arguments &arg
 std::unique_ptr<bm::alignment_verifier> bm_make_verifier(const bm::cmd_arguments &args);
 // --gpu-index: fills ix with the rows built on the device; false = not available in this build.
 bool bm_gpu_index(const bm::cmd_arguments &args, const bm::Genome &genome, unsigned int num_buckets, bm::QgramIndex &ix);
+// Whatever the build's devices need before their first use (HIP start-up and code objects: a third of a second), begun
+// on a thread of its own while the genome is read; errors are left for the real calls to report.  main() joins it.
+std::thread bm_warm_up(const bm::cmd_arguments &args);
 
 int main(int argc, char **argv) {
     bm::cmd_arguments args;
@@ -43,6 +47,12 @@ int main(int argc, char **argv) {
                      "Pass --genome (and optionally --bucket-len / --num-buckets).\n";
         return -1;
     }
+    struct joiner {
+        std::thread t;
+        ~joiner() {
+            if (t.joinable()) t.join();
+        }
+    } warm{bm_warm_up(args)};
     try {
         auto t_fa = std::chrono::steady_clock::now();
         bm::Genome genome = bm::read_fasta(args.genome_path.string());

@@ -8,6 +8,31 @@
 #include "gpu_q_gram_mapper.h"
 
 #include <memory>
+#include <thread>
+
+// HIP's start-up and the loading of the library's code objects take 0.2-0.4 s in a fresh process: a throw-away filter
+// context on every device of --gpus pays for them while main() reads the FASTA file (tools/init_probe.py).
+std::thread bm_warm_up(const bm::cmd_arguments &args) {
+    std::vector<int> devices = args.gpus.empty() ? std::vector<int>{0} : args.gpus;
+    std::sort(devices.begin(), devices.end());
+    devices.erase(std::unique(devices.begin(), devices.end()), devices.end());
+    return std::thread([devices] {
+        for (int d : devices) {
+            bmf_params p{};
+            p.num_buckets = 64;
+            p.q = 4;
+            p.k = 4;
+            p.num_samples = 1;
+            p.num_fault = 1;
+            p.max_candidates = 30;
+            p.read_len = 32;
+            p.num_segment_samples = 5;
+            p.device = d;
+            bmf_ctx *ctx = nullptr;
+            if (bmf_create(&p, &ctx) == BMF_OK) bmf_destroy(ctx);
+        }
+    });
+}
 
 std::unique_ptr<bm::mapper> bm_make_mapper(const bm::cmd_arguments &args, unsigned int num_buckets, unsigned int fault) {
     return std::make_unique<bm::gpu_q_gram_mapper>(num_buckets, args.bucket_len, args.max_read_length,
