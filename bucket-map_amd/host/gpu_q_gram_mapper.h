@@ -33,6 +33,10 @@ class batched_mapper : public mapper {
 protected:
     unsigned int num_buckets_, read_length_, num_segment_samples_, max_candidates_;
     size_t batch_reads_ = 1u << 18;   // reads per batch: small enough to overlap parsing with the devices
+    size_t batch_bytes_ = 32u << 20;  // ... and bases per batch (BM_BATCH_MB): 100 000 reads of 300 bp, 3 000 of 10 kbp.  The
+                                      // first batch leaves early and the staging buffers stay small: `mapper::map` for 1 M x 300 bp
+                                      // 0.36 s at 96 MB, 0.18-0.27 s at 32 MB, 0.31 s at 16 MB (tools/e2e_cli.py, BM_LOG_BATCHES=1)
+    bool log_batches_ = std::getenv("BM_LOG_BATCHES") != nullptr;   // one stderr line per batch: when it went out, how long it took
 
     // query_sequence for n windows (views into bases/quals); counts: 2 per window (read as-is, reverse complement),
     // ids: the candidate lists back to back in that order (resized by the callee).  Returns false on failure
@@ -58,8 +62,9 @@ private:
 
     void slot_reserve(Slot &s, size_t need) {
         if (need <= s.cap) return;
-        // first allocation: room for a whole batch of reads of the nominal length (one page-locking call)
-        size_t cap = s.cap ? s.cap : std::max<size_t>(1u << 20, batch_reads_ * static_cast<size_t>(read_length_ + 8));
+        // first allocation: room for a whole batch (one allocation: growing a page-locked buffer by doubling cost a
+        // 10-kbp batch half a second); more only for a single read longer than a batch
+        size_t cap = s.cap ? s.cap : std::max<size_t>(1u << 20, std::min(batch_bytes_, batch_reads_ * static_cast<size_t>(read_length_ + 8)));
         while (cap < need) cap *= 2;
         uint8_t *b = host_alloc(cap), *q = b ? host_alloc(cap) : nullptr;
         if (!b || !q) {
@@ -83,6 +88,7 @@ public:
         : num_buckets_(num_buckets), read_length_(read_len), num_segment_samples_(num_segment_samples),
           max_candidates_(num_candidate_buckets) {
         if (const char *e = std::getenv("BM_BATCH_READS")) batch_reads_ = std::max<size_t>(1, std::strtoull(e, nullptr, 10));
+        if (const char *e = std::getenv("BM_BATCH_MB")) batch_bytes_ = std::max<size_t>(1, std::strtoull(e, nullptr, 10)) << 20;
     }
 
     // q_gram_mapper::map (q_gram_mapper.h:483-557)
@@ -110,7 +116,12 @@ public:
                     // q_gram_mapper.h:389-393 (printed once per query in the reference; once per batch here)
                     std::cerr << "[ERROR]\t\tThe q-gram index is empty. Cannot accept query.\n";
                 } else {
+                    const auto q0 = std::chrono::steady_clock::now();
                     s.ok = query_windows(s.bases, s.quals, s.n_bytes, s.win_start.data(), s.win_len.data(), n, s.counts.data(), s.ids);
+                    if (log_batches_)
+                        std::cerr << "[bm] batch of " << s.n_reads << " reads, " << n << " windows, " << s.n_bytes << " bases: filter "
+                                  << std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - q0).count()
+                                  << " ms, " << std::chrono::duration<float, std::milli>(q0 - t0).count() << " ms after map() began\n";
                 }
             } catch (const std::exception &e) {
                 std::cerr << "[ERROR]\t\t" << e.what() << "\n";
@@ -156,9 +167,10 @@ public:
 
         try {
             for_each_fastq(sequence_file.string(), [&](const FastqRecord &rec) {
+                const uint32_t len = static_cast<uint32_t>(rec.seq.size());
+                if (slots[cur].n_reads && slots[cur].n_bytes + len > batch_bytes_) submit();   // the batch is full by bytes
                 Slot &s = slots[cur];
                 if (s.n_reads == 0) s.first_read = num_records;
-                const uint32_t len = static_cast<uint32_t>(rec.seq.size());
                 slot_reserve(s, s.n_bytes + len);
                 std::memcpy(s.bases + s.n_bytes, rec.seq.data(), len);
                 std::memcpy(s.quals + s.n_bytes, rec.qual.data(), len);
@@ -288,12 +300,20 @@ class gpu_q_gram_mapper : public batched_mapper {
 
 protected:
     bool index_loaded() const override { return loaded_; }
-    // pinned staging: the H2D copies of bmf_map_windows then run at link speed
+    // Staging: ordinary memory.  bmf_map_windows_compact moves the reads in pieces through page-locked buffers of its own,
+    // at the same speed from either kind of source (bench.py, pcie_inclusive: 58.0 ms page-locked, 58.1 ms pageable),
+    // and page-locking four batch-sized buffers cost the tool more than it could ever return.  BM_PINNED_STAGING=1: the
+    // round-1 behaviour.
+    bool pinned_staging_ = std::getenv("BM_PINNED_STAGING") != nullptr;
     uint8_t *host_alloc(size_t bytes) override {
+        if (!pinned_staging_) return batched_mapper::host_alloc(bytes);
         void *p = nullptr;
         return bmf_pinned_alloc(bytes, &p) == BMF_OK ? static_cast<uint8_t *>(p) : nullptr;
     }
-    void host_free(uint8_t *p) override { bmf_pinned_free(p); }
+    void host_free(uint8_t *p) override {
+        if (!pinned_staging_) return batched_mapper::host_free(p);
+        bmf_pinned_free(p);
+    }
 
     bool query_windows(const uint8_t *bases, const uint8_t *quals, uint64_t n_bytes, const uint64_t *win_start,
                        const uint32_t *win_len, uint32_t n, uint32_t *counts, std::vector<uint32_t> &ids) override {

@@ -79,7 +79,7 @@ r = subprocess.run([map_exe, *common, "-q", "reads.fastq", "-o", "out.sam", *arg
                    capture_output=True, text=True)
 say(f"[e2e] map ({os.path.basename(map_exe)} {args.extra}): exit {r.returncode}, {time.perf_counter() - t:.1f} s wall")
 for line in r.stderr.splitlines():
-    if "[BENCHMARK]" in line or "[ERROR]" in line:
+    if "[BENCHMARK]" in line or "[ERROR]" in line or line.startswith(("[bm]", "[bmv]")):
         say("    " + line)
 truth = [l.split() for l in open(os.path.join(args.dir, "reads.position_ground_truth"))]
 names = [g.record_id(i).split(" ")[0] for i in range(g.n_records)]
