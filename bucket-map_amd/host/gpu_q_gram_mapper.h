@@ -27,7 +27,7 @@ namespace bm {
 // The host half of q_gram_mapper::map, independent of where query_sequence runs.
 //
 // Two batch slots: while the devices work on one batch, the next one is parsed from the FASTQ file into
-// the other (staging buffers come from host_alloc, pinned memory in the GPU mapper).  Results are
+// the other (staging buffers come from host_alloc; a batch is at most batch_reads_ reads and batch_bytes_ bases).  Results are
 // scattered strictly in batch order, so the per-bucket lists keep the reference's (read, window) order.
 class batched_mapper : public mapper {
 protected:
