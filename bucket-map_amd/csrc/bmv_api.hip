@@ -366,7 +366,12 @@ int bmv_align(bmv_ctx *c, const uint8_t *reads, uint64_t n_read_bytes, const uin
         uint64_t chunk = std::max<uint64_t>(pl.gpw, c->scratch_bytes / per_slot);
         chunk = std::min<uint64_t>(chunk, (uint64_t)pl.gpw << 25);   // one wave per gpw alignments: waves * 64 threads < 2^32
         chunk = std::min<uint64_t>(chunk / pl.gpw * pl.gpw, (uint64_t)pl.members);
-        pl.chunk = chunk ? chunk : pl.members;
+        if (chunk == 0) chunk = pl.members;
+        // pieces of equal size: 40 000 alignments under a limit of 31 000 are 2 x 20 000, not 31 000 + 9 000 (a piece's
+        // last waves run on a card that is emptying, whatever its size)
+        const uint64_t n_pieces = (pl.members + chunk - 1u) / chunk;
+        const uint64_t even = ((pl.members + n_pieces - 1u) / n_pieces + pl.gpw - 1u) / pl.gpw * pl.gpw;
+        pl.chunk = std::min(chunk, even);
         need_trace = std::max(need_trace, (size_t)((pl.chunk + pl.gpw - 1u) / pl.gpw * pl.trace_stride));
         need_ops = std::max(need_ops, (size_t)(pl.chunk * pl.ops_stride));
         need_slots = std::max(need_slots, (size_t)pl.chunk);
