@@ -470,67 +470,110 @@ private:
     // the window is clipped to start at the bucket's first base.
     unsigned int write_verified(const std::string &sequence_file, const std::vector<std::vector<locate_t>> &locate_res,
                                 const sam_header &h, sam_text &sam, unsigned int quality_threshold, unsigned int &read_id) {
+        // Two blocks of reads: while the verifier works on one (a thread of its own), the records of the one before are
+        // written and the next is read from the file.
         struct held { std::string id, seq, qual; uint64_t start; };
-        std::vector<held> block;
-        std::vector<uint8_t> bases;
-        std::vector<uint64_t> text_start, query_start, cigar_offset;
-        std::vector<uint32_t> text_len, query_len, begin, cigar;
-        std::vector<uint8_t> text_rc;
-        std::vector<int32_t> score;
-        unsigned int mapped_locations = 0, first_read = 0;
-        const size_t block_reads = 1u << 17, block_bases = 64u << 20;
-        auto flush = [&]() {
-            if (!text_start.empty())
-                _v->align(bases.data(), bases.size(), text_start.data(), text_len.data(), text_rc.data(), query_start.data(),
-                          query_len.data(), static_cast<uint32_t>(text_start.size()), score, begin, cigar_offset, cigar);
+        struct Block {
+            std::vector<held> reads;
+            std::vector<uint8_t> bases;
+            std::vector<uint64_t> text_start, query_start, cigar_offset;
+            std::vector<uint32_t> text_len, query_len, begin, cigar;
+            std::vector<uint8_t> text_rc;
+            std::vector<int32_t> score;
+            unsigned int first_read = 0;
+            std::exception_ptr failed;
+        } blocks[2];
+        unsigned int mapped_locations = 0;
+        size_t block_reads = 1u << 17;
+        const size_t block_bases = 64u << 20;
+        if (const char *e = std::getenv("BM_VERIFY_BLOCK_READS")) block_reads = std::max<size_t>(1, std::strtoull(e, nullptr, 10));   // tests
+        int cur = 0, in_flight = -1, to_write = -1;
+        blocks[0].first_read = read_id;
+        std::thread worker;
+        auto align = [&](Block &b) {                            // on the worker thread
+            try {
+                if (!b.text_start.empty())
+                    _v->align(b.bases.data(), b.bases.size(), b.text_start.data(), b.text_len.data(), b.text_rc.data(),
+                              b.query_start.data(), b.query_len.data(), static_cast<uint32_t>(b.text_start.size()), b.score, b.begin,
+                              b.cigar_offset, b.cigar);
+            } catch (...) {
+                b.failed = std::current_exception();
+            }
+        };
+        auto write = [&](Block &b) {
+            if (b.failed) std::rethrow_exception(b.failed);
             size_t a = 0;
             std::string cg;
-            for (size_t r = 0; r < block.size(); r++) {
-                for (auto &[bucket_id, offset, segment_offset, votes, is_original] : locate_res[first_read + r]) {
+            for (size_t r = 0; r < b.reads.size(); r++) {
+                for (auto &[bucket_id, offset, segment_offset, votes, is_original] : locate_res[b.first_read + r]) {
                     (void)segment_offset; (void)votes;
-                    const unsigned int wrapped = 60u + static_cast<unsigned int>(score[a]);          // :570
+                    const unsigned int wrapped = 60u + static_cast<unsigned int>(b.score[a]);        // :570
                     const size_t map_qual = wrapped;
                     if (!(map_qual < quality_threshold)) {                                            // :571-573
                         const int clipped = offset < 0 ? 0 : offset;
-                        const size_t ref_offset = static_cast<size_t>(begin[a]) + h.bucket_offsets[bucket_id] + clipped;   // :576
+                        const size_t ref_offset = static_cast<size_t>(b.begin[a]) + h.bucket_offsets[bucket_id] + clipped;   // :576
                         cg.clear();
-                        for (uint64_t x = cigar_offset[a]; x < cigar_offset[a + 1]; x++) {
-                            cg += std::to_string(cigar[x] >> 4);
-                            cg += "MID"[cigar[x] & 15u];
+                        for (uint64_t x = b.cigar_offset[a]; x < b.cigar_offset[a + 1]; x++) {
+                            cg += std::to_string(b.cigar[x] >> 4);
+                            cg += "MID"[b.cigar[x] & 15u];
                         }
                         if (cg.empty()) cg = "*";
-                        sam.record(block[r].id, is_original ? 0 : 16, h.bucket_name[bucket_id], ref_offset + 1,
-                                   static_cast<uint8_t>(map_qual), cg, block[r].seq, block[r].qual);
+                        sam.record(b.reads[r].id, is_original ? 0 : 16, h.bucket_name[bucket_id], ref_offset + 1,
+                                   static_cast<uint8_t>(map_qual), cg, b.reads[r].seq, b.reads[r].qual);
                         mapped_locations++;
                     }
                     a++;
                 }
             }
-            first_read += static_cast<unsigned int>(block.size());
-            block.clear(); bases.clear();
-            text_start.clear(); text_len.clear(); text_rc.clear(); query_start.clear(); query_len.clear();
+            b.reads.clear(); b.bases.clear();
+            b.text_start.clear(); b.text_len.clear(); b.text_rc.clear(); b.query_start.clear(); b.query_len.clear();
         };
-        for_each_fastq(sequence_file, [&](const FastqRecord &rec) {
-            const size_t len = rec.seq.size();
-            block.push_back({std::string(rec.id), std::string(), std::string(rec.qual), bases.size()});
-            append_dna4(block.back().seq, rec.seq);
-            bases.insert(bases.end(), rec.seq.begin(), rec.seq.end());
-            for (auto &[bucket_id, offset, segment_offset, votes, is_original] : locate_res[read_id]) {
-                (void)segment_offset; (void)votes;
-                const size_t clipped = offset < 0 ? 0 : static_cast<size_t>(offset);
-                const size_t bucket_size = blen_[bucket_id];
-                const size_t width = std::min(len + 1 + static_cast<size_t>(allowed_indel_rate * len),   // :550
-                                              bucket_size - std::min(clipped, bucket_size));
-                text_start.push_back(bstart_[bucket_id] + std::min(clipped, bucket_size));
-                text_len.push_back(static_cast<uint32_t>(width));
-                text_rc.push_back(is_original ? 0 : 1);                                                 // :563-567
-                query_start.push_back(block.back().start);
-                query_len.push_back(static_cast<uint32_t>(len));
+        // the block just filled goes to the verifier as soon as the one before has left it; that one's records are written
+        // while the verifier works
+        auto flush = [&]() {
+            if (in_flight >= 0) {
+                worker.join();
+                to_write = in_flight;
             }
-            read_id++;
-            if (block.size() >= block_reads || bases.size() >= block_bases) flush();
-        });
-        flush();
+            in_flight = cur;
+            worker = std::thread(align, std::ref(blocks[cur]));
+            cur ^= 1;
+            if (to_write >= 0) {
+                write(blocks[to_write]);
+                to_write = -1;
+            }
+            blocks[cur].first_read = read_id;
+        };
+        try {
+            for_each_fastq(sequence_file, [&](const FastqRecord &rec) {
+                Block &b = blocks[cur];
+                const size_t len = rec.seq.size();
+                b.reads.push_back({std::string(rec.id), std::string(), std::string(rec.qual), b.bases.size()});
+                append_dna4(b.reads.back().seq, rec.seq);
+                b.bases.insert(b.bases.end(), rec.seq.begin(), rec.seq.end());
+                for (auto &[bucket_id, offset, segment_offset, votes, is_original] : locate_res[read_id]) {
+                    (void)segment_offset; (void)votes;
+                    const size_t clipped = offset < 0 ? 0 : static_cast<size_t>(offset);
+                    const size_t bucket_size = blen_[bucket_id];
+                    const size_t width = std::min(len + 1 + static_cast<size_t>(allowed_indel_rate * len),   // :550
+                                                  bucket_size - std::min(clipped, bucket_size));
+                    b.text_start.push_back(bstart_[bucket_id] + std::min(clipped, bucket_size));
+                    b.text_len.push_back(static_cast<uint32_t>(width));
+                    b.text_rc.push_back(is_original ? 0 : 1);                                               // :563-567
+                    b.query_start.push_back(b.reads.back().start);
+                    b.query_len.push_back(static_cast<uint32_t>(len));
+                }
+                read_id++;
+                if (b.reads.size() >= block_reads || b.bases.size() >= block_bases) flush();
+            });
+            flush();                                            // the last, possibly empty, block
+            worker.join();
+            in_flight = -1;
+            write(blocks[cur ^ 1]);
+        } catch (...) {
+            if (worker.joinable()) worker.join();
+            throw;
+        }
         return mapped_locations;
     }
 };

@@ -42,13 +42,14 @@ def write_inputs(golden, d):
             f.write(f"@{name}\n{seq}\n+\n{qual}\n")
 
 
-def run_tool(golden, which, backend, d, extra=()):
+def run_tool(golden, which, backend, d, extra=(), env=None):
     fl = golden["flags"]
     args = ["-i", "idx", "--genome", "g.fa", "--bucket-len", str(fl["bucket_len"]), "-r", str(fl["read_len"]),
             "-k", str(fl["q"]), "-l", str(fl["k"]), "-s", str(fl["S"]), "-e", str(fl["e"]), "-d", str(fl["d"]),
             "-b", str(fl["b"]), "-n", str(fl["n"]), "-p", str(fl["p"]), "-u", str(fl["u"]), "-f", "1",
             "-q", "reads.fastq", "-o", f"{which}_{backend}.sam", *extra]
-    r = subprocess.run([TOOLS[(which, backend)], *args], cwd=str(d), capture_output=True, text=True)
+    r = subprocess.run([TOOLS[(which, backend)], *args], cwd=str(d), capture_output=True, text=True,
+                       env=dict(os.environ, **(env or {})))
     assert r.returncode == 0, r.stderr
     sq, recs = [], []
     for line in open(d / f"{which}_{backend}.sam"):
@@ -101,6 +102,23 @@ def test_fixture_covers_the_order_sensitive_cases(golden):
 def test_oracle_backed_tool_equals_python_fixture(golden, tmp_path, which):
     write_inputs(golden, tmp_path)
     check(golden, which, *run_tool(golden, which, "oracle", tmp_path))
+
+
+@pytest.mark.parametrize("block_reads", ["1", "3", "7"])
+def test_verified_records_keep_their_order_across_blocks(golden, tmp_path, block_reads):
+    """bucketmap_align verifies a block of reads while it writes the records of the block before and reads the next one:
+    with blocks of 1, 3 and 7 reads the file is still the fixture's, record for record (batches of a few reads for the
+    mapper too)."""
+    write_inputs(golden, tmp_path)
+    check(golden, "bucketmap_align", *run_tool(golden, "bucketmap_align", "oracle", tmp_path,
+                                              env={"BM_VERIFY_BLOCK_READS": block_reads, "BM_BATCH_READS": "5"}))
+
+
+@pytest.mark.gpu
+def test_gpu_verified_records_keep_their_order_across_blocks(golden, tmp_path):
+    write_inputs(golden, tmp_path)
+    check(golden, "bucketmap_align", *run_tool(golden, "bucketmap_align", "gpu", tmp_path, extra=["--gpus", "0,0"],
+                                              env={"BM_VERIFY_BLOCK_READS": "4", "BM_BATCH_READS": "5"}))
 
 
 @pytest.mark.gpu
