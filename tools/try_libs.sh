@@ -1,7 +1,10 @@
 #!/bin/bash
-# Experiment helper: bench.py's pruned step under alternative builds of libbmf.so (bucket-map_amd/alt/*.so).
-#   bash tools/try_libs.sh
+# Experiment helper: bench.py's pruned step under alternative builds of libbmf.so (bucket-map_amd/alt/*.so), e.g.
+#   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -DBMF_RECOUNT_OCC=3 -c -o /tmp/bmf_api_occ3.o bucket-map_amd/csrc/bmf_api.hip
+#   hipcc --offload-arch=gfx950 -shared -o bucket-map_amd/alt/libbmf_occ3.so /tmp/bmf_api_occ3.o bucket-map_amd/csrc/bm[lv]_*.o
+#   gpurun -- 'bash tools/try_libs.sh'
 set -e
+shopt -s nullglob
 mkdir -p gpurun_out
 cp bucket-map_amd/libbmf.so /tmp/libbmf_main.so
 for lib in /tmp/libbmf_main.so bucket-map_amd/alt/*.so /tmp/libbmf_main.so; do
