@@ -355,7 +355,7 @@ int bmv_align(bmv_ctx *c, const uint8_t *reads, uint64_t n_read_bytes, const uin
         pl.trace_words = std::max(std::max(words, 1u), pl.sh.group * (uint32_t)pl.sh.cw);   // (more than the words only for strips)
         pl.gpw = 64u / pl.sh.group;
         // checkpoints every 16 columns: (Pv, Mv) per word, plus one 32-bit word of horizontal deltas per word and block
-        pl.n_blocks = (max_n + 15u) / 16u + 1u;
+        pl.n_blocks = (max_n + pl.sh.group + 15u) / 16u + 1u;     // blocks of 16 STEPS: the group's last lane is group - 1 steps behind
         const uint64_t n_entries = (uint64_t)pl.n_blocks * pl.gpw * pl.trace_words;
         pl.trace_stride = n_entries * 2u + (n_entries + 1u) / 2u;               // 64-bit words per wave
         pl.ops_stride = max_m + max_n + 1u;

@@ -210,21 +210,26 @@ __global__ __launch_bounds__(kWave) void bmv_align_kernel(Job J) {
             steps = other > steps ? other : steps;
         }
         int hout_prev = 0;
-        uint32_t habove = 0x55555555u;                          // deltas leaving the strip above, 16 columns at a time
+        uint32_t habove = 0x55555555u;                          // deltas leaving the strip above, 16 at a time
+        const uint32_t above_lane = GROUP - 1u;                 // the lane that held the strip above's last word (a full strip)
         for (uint32_t t = 1; t <= steps; t++) {
             // the delta that left lane l-1's last row a step ago: a DPP move down the whole wave by one lane (wave_shr:1), a
             // VALU operation -- __shfl_up is a round trip through the LDS crossbar, waited for at the head of every step
             int hin = __builtin_amdgcn_update_dpp(0, hout_prev, 0x138, 0xF, 0xF, false);
             const uint32_t j = t - gl;                          // 1-based text column of this lane
+            const uint32_t xt = (t - 1u) % kBlock;              // blocks are cut in TIME: the same for every lane of the wave
             if (gl < L && j >= 1u && j <= n && t >= gl + 1u) {
-                const uint32_t x = (j - 1u) % kBlock;
-                const uint32_t ch = (text[(j - 1u) / kBlock] >> (2u * x)) & 3u;
-                const bool block_end = x == kBlock - 1u || j == n;
+                const uint32_t ch = (text[(j - 1u) / kBlock] >> (2u * ((j - 1u) % kBlock))) & 3u;
                 if (gl == 0) {
                     // row 0 is all zeros (free leading text gaps); below the first strip the deltas come from
-                    // the last word of the strip above
-                    if (STRIPS && strip && x == 0) habove = hbuf[entry((j - 1u) / kBlock, w0 - 1u)];
-                    hin = (STRIPS && strip) ? (int)((habove >> (2u * x)) & 3u) - 1 : 0;
+                    // the last word of the strip above, which passed column j at its own step j + above_lane
+                    if (STRIPS && strip) {
+                        const uint32_t ta = j + above_lane - 1u;
+                        if (ta % kBlock == 0u || j == 1u) habove = hbuf[entry(ta / kBlock, w0 - 1u)];
+                        hin = (int)((habove >> (2u * (ta % kBlock))) & 3u) - 1;
+                    } else {
+                        hin = 0;
+                    }
                 }
 #pragma unroll
                 for (int c = 0; c < CW; c++) {
@@ -242,20 +247,28 @@ __global__ __launch_bounds__(kWave) void bmv_align_kernel(Job J) {
                             }
                         }
                         hin = hout;
-                        hacc[c] |= (uint32_t)(hout + 1) << (2u * x);
-                        if (block_end) {
-                            const uint32_t e = entry((j - 1u) / kBlock, w0 + w);
-                            hbuf[e] = hacc[c];
-                            hacc[c] = 0;
-                            if (j < n) {                        // state the next block starts from (j is a multiple of 16)
-                                uint64_t *ck = ckpt + (size_t)(e + GPW * TW) * 2u;
-                                ck[0] = pv[c];
-                                ck[1] = mv[c];
-                            }
-                        }
+                        hacc[c] |= (uint32_t)(hout + 1) << (2u * xt);
                     }
                 }
                 hout_prev = hin;
+            }
+            // End of a time block -- for the whole wave at once, a branch taken one step in 16 (cut by COLUMN, the lanes of
+            // a group, one column apart, reached their block ends one after the other and the wave stored something at every
+            // step): the horizontal deltas of the block and the vertical state the next one starts from.
+            if (xt == kBlock - 1u || t == steps) {
+                const uint32_t bt = (t - 1u) / kBlock;
+#pragma unroll
+                for (int c = 0; c < CW; c++) {
+                    const uint32_t w = gl * CW + c;
+                    if (gl < L && w < Ws) {
+                        const uint32_t e = entry(bt, w0 + w);
+                        hbuf[e] = hacc[c];
+                        uint64_t *ck = ckpt + (size_t)(e + GPW * TW) * 2u;
+                        ck[0] = pv[c];
+                        ck[1] = mv[c];
+                    }
+                    hacc[c] = 0;
+                }
             }
         }
         // the next strip (and the traceback) read what other lanes of this wave wrote: same wave, same L1,
@@ -281,8 +294,13 @@ __global__ __launch_bounds__(kWave) void bmv_align_kernel(Job J) {
     uint64_t db[kSlots], ub[kSlots];
 #pragma unroll
     for (int q = 0; q < kSlots; q++) db[q] = ub[q] = 0;
-    // checkpoint of (word w, block b): vertical state the block starts from, and the deltas entering the word
-    // = the deltas that left the word above (row 0 for the first word: all zero)
+    // Blocks are cut in time: word w sits on lane lane_of(w) and passes column j at step j + lane_of(w); block b of a word
+    // is its steps 16 b + 1 .. 16 b + 16.
+    auto lane_of = [&](uint32_t w) { return (STRIPS ? w % strip_words : w) / CW; };
+    // checkpoint of (word w, block b): vertical state the block starts from, and the deltas entering the word at the block's
+    // 16 steps = the deltas that left the word above at the same COLUMNS (row 0 for the first word: all zero).  The word
+    // above passed those columns at the same steps if it sits on the same lane, one step earlier on the lane before, and
+    // GROUP - 1 steps later if it is the last word of the strip above.
     struct Checkpoint {
         uint64_t pv, mv;
         uint32_t hw;
@@ -294,7 +312,19 @@ __global__ __launch_bounds__(kWave) void bmv_align_kernel(Job J) {
             k.pv = ck[0];
             k.mv = ck[1];
         }
-        if (w) k.hw = hbuf[entry(b, w - 1u)];
+        if (w) {
+            const uint32_t lw = lane_of(w), la = lane_of(w - 1u);
+            if (la == lw) {
+                k.hw = hbuf[entry(b, w - 1u)];
+            } else if (la + 1u == lw) {                         // entry x of this block = entry x - 1 of the word above's
+                const uint32_t lo = b ? hbuf[entry(b - 1u, w - 1u)] : 0u;
+                k.hw = (hbuf[entry(b, w - 1u)] << 2) | (lo >> 30);
+            } else {                                            // first word of a strip: entry x = entry x + (GROUP - 1) above
+                const uint32_t sh = (GROUP - 1u) % kBlock, q = (GROUP - 1u) / kBlock;
+                const uint32_t lo = hbuf[entry(b + q, w - 1u)], hi = hbuf[entry(b + q + 1u, w - 1u)];
+                k.hw = sh ? (lo >> (2u * sh)) | (hi << (32u - 2u * sh)) : lo;
+            }
+        }
         return k;
     };
     auto refill = [&](uint32_t w, uint32_t b, Checkpoint k) {
@@ -315,11 +345,16 @@ __global__ __launch_bounds__(kWave) void bmv_align_kernel(Job J) {
 #pragma unroll
             for (int r = 0; r < 4; r++) pm[r] = __ballot(rk == (uint32_t)r);
         }
-        const uint32_t tw = text[b];                            // the block's 16 text bases
+        // the block's 16 text bases: columns 16 b + 1 - lane_of(w) + x, out of two words of the 2-bit stream
+        const int32_t c0 = (int32_t)(b * kBlock) - (int32_t)lane_of(w);          // 0-based column of x = 0 (may be negative)
+        const int32_t tq = c0 >> 4;                             // floor
+        const uint32_t tsh = (uint32_t)(c0 & 15);
+        const uint32_t tlo = tq >= 0 ? text[tq] : 0u, thi = tq + 1 >= 0 ? text[tq + 1] : 0u;
+        const uint32_t tw = tsh ? (tlo >> (2u * tsh)) | (thi << (32u - 2u * tsh)) : tlo;
 #pragma unroll
         for (int x = 0; x < (int)kBlock; x++) {
-            const uint32_t col = b * kBlock + 1u + (uint32_t)x;
-            if (col <= n) {
+            const int32_t col = c0 + 1 + x;                     // 1-based
+            if (col >= 1 && col <= (int32_t)n) {
                 const uint32_t ch = (tw >> (2 * x)) & 3u;
                 const uint64_t eq0 = pick_mask(pm[0], pm[1], pm[2], pm[3], ch);
                 uint64_t ph, mh, d0;
@@ -342,10 +377,11 @@ __global__ __launch_bounds__(kWave) void bmv_align_kernel(Job J) {
     uint32_t nw = 0xFFFFFFFFu, nb = 0;
     Checkpoint next{0, 0, 0};
     while (__ballot(i > 0) != 0) {
-        uint32_t wc = 0, bc = 0;
+        uint32_t wc = 0, bc = 0, lc = 0;                        // word, time block of the cell, lane of the word
         if (i > 0 && j > 0) {
             wc = (i - 1u) >> 6;
-            bc = (j - 1u) / kBlock;
+            lc = lane_of(wc);
+            bc = (j + lc - 1u) / kBlock;
             refill(wc, bc, (wc == nw && bc == nb) ? next : load_checkpoint(wc, bc));
             if (bc > 0) {
                 nw = wc;
@@ -353,13 +389,13 @@ __global__ __launch_bounds__(kWave) void bmv_align_kernel(Job J) {
                 next = load_checkpoint(nw, nb);
             }
         }
-        while (i > 0 && (j == 0 || (((i - 1u) >> 6) == wc && (j - 1u) / kBlock == bc))) {
+        while (i > 0 && (j == 0 || (((i - 1u) >> 6) == wc && (j + lc - 1u) / kBlock == bc))) {
             uint32_t op;
             if (j == 0) {                                       // column 0: only the upper predecessor
                 op = 1;
                 i--;
             } else {
-                const uint32_t x = (j - 1u) % kBlock, held = x / kHold;
+                const uint32_t x = (j + lc - 1u) % kBlock, held = x / kHold;
                 uint64_t md = db[0], mu = ub[0];
 #pragma unroll
                 for (int q = 1; q < kSlots; q++) {
