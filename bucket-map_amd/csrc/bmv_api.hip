@@ -97,14 +97,14 @@ struct Shape {
 // A group is as many lanes as the longest query has words, over CW words per lane; the kernel variant fixes CW and how many
 // of the group's lanes hold the traceback's 16 pairs of trace words.  CW is chosen by what a wave then spends per
 // alignment: the cost of a column step at that CW (the table below: what a step pays once -- the neighbour lane's delta,
-// the text base, the loop -- is worth about 1.6 words' recurrences), times n + group - 1 steps (the skew), over the
+// the text base, the loop -- is worth about two words' recurrences), times n + group - 1 steps (the skew), over the
 // 64 / group alignments that share them.  A 5-kbp read (79 words) is 4 alignments of 16 lanes x 5 words per wave, not
-// one of 40 x 2; a 10-kbp read (157 words) is 2 of 32 x 5, not one of 40 x 4.
+// one of 40 x 2; a 10-kbp read (157 words) is 2 of 32 x 5, not one of 40 x 4; an 8-kbp read (125 words) 4 of 16 x 8.
 constexpr int kMaxCw = 8;
 // what one column step of a wave costs at CW words per lane, measured (ns of the whole card per wave and step,
-// tools/bench_verify_cw.sh; only the ratios matter): about 1.6 + CW words' recurrences up to CW = 4, more beyond, where
-// the registers a lane holds (13 per word) begin to cost waves per SIMD
-constexpr double kStepCost[kMaxCw + 1] = {0, 0.221, 0.300, 0.390, 0.475, 0.600, 0.660, 0.800, 0.950};
+// tools/bench_verify_cw.sh, profiles/r02/verify_shapes.txt; only the ratios matter): about 1.9 + CW words' recurrences --
+// what a step pays once (the neighbour lane's delta, the text base, the loop) is worth two words
+constexpr double kStepCost[kMaxCw + 1] = {0, 0.206, 0.290, 0.356, 0.440, 0.545, 0.645, 0.700, 0.810};
 constexpr uint32_t kStripsBeyond = 64u * kMaxCw;                 // words: longer queries go through in strips
 
 Shape pick_shape(uint32_t words, uint32_t max_n) {

@@ -23,14 +23,18 @@
 // delta 0, or mismatch with diagonal delta 1: ~(Eq ^ D0)) and "the upper predecessor is valid" (vertical delta
 // +1: Pv); when neither holds the left one must be.  Writing them for every cell is 16 B per word and column
 // -- 25 KB per 300x307 alignment, 28 MB per 10-kbp alignment -- and the stores, not the arithmetic, set the
-// kernel's time.  So the forward pass keeps only CHECKPOINTS: every kBlock = 16 columns the vertical state
-// (Pv, Mv) of each word, and for every column the horizontal delta that leaves each word (2 bits, 16 columns
+// kernel's time.  So the forward pass keeps only CHECKPOINTS: every kBlock = 16 STEPS the vertical state
+// (Pv, Mv) of each word, and for every step the horizontal delta that leaves each word (2 bits, 16 steps
 // per 32-bit word): 1.25 B per word and column.  The traceback walks from the LAST minimum of the bottom row,
-// trying diagonal, up, left in that order (include/bmv.h, tie rules 1-2); when it enters a (word, column
-// block) it recomputes that block's 16 column steps from the checkpoint -- the horizontal deltas entering
+// trying diagonal, up, left in that order (include/bmv.h, tie rules 1-2); when it enters a (word, block)
+// it recomputes that block's 16 steps from the checkpoint -- the horizontal deltas entering
 // the word are the stored ones of the word above, so one word is recomputed on its own -- and the lanes of
-// the group keep the 16 pairs of trace words in registers.  Run-length CIGAR entries are left in reverse;
-// bmv_gather_kernel reverses and packs them.
+// the group keep the 16 pairs of trace words in registers.  Blocks are cut in TIME, not by column: lane l is at column
+// t - l, so a block of a word on lane l is the 16 columns 16 b + 1 - l ..; every lane of the wave ends its block at the
+// same step and the wave stores once in 16 steps (cut by column, a few lanes of every group reached a block end at
+// every step, and the wave ran the store path at every step).  The deltas of the word above for a block's columns are
+// the same block's if that word sits on the same lane, shifted by one step if it sits on the lane before.
+// Run-length CIGAR entries are left in reverse; bmv_gather_kernel (bmv_api.hip) reverses and packs them.
 #pragma once
 
 #include <hip/hip_runtime.h>
