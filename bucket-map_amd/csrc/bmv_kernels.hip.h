@@ -77,21 +77,22 @@ __device__ __forceinline__ uint64_t shfl64(uint64_t v, int src_lane) {
 constexpr uint32_t kBlock = 16;   // columns between checkpoints = horizontal deltas per 32-bit word
 
 // One column step of one 64-row word (Myers 1999 in Hyyro's block form).  eq0: rows that match the text
-// base; hin: horizontal delta entering the word from above (-1, 0, +1).  Updates (pv, mv) to this column,
-// returns the delta leaving the word; ph / mh are the horizontal deltas of the rows BEFORE the shift (bit r =
+// base; hd: the horizontal delta entering the word from above as a 2-bit code (0: 0, 1: +1, 2: -1 -- bit 0 "plus", bit 1
+// "minus": the form the recurrence wants, and the form the trace stores).  Updates (pv, mv) to this column,
+// returns the code of the delta leaving the word; ph / mh are the horizontal deltas of the rows BEFORE the shift (bit r =
 // row r of the word), d0 the rows whose diagonal delta is 0.
-__device__ __forceinline__ int myers_step(uint64_t eq0, int hin, uint64_t &pv, uint64_t &mv, uint64_t &ph, uint64_t &mh,
-                                          uint64_t &d0) {
-    const uint64_t hin_neg = hin < 0 ? 1ull : 0ull;
+__device__ __forceinline__ uint32_t myers_step(uint64_t eq0, uint32_t hd, uint64_t &pv, uint64_t &mv, uint64_t &ph, uint64_t &mh,
+                                               uint64_t &d0) {
+    const uint64_t h_plus = hd & 1u, h_minus = hd >> 1;
     const uint64_t xv = eq0 | mv;
-    const uint64_t eq = eq0 | hin_neg;
+    const uint64_t eq = eq0 | h_minus;
     const uint64_t xh = (((eq & pv) + pv) ^ pv) | eq;
     ph = mv | ~(xh | pv);
     mh = pv & xh;
     d0 = xh | mv;
-    const int hout = (int)(ph >> 63) - (int)(mh >> 63);
-    const uint64_t phs = (ph << 1) | (hin > 0 ? 1ull : 0ull);
-    const uint64_t mhs = (mh << 1) | hin_neg;
+    const uint32_t hout = (uint32_t)(ph >> 63) | ((uint32_t)(mh >> 63) << 1);
+    const uint64_t phs = (ph << 1) | h_plus;
+    const uint64_t mhs = (mh << 1) | h_minus;
     pv = mhs | ~(xv | phs);
     mv = phs & xv;
     return hout;
@@ -213,13 +214,13 @@ __global__ __launch_bounds__(kWave) void bmv_align_kernel(Job J) {
             const uint32_t other = (uint32_t)__shfl_xor((int)steps, o, kWave);
             steps = other > steps ? other : steps;
         }
-        int hout_prev = 0;
-        uint32_t habove = 0x55555555u;                          // deltas leaving the strip above, 16 at a time
+        uint32_t hout_prev = 0;
+        uint32_t habove = 0u;                                   // deltas leaving the strip above, 16 at a time
         const uint32_t above_lane = GROUP - 1u;                 // the lane that held the strip above's last word (a full strip)
         for (uint32_t t = 1; t <= steps; t++) {
             // the delta that left lane l-1's last row a step ago: a DPP move down the whole wave by one lane (wave_shr:1), a
             // VALU operation -- __shfl_up is a round trip through the LDS crossbar, waited for at the head of every step
-            int hin = __builtin_amdgcn_update_dpp(0, hout_prev, 0x138, 0xF, 0xF, false);
+            uint32_t hin = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hout_prev, 0x138, 0xF, 0xF, false);
             const uint32_t j = t - gl;                          // 1-based text column of this lane
             const uint32_t xt = (t - 1u) % kBlock;              // blocks are cut in TIME: the same for every lane of the wave
             if (gl < L && j >= 1u && j <= n && t >= gl + 1u) {
@@ -230,7 +231,7 @@ __global__ __launch_bounds__(kWave) void bmv_align_kernel(Job J) {
                     if (STRIPS && strip) {
                         const uint32_t ta = j + above_lane - 1u;
                         if (ta % kBlock == 0u || j == 1u) habove = hbuf[entry(ta / kBlock, w0 - 1u)];
-                        hin = (int)((habove >> (2u * (ta % kBlock))) & 3u) - 1;
+                        hin = (habove >> (2u * (ta % kBlock))) & 3u;
                     } else {
                         hin = 0;
                     }
@@ -241,7 +242,7 @@ __global__ __launch_bounds__(kWave) void bmv_align_kernel(Job J) {
                     if (w < Ws) {
                         const uint64_t eq0 = pick_mask(peq[0][c], peq[1][c], peq[2][c], peq[3][c], ch);
                         uint64_t ph, mh, d0;
-                        const int hout = myers_step(eq0, hin, pv[c], mv[c], ph, mh, d0);
+                        const uint32_t hout = myers_step(eq0, hin, pv[c], mv[c], ph, mh, d0);
                         if ((uint32_t)c == last_c && w0 + w == last_word) {
                             if (CW > 1) asm volatile("" ::: "memory");   // keeps this a branch: not to be if-converted
                             score += (int32_t)((ph >> last_bit) & 1ull) - (int32_t)((mh >> last_bit) & 1ull);
@@ -251,7 +252,7 @@ __global__ __launch_bounds__(kWave) void bmv_align_kernel(Job J) {
                             }
                         }
                         hin = hout;
-                        hacc[c] |= (uint32_t)(hout + 1) << (2u * xt);
+                        hacc[c] |= hout << (2u * xt);
                     }
                 }
                 hout_prev = hin;
@@ -310,7 +311,7 @@ __global__ __launch_bounds__(kWave) void bmv_align_kernel(Job J) {
         uint32_t hw;
     };
     auto load_checkpoint = [&](uint32_t w, uint32_t b) {
-        Checkpoint k{~0ull, 0ull, 0x55555555u};                 // block 0 starts from column 0: H[i][0] = i
+        Checkpoint k{~0ull, 0ull, 0u};                          // block 0 starts from column 0: H[i][0] = i; row 0: deltas 0
         if (b) {
             const uint64_t *ck = ckpt + (size_t)entry(b, w) * 2u;
             k.pv = ck[0];
@@ -362,7 +363,7 @@ __global__ __launch_bounds__(kWave) void bmv_align_kernel(Job J) {
                 const uint32_t ch = (tw >> (2 * x)) & 3u;
                 const uint64_t eq0 = pick_mask(pm[0], pm[1], pm[2], pm[3], ch);
                 uint64_t ph, mh, d0;
-                myers_step(eq0, (int)((k.hw >> (2 * x)) & 3u) - 1, k.pv, k.mv, ph, mh, d0);
+                myers_step(eq0, (k.hw >> (2 * x)) & 3u, k.pv, k.mv, ph, mh, d0);
                 if (gl == (uint32_t)x % kHold) {
                     db[x / (int)kHold] = ~(eq0 ^ d0);           // diagonal predecessor valid
                     ub[x / (int)kHold] = k.pv;                  // upper predecessor valid
