@@ -11,6 +11,15 @@ extern template __global__ void bmv_align_kernel<1, 6, false>(Job);
 extern template __global__ void bmv_align_kernel<1, 7, false>(Job);
 extern template __global__ void bmv_align_kernel<1, 8, false>(Job);
 extern template __global__ void bmv_align_kernel<1, 6, true>(Job);
+extern template __global__ void bmv_align_kernel<2, 2, false>(Job);
+extern template __global__ void bmv_align_kernel<2, 3, false>(Job);
+extern template __global__ void bmv_align_kernel<2, 4, false>(Job);
+extern template __global__ void bmv_align_kernel<2, 5, false>(Job);
+extern template __global__ void bmv_align_kernel<4, 2, false>(Job);
+extern template __global__ void bmv_align_kernel<4, 3, false>(Job);
+extern template __global__ void bmv_align_kernel<4, 4, false>(Job);
+extern template __global__ void bmv_align_kernel<8, 2, false>(Job);
+extern template __global__ void bmv_align_kernel<8, 3, false>(Job);
 extern template __global__ void bmv_align_kernel<1, 8, true>(Job);
 
 // CIGAR entries of one chunk, reversed into reading order at their final offsets.
@@ -122,7 +131,10 @@ Shape pick_shape(uint32_t words, uint32_t max_n) {
     const int forced = env ? atoi(env) : 0;
     for (int c = 1; c <= kMaxCw; c++) {
         const uint32_t g = (words + (uint32_t)c - 1u) / (uint32_t)c;
-        if (g > 64u || (c > 1 && g < 16u)) continue;             // (the CW > 1 variants keep one trace pair per lane)
+        // (a group's lanes share the traceback's 16 trace-word pairs: the CW > 1 variants exist for 1 pair per lane, for 2
+        // -- groups of 8..15 lanes, CW <= 5 --, for 4 -- 4..7 lanes, CW <= 4 -- and for 8 -- 2..3 lanes, CW <= 3)
+        const int max_cw = g >= 16u ? kMaxCw : (g >= 8u ? 5 : (g >= 4u ? 4 : (g >= 2u ? 3 : 1)));
+        if (g > 64u || c > max_cw) continue;
         if (forced == c) {
             cw = c;
             break;
@@ -134,6 +146,14 @@ Shape pick_shape(uint32_t words, uint32_t max_n) {
         }
     }
     const uint32_t g = std::max(1u, (words + (uint32_t)cw - 1u) / (uint32_t)cw);
+    static const align_fn two_pairs[6] = {nullptr, nullptr, bmv::bmv_align_kernel<2, 2, false>, bmv::bmv_align_kernel<2, 3, false>,
+                                          bmv::bmv_align_kernel<2, 4, false>, bmv::bmv_align_kernel<2, 5, false>};
+    static const align_fn four_pairs[5] = {nullptr, nullptr, bmv::bmv_align_kernel<4, 2, false>, bmv::bmv_align_kernel<4, 3, false>,
+                                           bmv::bmv_align_kernel<4, 4, false>};
+    static const align_fn eight_pairs[4] = {nullptr, nullptr, bmv::bmv_align_kernel<8, 2, false>, bmv::bmv_align_kernel<8, 3, false>};
+    if (cw > 1 && g < 4) return {g, cw, eight_pairs[cw]};
+    if (cw > 1 && g < 8) return {g, cw, four_pairs[cw]};
+    if (cw > 1 && g < 16) return {g, cw, two_pairs[cw]};
     if (cw > 1 || g >= 16) return {g, cw, one_pass[cw]};
     if (g >= 8) return {g, 1, bmv::bmv_align_kernel<2, 1, false>};
     if (g >= 4) return {g, 1, bmv::bmv_align_kernel<4, 1, false>};

@@ -9,5 +9,16 @@ template __global__ void bmv_align_kernel<1, 6, false>(Job);
 template __global__ void bmv_align_kernel<1, 7, false>(Job);
 template __global__ void bmv_align_kernel<1, 8, false>(Job);
 template __global__ void bmv_align_kernel<1, 6, true>(Job);
+// groups of 8..15 lanes with several words per lane (1-4 kbp reads): two trace-word pairs per lane in the traceback
+template __global__ void bmv_align_kernel<2, 2, false>(Job);
+template __global__ void bmv_align_kernel<2, 3, false>(Job);
+template __global__ void bmv_align_kernel<2, 4, false>(Job);
+template __global__ void bmv_align_kernel<2, 5, false>(Job);
+// ... of 4..7 lanes (four pairs per lane) and of 2..3 lanes (eight): reads of a few hundred bases
+template __global__ void bmv_align_kernel<4, 2, false>(Job);
+template __global__ void bmv_align_kernel<4, 3, false>(Job);
+template __global__ void bmv_align_kernel<4, 4, false>(Job);
+template __global__ void bmv_align_kernel<8, 2, false>(Job);
+template __global__ void bmv_align_kernel<8, 3, false>(Job);
 template __global__ void bmv_align_kernel<1, 8, true>(Job);
 }  // namespace bmv
