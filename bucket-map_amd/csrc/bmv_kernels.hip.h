@@ -9,12 +9,12 @@
 // column as +1/-1 vertical deltas (Pv, Mv); a column step is ~20 word operations.  A query of m bases is
 // ceil(m/64) words; they are laid over the lanes of a GROUP (CW consecutive words per lane, 1..8) and the lanes
 // are skewed along the text: at step t lane l works on column t-l and takes the horizontal delta that
-// leaves lane l-1's last row (computed one step earlier) through a shuffle.  A group is exactly as many lanes
+// leaves lane l-1's last row (computed one step earlier) through a DPP move.  A group is exactly as many lanes
 // as the longest query of the batch has words over CW (any size, not a power of two: lanes are addressed explicitly),
-// so a wave verifies 64/G candidates at once: 12 for 300-bp reads (5 lanes x 1 word), 3 for 5-kbp reads (20 x 4),
-// 2 for 10-kbp reads (32 x 5).  The host picks CW (bmv_api.hip, pick_shape): what a step pays once -- the shuffle and
-// the wait for it, the text base, the loop -- is worth about 1.5 words' recurrences, so more words per lane and more
-// alignments per wave win until the group would fall below 16 lanes.
+// so a wave verifies 64/G candidates at once: 32 for 300-bp reads (2 lanes x 3 words), 4 for 5-kbp reads (16 x 5),
+// 2 for 10-kbp reads (32 x 5).  The host picks CW (bmv_api.hip, pick_shape): what a step pays once -- the neighbour's
+// delta, the text base, the loop -- is worth about two words' recurrences, so more words per lane and more
+// alignments per wave win until the registers (13 per word) cost waves per SIMD.
 // A query of more than 512 words (32 768 bases) is processed in STRIPS of 64 * CW words, one
 // after the other over the whole text: the horizontal deltas entering a strip's first word are the stored
 // ones that left the last word of the strip above.
