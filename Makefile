@@ -58,10 +58,14 @@ tests/cpp/bucketmap_oracle: $(HOST)/main.cpp tests/cpp/make_mapper_oracle.cpp $(
 tests/cpp/bucketmap_align_oracle: $(HOST)/main.cpp tests/cpp/make_mapper_oracle.cpp $(ORACLE_OBJ) $(HOST_HDRS) $(PKG)/libbmf.so
 	$(CXX) $(CXXFLAGS) -DBM_ALIGN -o $@ $(HOST)/main.cpp tests/cpp/make_mapper_oracle.cpp $(ORACLE_OBJ) -L$(PKG) -lbmf -Wl,-rpath,'$$ORIGIN/../../$(PKG)' -lm
 
-# TEST ONLY, not part of `all`: the oracle-backed bucketmap_align under AddressSanitizer + UBSan (CPU build; GPU
-# sanitizers are not available on the pool).  Run it on any FASTA/FASTQ pair with ASAN_OPTIONS=protect_shadow_gap=0.
+# TEST ONLY, not part of `all`: the oracle-backed tools under AddressSanitizer + UBSan (CPU build; GPU sanitizers are
+# not available on the pool).  tests/test_sanitizers.py builds them and runs them on the SAM fixture's inputs.
+SANITIZE = -O1 -g -fsanitize=address,undefined -fno-sanitize-recover=undefined -fno-omit-frame-pointer -std=c++17 -pthread
+tests/cpp/bucketmap_oracle_asan: $(HOST)/main.cpp tests/cpp/make_mapper_oracle.cpp $(ORACLE_SRC) $(HOST_HDRS) $(PKG)/libbmf.so
+	$(CXX) $(SANITIZE) -o $@ $(HOST)/main.cpp tests/cpp/make_mapper_oracle.cpp $(ORACLE_SRC) -L$(PKG) -lbmf -Wl,-rpath,'$$ORIGIN/../../$(PKG)' -lm
+
 tests/cpp/bucketmap_align_oracle_asan: $(HOST)/main.cpp tests/cpp/make_mapper_oracle.cpp $(ORACLE_SRC) $(HOST_HDRS) $(PKG)/libbmf.so
-	$(CXX) -O1 -g -fsanitize=address,undefined -fno-omit-frame-pointer -std=c++17 -pthread -DBM_ALIGN -o $@ $(HOST)/main.cpp tests/cpp/make_mapper_oracle.cpp $(ORACLE_SRC) -L$(PKG) -lbmf -Wl,-rpath,'$$ORIGIN/../../$(PKG)' -lm
+	$(CXX) $(SANITIZE) -DBM_ALIGN -o $@ $(HOST)/main.cpp tests/cpp/make_mapper_oracle.cpp $(ORACLE_SRC) -L$(PKG) -lbmf -Wl,-rpath,'$$ORIGIN/../../$(PKG)' -lm
 
 # TEST ONLY: checks the one assumption the locator oracle imports from libstdc++ (equal_range order)
 tests/cpp/umm_order: tests/cpp/umm_order.cpp

@@ -86,7 +86,7 @@ def live_pmc_traffic(args, log):
     cmd = [exe, "--pmc", "FETCH_SIZE", "--output-format", "csv", "-d", out, "--", sys.executable, os.path.abspath(__file__),
            "--pmc-child", "--workload", args.workload, "--params", args.params, "--kmer-frac", str(args.kmer_frac),
            "--reads", str(args.reads), "--total-bp", str(args.total_bp), "--bucket-len", str(args.bucket_len),
-           "--host-threads", str(args.host_threads)]
+           "--host-threads", str(args.host_threads), "--genome-profile", args.genome_profile]
     t0 = time.perf_counter()
     try:
         r = subprocess.run(cmd, cwd="/tmp", env={**os.environ, "TMPDIR": "/tmp"}, capture_output=True, text=True, timeout=600)
@@ -130,7 +130,7 @@ def pmc_child(args):
                 average_base_quality=10) if args.params == "bench" else
            dict(index_seed=9, query_seed=12, read_len=read_len, mapper_samples=15, max_error_rate=0.4, distinguishability=0.5,
                 average_base_quality=25))
-    genome = host.Genome.synth(20240001, workload_record_lengths(args.workload, total_bp), threads)
+    genome = host.Genome.synth(20240001, workload_record_lengths(args.workload, total_bp), threads, profile=args.genome_profile)
     nb = genome.awk_bucket_num(bucket_len)
     reads = host.Reads(genome, bucket_len, read_len, read_len, n_reads, sub=0.002, ins=0.00025, dele=0.00025, seed=20240003,
                        threads=threads)
@@ -173,6 +173,8 @@ def main():
                     help="-f of the index (FracMinHash, seeded): 1 = all 4^q rows (the roofline configuration); 0.25 = the "
                          "reference's default, a 217 MB index that fits the 256 MiB Infinity Cache (secondary data point)")
     ap.add_argument("--host-threads", type=int, default=0)
+    ap.add_argument("--genome-profile", default="uniform", choices=["uniform", "genome"],
+                    help="uniform = i.i.d. bases (SURVEY 8d, the headline); genome = bm_synth.h's skewed, repetitive generator")
     ap.add_argument("--index-build", default="gpu", choices=["gpu", "host"],
                     help="where the synthetic index is built (setup only, outside the timed region)")
     ap.add_argument("--early-exit", action="store_true",
@@ -241,9 +243,9 @@ def main():
     # ---------------- synthetic inputs, identical on every rank except the reads
     t0 = time.perf_counter()
     lens = workload_record_lengths(args.workload, total_bp)
-    genome = host.Genome.synth(20240001, lens, threads)
+    genome = host.Genome.synth(20240001, lens, threads, profile=args.genome_profile)
     nb = genome.awk_bucket_num(bucket_len)
-    log(f"genome: {len(lens)} records, {genome.total_length()} bp, NB={nb} ({time.perf_counter() - t0:.1f}s)")
+    log(f"genome ({args.genome_profile}): {len(lens)} records, {genome.total_length()} bp, NB={nb} ({time.perf_counter() - t0:.1f}s)")
     row_bytes = (nb + 7) >> 3
     index = None
     if args.index_build == "host":
@@ -423,7 +425,7 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": scaling,
             "vs_baseline": None, "dtype": "u32", "data": "synthetic",
             "config": {
-                "workload": f"{args.workload}-like synthetic genome {genome.total_length()} bp, bucket_len {bucket_len}, "
+                "workload": f"{args.workload}-like synthetic genome ({args.genome_profile} profile) {genome.total_length()} bp, bucket_len {bucket_len}, "
                             f"NB={nb}, -f {args.kmer_frac:g} index ({n_rows} rows x {row_bytes} B), {reads_per_step} x {read_len} bp "
                             f"simulated reads per step (sub 0.002, ins=del 0.00025), params {args.params} "
                             f"(k={params.k} q={params.q} S={params.num_samples} F={params.num_fault})",

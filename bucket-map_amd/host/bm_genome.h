@@ -41,6 +41,9 @@ inline size_t io_block_bytes() {
 struct Genome {
     std::vector<std::string> ids;      // full FASTA header lines without '>'
     std::vector<std::string> seqs;     // ACGT only (folded like dna5 -> dna4: everything else -> A)
+    // assembly gaps of a synthetic genome as (record, start, length), sorted: in `seqs` they are runs of A (what the
+    // folding makes of N); write_fasta prints them as N.  Empty for genomes read from a file.
+    std::vector<std::array<uint64_t, 3>> gaps;
     uint64_t total_length() const {
         uint64_t t = 0;
         for (auto &s : seqs) t += s.size();
@@ -156,11 +159,24 @@ inline Genome read_fasta(const std::string &path, unsigned threads = 0) {
 inline void write_fasta(const Genome &g, const std::string &path, size_t width = 60) {
     std::ofstream out(path, std::ios::binary);
     if (!out) throw std::runtime_error("cannot write FASTA file " + path);
+    size_t gi = 0;
+    std::string line;
     for (size_t r = 0; r < g.ids.size(); r++) {
         out << '>' << g.ids[r] << '\n';
         const std::string &s = g.seqs[r];
+        while (gi < g.gaps.size() && g.gaps[gi][0] < r) gi++;
         for (size_t i = 0; i < s.size(); i += width) {
-            out.write(s.data() + i, std::min(width, s.size() - i));
+            const size_t n = std::min(width, s.size() - i);
+            while (gi < g.gaps.size() && g.gaps[gi][0] == r && g.gaps[gi][1] + g.gaps[gi][2] <= i) gi++;
+            if (gi < g.gaps.size() && g.gaps[gi][0] == r && g.gaps[gi][1] < i + n) {   // a gap touches this line
+                line.assign(s.data() + i, n);
+                for (size_t k = gi; k < g.gaps.size() && g.gaps[k][0] == r && g.gaps[k][1] < i + n; k++)
+                    for (size_t at = std::max<size_t>(i, g.gaps[k][1]); at < std::min<size_t>(i + n, g.gaps[k][1] + g.gaps[k][2]); at++)
+                        line[at - i] = 'N';
+                out.write(line.data(), static_cast<std::streamsize>(n));
+            } else {
+                out.write(s.data() + i, static_cast<std::streamsize>(n));
+            }
             out.put('\n');
         }
     }

@@ -36,6 +36,25 @@ bmh_genome *bmh_genome_synth(uint64_t seed, const uint64_t *record_lengths, uint
     })
 }
 
+// profile 1: the genome-like generator (bm_synth.h, synth_genome_skewed); sigma <= 0 keeps the profile's default
+bmh_genome *bmh_genome_synth_skewed(uint64_t seed, const uint64_t *record_lengths, uint32_t n_records, uint32_t threads,
+                                    double sigma, double p_repeat) {
+    BMH_GUARD(nullptr, {
+        std::vector<uint64_t> lens(record_lengths, record_lengths + n_records);
+        bm::SkewProfile pf;
+        if (sigma > 0) pf.sigma = sigma;
+        if (p_repeat >= 0) pf.p_repeat = p_repeat;
+        auto *h = new bmh_genome();
+        h->g = bm::synth_genome_skewed(seed, lens, threads, pf);
+        return h;
+    })
+}
+uint64_t bmh_genome_gap_bases(const bmh_genome *g) {
+    uint64_t n = 0;
+    for (auto &gp : g->g.gaps) n += gp[2];
+    return n;
+}
+
 bmh_genome *bmh_genome_read_fasta(const char *path) {
     BMH_GUARD(nullptr, {
         auto *h = new bmh_genome();

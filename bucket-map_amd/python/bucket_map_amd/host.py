@@ -24,6 +24,8 @@ def lib() -> C.CDLL:
         sig = {
             "bmh_last_error": (C.c_char_p, []),
             "bmh_genome_synth": (vp, [u64, C.POINTER(u64), u32, u32]),
+            "bmh_genome_synth_skewed": (vp, [u64, C.POINTER(u64), u32, u32, C.c_double, C.c_double]),
+            "bmh_genome_gap_bases": (u64, [vp]),
             "bmh_genome_read_fasta": (vp, [C.c_char_p]),
             "bmh_genome_write_fasta": (C.c_int, [vp, C.c_char_p]),
             "bmh_genome_free": (None, [vp]),
@@ -97,9 +99,18 @@ class Genome:
         self._h = handle
 
     @classmethod
-    def synth(cls, seed: int, record_lengths, threads: int = 0) -> "Genome":
+    def synth(cls, seed: int, record_lengths, threads: int = 0, profile: str = "uniform", sigma: float = 0.0,
+              p_repeat: float = -1.0) -> "Genome":
+        """profile "uniform": i.i.d. bases; "genome": the skewed, repetitive generator of bm_synth.h."""
         lens = (C.c_uint64 * len(record_lengths))(*[int(x) for x in record_lengths])
+        if profile == "genome":
+            return cls(lib().bmh_genome_synth_skewed(seed, lens, len(record_lengths), threads, sigma, p_repeat))
+        if profile != "uniform":
+            raise ValueError(f"unknown genome profile {profile!r}")
         return cls(lib().bmh_genome_synth(seed, lens, len(record_lengths), threads))
+
+    def gap_bases(self) -> int:
+        return lib().bmh_genome_gap_bases(self._h)
 
     @classmethod
     def read_fasta(cls, path: str) -> "Genome":

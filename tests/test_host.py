@@ -39,6 +39,35 @@ def test_bucket_cutting_rules():
     assert b[0][3] - b[0][2] == 65536 + 300
 
 
+def test_bucket_num_matches_the_reference_script(tmp_path):
+    """NB pinned by a reference-owned artefact: tests/golden/bucket_num_ref.json holds what the reference's own
+    get_num_buckets.sh (= bucket_map/CMakeLists.txt:13-46) printed for these FASTA files (make_nb_golden.py rebuilds
+    them byte for byte).  Held to it: awk_bucket_num on the parsed genome, and the NB the tool announces."""
+    import importlib.util
+    import json
+    spec = importlib.util.spec_from_file_location("make_nb_golden", os.path.join(ROOT, "tests", "golden", "make_nb_golden.py"))
+    mk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mk)
+    golden = json.load(open(os.path.join(ROOT, "tests", "golden", "bucket_num_ref.json")))["cases"]
+    assert set(golden) == {c[0] for c in mk.CASES}
+    exe = build_oracle_cli()
+    for case in mk.CASES:
+        name, bucket_len = case[0], case[1]
+        path = tmp_path / f"{name}.fa"
+        path.write_text(mk.fasta_text(case))
+        g = host.Genome.read_fasta(str(path))
+        want = golden[name]
+        assert want["bucket_len"] == bucket_len
+        assert g.awk_bucket_num(bucket_len) == want["bucket_num"], name
+        assert [g.record_len(i) for i in range(g.n_records)] == [n for n, _ in case[3]], name
+        r = run_cli(exe, ["-x", "-i", name, "--genome", path.name, "--bucket-len", str(bucket_len), "-r", "100", "-k", "5"], tmp_path)
+        assert r.returncode == 0, r.stderr
+        assert f"number of buckets: {want['bucket_num']}." in r.stderr, (name, r.stderr)
+    # the reference's NB can exceed the buckets its indexer keeps (utils.h:88-90 drops tails <= read_len)
+    g = host.Genome.read_fasta(str(tmp_path / "dropped_tail.fa"))
+    assert len(g.cut_buckets(1024, 100)) == 3 < golden["dropped_tail"]["bucket_num"] == 5
+
+
 def test_fasta_roundtrip(tmp_path):
     g = host.Genome.synth(2, [1000, 61, 60, 1])
     p = str(tmp_path / "g.fa")
@@ -53,6 +82,46 @@ def test_fasta_roundtrip(tmp_path):
     x = host.Genome.read_fasta(str(tmp_path / "x.fa"))
     assert x.record_id(0) == "r1 some description"
     assert bytes(x.record_seq(0)) == b"ACGTTAAAAAAC"
+
+
+# ------------------------------------------------------------------ the genome-like generator (bm_synth.h)
+
+def test_genome_like_generator_is_seeded_and_skewed(tmp_path):
+    lens = [30_000_000, 9_000_001, 70_000]
+    a = host.Genome.synth(77, lens, 1, profile="genome")
+    b = host.Genome.synth(77, lens, 5, profile="genome")
+    for i in range(len(lens)):                                # thread-count independent, ACGT only
+        sa = a.record_seq(i)
+        assert a.record_len(i) == lens[i] and np.array_equal(sa, b.record_seq(i))
+        assert np.isin(sa, np.frombuffer(b"ACGT", np.uint8)).all()
+    c = host.Genome.synth(78, lens, 0, profile="genome")
+    assert not np.array_equal(a.record_seq(2), c.record_seq(2))
+    # base composition: AT-rich, CpG-depleted, reverse-complement symmetric
+    s = a.record_seq(0)
+    code = np.zeros(256, np.int64)
+    code[list(b"ACGT")] = np.arange(4)
+    r = code[s]
+    f = np.bincount(r, minlength=4) / len(r)
+    assert 0.36 < f[1] + f[2] < 0.50 and abs(f[0] - f[3]) < 0.01 and abs(f[1] - f[2]) < 0.01
+    di = np.bincount(r[:-1] * 4 + r[1:], minlength=16) / (len(r) - 1)
+    assert di[1 * 4 + 2] < 0.5 * f[1] * f[2]                  # CG
+    assert abs(di[0 * 4 + 2] - di[1 * 4 + 3]) < 0.003         # AG ~ CT
+    # what the filter sees: the share of index rows that pass the distinguishability threshold is neither 0 nor 1
+    # (reference log, GRCh38 at 65 536: 95.8 %, bucketmap_3_map.log:8; uniform bases: 100 % / 0 %)
+    for bucket_len, lo, hi in ((65536, 0.90, 0.985), (262144, 0.30, 0.70)):
+        nb = a.awk_bucket_num(bucket_len)
+        ix = host.Index(a, nb, bucket_len, 300, q=9)
+        pop = np.unpackbits(ix.rows(), axis=1).sum(axis=1)
+        zeros = np.where(pop == 0, nb, nb - pop)
+        share = (zeros >= int(np.float32(0.5) * np.float32(nb))).mean()
+        assert lo < share < hi, (bucket_len, share)
+    # assembly gaps are runs of A in memory (dna5 -> dna4) and N in the FASTA file; reading it back folds them again
+    assert a.gap_bases() > 0
+    a.write_fasta(str(tmp_path / "g.fa"))
+    text = (tmp_path / "g.fa").read_bytes()
+    assert text.count(b"N") == a.gap_bases()
+    back = host.Genome.read_fasta(str(tmp_path / "g.fa"))
+    assert all(np.array_equal(back.record_seq(i), a.record_seq(i)) for i in range(len(lens)))
 
 
 # ------------------------------------------------------------------ indexer (bucket_indexer.h:49-127,138-216)
