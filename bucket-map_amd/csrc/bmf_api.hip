@@ -253,6 +253,12 @@ struct bmf_ctx {
     uint64_t guard_items = 0;
     bool guard_pending = false;
     pass1_fn pass1_fold = nullptr;   // non-null: pass 1 streams d_fold instead of d_rows
+    int unfolded_max_live = 32;      // lanes per item of the recount kernel that go with unfolded_rows
+    bool sort_rows = true;           // two-pass forms: each sample's rows sparsest first (BMF_ROW_ORDER=far|linear: not)
+    bool tunable = false, tuned = false;   // the pruning form is measured on the first large batch (tune_pruned)
+    uint32_t tune_windows = 32768;
+    double guard_baseline = -1.0;    // share of slow-path items of the first run after tuning (< 0: not sampled yet)
+    unsigned recount_waves = 4096;   // waves of the recount kernel the device holds at once (CUs x 4 SIMDs x BMF_RECOUNT_OCC)
     size_t sample_lds = 0;
     bmf::SampleGeom sample_geom{};
     bool sample_bitmap_lds = false;
@@ -363,6 +369,12 @@ int bmf_create(const bmf_params *params, bmf_ctx **out) {
     c->planes = planes;
     c->n_slices = n_slices;
     c->depth = n_slices > 1 ? 2 : depth_for(cpl);
+    {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, p.device) == hipSuccess && cus > 0)
+            c->recount_waves = (unsigned)cus * 4u * BMF_RECOUNT_OCC;
+        if (const char *env = getenv("BMF_RECOUNT_WAVES")) c->recount_waves = (unsigned)std::max(64, atoi(env));   // experiments
+    }
     const bool prune = (p.flags & BMF_FLAG_EARLY_EXIT) != 0;
     c->vote = n_slices > 1 ? pick_sliced(planes, prune) : pick_vote(cpl, planes, prune);
     if (!c->vote) {
@@ -502,6 +514,40 @@ static void free_index(bmf_ctx *c) {
     c->loaded = false;
 }
 
+// The folded copy of the index for a first pass that reads `fold_r` rows per sample of one bit per `fold_f` buckets:
+// sets c->dpf / c->pass1_fold / c->fold and (re)builds c->d_fold when the fold factor changes.
+static int build_fold(bmf_ctx *c, uint32_t fold_f, uint32_t fold_r) {
+    const bmf::DevParams &d = c->dp;
+    bmf::DevParams &f = c->dpf;
+    f = c->dp;
+    f.nb = (d.nb + fold_f - 1u) / fold_f;
+    const uint32_t row_bytes_f = (f.nb + 7u) >> 3;
+    f.n_chunks = (row_bytes_f + 15u) / 16u;
+    f.pitch = (row_bytes_f + 127u) & ~127u;
+    f.pass1_rows = fold_r;
+    const int cpl_f = (int)((f.n_chunks + 63u) / 64u);
+    c->pass1_fold = pick_pass1_fold((int)fold_f, cpl_f, c->planes);
+    if (!c->pass1_fold) return BMF_OK;
+    if (c->d_fold && c->fold == fold_f) return BMF_OK;             // the copy is there already
+    if (c->d_fold) (void)hipFree(c->d_fold);
+    c->d_fold = nullptr;
+    c->fold = fold_f;
+    HIP_TRY(dev_alloc(&c->d_fold, (size_t)(c->n_rows + 1) * f.pitch));
+    // whole rows per launch, grid.x * 256 threads below 2^32
+    const uint64_t rows_per_launch = std::max<uint64_t>(1, ((uint64_t)1 << 30) / (f.pitch >> 2));
+    for (uint64_t r0 = 0; r0 <= c->n_rows; r0 += rows_per_launch) {
+        const uint64_t nr = std::min<uint64_t>(rows_per_launch, c->n_rows + 1 - r0);
+        const uint64_t w = nr * (f.pitch >> 2);
+        auto fk = fold_f == 4 ? bmf::bmf_fold_kernel<4> : bmf::bmf_fold_kernel<2>;
+        hipLaunchKernelGGL(fk, dim3((unsigned)((w + 255) / 256)), dim3(256), 0, c->stream,
+                           c->d_rows + (size_t)r0 * c->dp.pitch, nr, c->dp.pitch, c->d_fold + (size_t)r0 * f.pitch, f.pitch);
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return BMF_OK;
+}
+
+
 // BMF_FLAG_EARLY_EXIT: which exact-pruning kernel serves this index.  The two-pass kernel streams r rows
 // per sample at full width, then recounts the chunks that survive; a bucket unrelated to the read survives
 // a sample with probability about h^r, h = 1 - f + f*d (d = density of the rows a read meets, weighted by density
@@ -510,6 +556,9 @@ static void free_index(bmf_ctx *c) {
 // before it can narrow.  BMF_PASS1_ROWS=r forces r (0: never two-pass) for experiments.
 static int select_pruned_variant(bmf_ctx *c) {
     const bmf::DevParams &d = c->dp;
+    c->sort_rows = !getenv("BMF_ROW_ORDER");
+    c->tunable = c->tuned = false;
+    c->guard_baseline = -1.0;
     c->dp.pass1_rows = 0;
     c->dp.max_live = bmf::kMaxLive;
     c->dp.item_base = 0;
@@ -539,6 +588,14 @@ static int select_pruned_variant(bmf_ctx *c) {
     if ((kept < 0.6 || d.n_chunks <= 16u) && !getenv("BMF_PASS1_ROWS") && !fold_forced) {
         c->vote = pick_vote(c->cpl, c->planes, false);
         return BMF_OK;
+    }
+    {   // from here on a pruning form serves the index: which one is measured on the first large batch (tune_pruned)
+        const char *at = getenv("BMF_AUTOTUNE");
+        const bool forced = getenv("BMF_PASS1_ROWS") || getenv("BMF_FOLD") || getenv("BMF_MAX_LIVE") || getenv("BMF_ROW_ORDER") ||
+                            getenv("BMF_SLICES") || getenv("BMF_GUARD_TRIP");
+        c->tunable = !forced && !(at && at[0] == '0');
+        c->tune_windows = 32768;
+        if (const char *tw = getenv("BMF_TUNE_WINDOWS")) c->tune_windows = (uint32_t)std::max(64l, atol(tw));
     }
     const double row_bytes = (double)d.n_chunks * 16.0, sector = 64.0;
     const double prune_cost = (double)d.F * d.G * row_bytes;
@@ -611,6 +668,9 @@ static int select_pruned_variant(bmf_ctx *c) {
             fold_live = survivors(fold_f, fold_r);
         }
         c->unfolded_rows = best_r;
+        // the recount kernel's form that goes with the UNFOLDED choice (the folded model keeps fold_live <= 8 and so
+        // always asks for 16 lanes; the unfolded passes may leave ~20 chunks alive by chance): the guard restores both
+        c->unfolded_max_live = best_live + 1.0 <= 9.0 ? 16 : 32;
         if (fold_r) {
             best_r = best_r ? best_r : 1u;               // what the recount and the slow kernel call "pass 1's rows"
             best_live = fold_live;
@@ -628,32 +688,7 @@ static int select_pruned_variant(bmf_ctx *c) {
             c->dp.max_live = (uint32_t)max_live;
         }
     }
-    if (fold_r && c->dp.pass1_rows) {
-        bmf::DevParams &f = c->dpf;
-        f = c->dp;
-        f.nb = (d.nb + fold_f - 1u) / fold_f;
-        const uint32_t row_bytes_f = (f.nb + 7u) >> 3;
-        f.n_chunks = (row_bytes_f + 15u) / 16u;
-        f.pitch = (row_bytes_f + 127u) & ~127u;
-        f.pass1_rows = fold_r;
-        const int cpl_f = (int)((f.n_chunks + 63u) / 64u);
-        c->pass1_fold = pick_pass1_fold((int)fold_f, cpl_f, c->planes);
-        c->fold = fold_f;
-        if (c->pass1_fold) {
-            HIP_TRY(dev_alloc(&c->d_fold, (size_t)(c->n_rows + 1) * f.pitch));
-            // whole rows per launch, grid.x * 256 threads below 2^32
-            const uint64_t rows_per_launch = std::max<uint64_t>(1, ((uint64_t)1 << 30) / (f.pitch >> 2));
-            for (uint64_t r0 = 0; r0 <= c->n_rows; r0 += rows_per_launch) {
-                const uint64_t nr = std::min<uint64_t>(rows_per_launch, c->n_rows + 1 - r0);
-                const uint64_t w = nr * (f.pitch >> 2);
-                auto fk = fold_f == 4 ? bmf::bmf_fold_kernel<4> : bmf::bmf_fold_kernel<2>;
-                hipLaunchKernelGGL(fk, dim3((unsigned)((w + 255) / 256)), dim3(256), 0, c->stream,
-                                   c->d_rows + (size_t)r0 * c->dp.pitch, nr, c->dp.pitch, c->d_fold + (size_t)r0 * f.pitch, f.pitch);
-            }
-            HIP_TRY(hipGetLastError());
-            HIP_TRY(hipStreamSynchronize(c->stream));
-        }
-    }
+    if (fold_r && c->dp.pass1_rows) return build_fold(c, fold_f, fold_r);
     return BMF_OK;
 }
 
@@ -1105,35 +1140,27 @@ int bmf_batch_create(bmf_ctx *c, const uint8_t *bases, const uint8_t *quals, uin
     return BMF_OK;
 }
 
-// The filter's kernels for the n_windows windows of `b`, reads at d_bases / d_quals, on the context's stream.
-static int launch_filter(bmf_ctx *c, bmf_batch *b, const uint8_t *d_bases, const uint8_t *d_quals, hipEvent_t *ev) {
-    if (ev) HIP_TRY(hipEventRecord(ev[0], c->stream));
-    {
-        bmf::SampleGeom g = c->sample_geom;
-        g.n_windows = b->n_windows;
-        const unsigned wgs = std::min<unsigned>((b->n_windows + g.waves_per_wg - 1) / g.waves_per_wg, 2048u);
-        auto fn = c->sample_bitmap_lds ? bmf::bmf_sample_kernel<true> : bmf::bmf_sample_kernel<false>;
-        hipLaunchKernelGGL(fn, dim3(wgs), dim3(g.waves_per_wg * bmf::kWave), c->sample_lds, c->stream, c->dp, g, d_bases, d_quals,
-                           b->win_start.p, b->win_len.p, c->d_qgram_ok, c->d_k2i, c->d_pos_table, b->lists.p, b->list_n.p,
-                           b->rows_anded.p);
-    }
-    if (ev) HIP_TRY(hipEventRecord(ev[1], c->stream));
-    if (c->guard_pending && hipEventQuery(c->guard_ev) == hipSuccess) {
-        c->guard_pending = false;
-        const bool trip = (uint64_t)c->h_guard[1] * 50u > c->guard_items || getenv("BMF_GUARD_TRIP");   // (the env: tests)
-        if (c->pass1_fold && trip && !getenv("BMF_FOLD")) {
-            c->pass1_fold = nullptr;                     // the folded pass lets too much through on this index:
-            c->dp.pass1_rows = c->unfolded_rows;         // back to the unfolded choice (0 = the single-pass pruning kernel)
-        }
-    }
+// Everything after the sample kernel for the first n_windows windows of `b` (row-id lists in b->lists), on the
+// context's stream: the vote kernel, or the exact-pruning kernels the context currently uses.
+static int launch_vote_stage(bmf_ctx *c, bmf_batch *b, uint32_t n_windows) {
     if (c->dp.pass1_rows) {
         // two-pass pruning: full-width lower-bound pass, then the queued items' exact recount (bmf_vote2.hip.h)
-        const size_t n_items = 2 * (size_t)b->n_windows;
+        const size_t n_items = 2 * (size_t)n_windows;
+        if (c->sort_rows && c->dp.G >= 2) {                      // each sample's rows sparsest first
+            using order_fn = void (*)(bmf::DevParams, uint32_t, const uint32_t *, const uint32_t *, uint32_t *);
+            static const order_fn order[9] = {nullptr, nullptr, bmf::bmf_order_rows_kernel<2>, bmf::bmf_order_rows_kernel<3>,
+                                              bmf::bmf_order_rows_kernel<4>, bmf::bmf_order_rows_kernel<5>,
+                                              bmf::bmf_order_rows_kernel<6>, bmf::bmf_order_rows_kernel<7>,
+                                              bmf::bmf_order_rows_kernel<8>};
+            const uint64_t threads = (uint64_t)n_items * c->dp.S;
+            hipLaunchKernelGGL(order[c->dp.G], dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, c->stream, c->dp,
+                               (uint32_t)n_items, b->list_n.p, c->d_zeros, b->lists.p);
+        }
         HIP_TRY(b->q_counters.need(4));
-        HIP_TRY(b->q_slow.need(n_items));
-        HIP_TRY(b->q_live_n.need(n_items));
-        HIP_TRY(b->q_live_chunks.need(n_items * bmf::kMaxLive));
-        HIP_TRY(b->q_live_mask.need(n_items * c->dp.max_live));
+        HIP_TRY(b->q_slow.need(2 * (size_t)b->n_windows));
+        HIP_TRY(b->q_live_n.need(2 * (size_t)b->n_windows));
+        HIP_TRY(b->q_live_chunks.need(2 * (size_t)b->n_windows * bmf::kMaxLive));
+        HIP_TRY(b->q_live_mask.need(2 * (size_t)b->n_windows * c->dp.max_live));
         HIP_TRY(hipMemsetAsync(b->q_counters.p, 0, 4 * sizeof(uint32_t), c->stream));
         const bmf::Pass2Queue q{b->q_counters.p, b->q_slow.p, b->q_live_n.p, b->q_live_chunks.p, b->q_live_mask.p};
         const size_t per_wave = bmf::kWave / c->dp.max_live;   // items per wave of the recount kernel
@@ -1161,6 +1188,7 @@ static int launch_filter(bmf_ctx *c, bmf_batch *b, const uint8_t *d_bases, const
             dp.item_base = (uint32_t)first;
             if (c->pass1_fold) {
                 bmf::DevParams df = c->dpf;
+                df.max_live = dp.max_live;
                 df.item_base = dp.item_base;
                 hipLaunchKernelGGL(c->pass1_fold, dim3((unsigned)count), dim3(bmf::kWave), 0, c->stream, df, c->d_fold, b->lists.p,
                                    b->list_n.p, b->counts.p, q);
@@ -1174,7 +1202,10 @@ static int launch_filter(bmf_ctx *c, bmf_batch *b, const uint8_t *d_bases, const
                 HIP_TRY(hipStreamWaitEvent(c->side, c->slice_done[sl], 0));
                 rs = c->side;
             }
-            const unsigned recount_blocks = (unsigned)std::min<size_t>((count + per_wave - 1) / per_wave, 32768);
+            // One resident round of waves, each walking its share of the items: the recount kernel spills a few
+            // registers to scratch, and a wave that needs scratch takes ~75 us to start (measured: 32 768 one-item waves
+            // took 0.87 ms for the work 4 096 waves do in 0.3 ms) -- so no more waves than the card holds at once.
+            const unsigned recount_blocks = (unsigned)std::min<size_t>((count + per_wave - 1) / per_wave, c->recount_waves);
             hipLaunchKernelGGL(c->two_pass.recount, dim3(recount_blocks), dim3(bmf::kWave), recount_lds, rs, dp, c->d_rows, b->lists.p,
                                (uint32_t)count, b->counts.p, b->buckets.p, q);
         }
@@ -1185,7 +1216,7 @@ static int launch_filter(bmf_ctx *c, bmf_batch *b, const uint8_t *d_bases, const
         const unsigned slow_blocks = (unsigned)std::min<size_t>(n_items, 2048);
         hipLaunchKernelGGL(c->two_pass.slow, dim3(slow_blocks), dim3(bmf::kWave), 0, c->stream, c->dp, c->d_rows, b->lists.p,
                            b->counts.p, b->buckets.p, q);
-        if (c->pass1_fold && !c->guard_pending && n_items >= 4096) {   // the guard's sample: this run's slow-path count
+        if (!c->guard_pending && n_items >= 4096) {   // the guard's sample: this run's slow-path count
             if (!c->h_guard) {
                 HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&c->h_guard), 4 * sizeof(uint32_t), hipHostMallocDefault));
                 HIP_TRY(hipEventCreateWithFlags(&c->guard_ev, hipEventDisableTiming));
@@ -1196,15 +1227,156 @@ static int launch_filter(bmf_ctx *c, bmf_batch *b, const uint8_t *d_bases, const
             c->guard_pending = true;
         }
     } else if (c->n_slices == 1) {
-        hipLaunchKernelGGL(c->vote, dim3(2 * b->n_windows), dim3(bmf::kWave), 0, c->stream, c->dp, c->d_rows, b->lists.p,
+        hipLaunchKernelGGL(c->vote, dim3(2 * n_windows), dim3(bmf::kWave), 0, c->stream, c->dp, c->d_rows, b->lists.p,
                            b->list_n.p, b->counts.p, b->buckets.p, (uint32_t *)nullptr);
     } else {
-        hipLaunchKernelGGL(c->vote, dim3(2 * b->n_windows, c->n_slices), dim3(bmf::kWave), 0, c->stream, c->dp, c->d_rows,
+        hipLaunchKernelGGL(c->vote, dim3(2 * n_windows, c->n_slices), dim3(bmf::kWave), 0, c->stream, c->dp, c->d_rows,
                            b->lists.p, b->list_n.p, b->slice_cnt.p, b->slice_ids.p, b->slice_min.p);
-        hipLaunchKernelGGL(bmf::bmf_merge_slices_kernel, dim3((2 * b->n_windows + 255) / 256), dim3(256), 0, c->stream, c->dp,
-                           2 * b->n_windows, c->n_slices, b->slice_min.p, b->slice_cnt.p, b->slice_ids.p, b->counts.p,
+        hipLaunchKernelGGL(bmf::bmf_merge_slices_kernel, dim3((2 * n_windows + 255) / 256), dim3(256), 0, c->stream, c->dp,
+                           2 * n_windows, c->n_slices, b->slice_min.p, b->slice_cnt.p, b->slice_ids.p, b->counts.p,
                            b->buckets.p);
     }
+    return BMF_OK;
+}
+
+// One way of serving BMF_FLAG_EARLY_EXIT (all of them give the plain kernel's outputs).
+struct PruneChoice {
+    int kind = 0;                    // 0: plain vote kernel, 1: single-pass pruning kernel, 2: two passes
+    uint32_t fold = 1, rows = 0;     // two passes: the first reads `rows` rows per sample of the index folded by `fold`
+    uint32_t max_live = 32;          // two passes: lanes per item of the recount kernel
+    bool sort = true;                // two passes: each sample's rows sparsest first
+};
+
+static int apply_choice(bmf_ctx *c, const PruneChoice &ch) {
+    c->pass1_fold = nullptr;
+    c->dp.pass1_rows = 0;
+    c->dp.max_live = bmf::kMaxLive;
+    c->vote = pick_vote(c->cpl, c->planes, ch.kind == 1);
+    if (ch.kind != 2) return BMF_OK;
+    c->two_pass = pick_vote2(c->cpl, c->planes, (int)ch.max_live);
+    if (!c->two_pass.pass1) return BMF_OK;
+    c->dp.max_live = ch.max_live;
+    c->sort_rows = ch.sort;
+    // the recount's thin pass reads entry pass1_rows of every sample: the first row pass 1 has not seen at full width
+    c->dp.pass1_rows = ch.fold > 1 ? 1u : ch.rows;
+    if (ch.fold > 1) return build_fold(c, ch.fold, ch.rows);
+    return BMF_OK;
+}
+
+// MEASURED choice of the pruning form.  The model in select_pruned_variant prices the forms from one number, the
+// density of the rows a read meets; on a real genome the rows differ a hundredfold in density, reads from repeats keep
+// hundreds of chunks alive, and which form wins depends on the reads as much as on the index.  So the first batch of
+// at least kTuneWindows windows is used as the benchmark: every candidate form runs on its first kTuneWindows windows
+// (row-id lists already written by the sample kernel), timed with HIP events on the context's stream, and the fastest
+// serves the context from then on.  All forms write the same outputs, so this costs a few tens of milliseconds once
+// and nothing else.  BMF_AUTOTUNE=0 keeps the model's choice; forcing a form (BMF_PASS1_ROWS, BMF_FOLD, BMF_MAX_LIVE,
+// BMF_ROW_ORDER) does too; BMF_TUNE_WINDOWS=n moves the threshold (tests); BMF_LOG_TUNE=1 prints the table.
+static int tune_pruned(bmf_ctx *c, bmf_batch *b) {
+    c->tuned = true;
+    c->guard_baseline = -1.0;
+    const bmf::DevParams &d = c->dp;
+    const uint32_t n_win = std::min<uint32_t>(b->n_windows, c->tune_windows);
+    const bool log = getenv("BMF_LOG_TUNE") != nullptr;
+    std::vector<PruneChoice> cands;
+    auto add = [&](int kind, uint32_t fold, uint32_t rows, uint32_t live, bool sort) {
+        PruneChoice ch;
+        ch.kind = kind; ch.fold = fold; ch.rows = rows; ch.max_live = live; ch.sort = sort;
+        cands.push_back(ch);
+    };
+    // Unsorted forms first: the order kernel re-orders the lists in place (any order is valid for every kernel).
+    const uint32_t chunks2 = ((((d.nb + 1u) / 2u + 7u) >> 3) + 15u) / 16u, chunks4 = ((((d.nb + 3u) / 4u + 7u) >> 3) + 15u) / 16u;
+    for (int sorted = 0; sorted < 2; sorted++) {
+        if (!sorted) {
+            add(0, 1, 0, 32, false);
+            add(1, 1, 0, 32, false);
+        }
+        for (uint32_t live : {16u, 32u}) {
+            for (uint32_t r = 1; r < d.G && r <= 3; r++) add(2, 1, r, live, sorted != 0);
+            if (chunks2 <= 256u)
+                for (uint32_t r = 2; r <= d.G && r <= 4; r++) add(2, 2, r, live, sorted != 0);
+            if (chunks4 <= 128u)
+                for (uint32_t r = 3; r <= d.G && r <= 5; r++) add(2, 4, r, live, sorted != 0);
+        }
+    }
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    float best_ms = 1e30f;
+    size_t best = 0;
+    int rc = BMF_OK;
+    for (size_t i = 0; i < cands.size() && rc == BMF_OK; i++) {
+        rc = apply_choice(c, cands[i]);
+        if (rc != BMF_OK) break;
+        if (cands[i].kind == 2 && (!c->dp.pass1_rows || (cands[i].fold > 1 && !c->pass1_fold))) continue;   // no such kernel
+        c->guard_pending = true;                                   // (no guard samples from the tuning runs)
+        float ms = 1e30f;
+        for (int rep = 0; rep < 2 && rc == BMF_OK; rep++) {        // the first run of a form also sizes its buffers
+            if (rep == 1 && ms > 1.5f * best_ms) break;            // far behind already: no second look
+            (void)hipEventRecord(e0, c->stream);
+            rc = launch_vote_stage(c, b, n_win);
+            (void)hipEventRecord(e1, c->stream);
+            if (hipEventSynchronize(e1) != hipSuccess || hipGetLastError() != hipSuccess) rc = fail(BMF_ERR_HIP, "tuning run failed");
+            float t = 0.f;
+            (void)hipEventElapsedTime(&t, e0, e1);
+            ms = std::min(ms, t);
+        }
+        c->guard_pending = false;
+        if (log)
+            fprintf(stderr, "[bmf] tune: kind %d fold %u rows %u lanes %u sorted %d: %.3f ms per %u windows\n", cands[i].kind,
+                    cands[i].fold, cands[i].rows, cands[i].max_live, (int)cands[i].sort, ms, n_win);
+        if (ms < best_ms) {
+            best_ms = ms;
+            best = i;
+        }
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (rc != BMF_OK) return rc;
+    if (log)
+        fprintf(stderr, "[bmf] tune: chose kind %d fold %u rows %u lanes %u sorted %d\n", cands[best].kind, cands[best].fold,
+                cands[best].rows, cands[best].max_live, (int)cands[best].sort);
+    return apply_choice(c, cands[best]);
+}
+
+// The filter's kernels for the n_windows windows of `b`, reads at d_bases / d_quals, on the context's stream.
+static int launch_filter(bmf_ctx *c, bmf_batch *b, const uint8_t *d_bases, const uint8_t *d_quals, hipEvent_t *ev) {
+    if (ev) HIP_TRY(hipEventRecord(ev[0], c->stream));
+    {
+        bmf::SampleGeom g = c->sample_geom;
+        g.n_windows = b->n_windows;
+        const unsigned wgs = std::min<unsigned>((b->n_windows + g.waves_per_wg - 1) / g.waves_per_wg, 2048u);
+        auto fn = c->sample_bitmap_lds ? bmf::bmf_sample_kernel<true> : bmf::bmf_sample_kernel<false>;
+        hipLaunchKernelGGL(fn, dim3(wgs), dim3(g.waves_per_wg * bmf::kWave), c->sample_lds, c->stream, c->dp, g, d_bases, d_quals,
+                           b->win_start.p, b->win_len.p, c->d_qgram_ok, c->d_k2i, c->d_pos_table, b->lists.p, b->list_n.p,
+                           b->rows_anded.p);
+    }
+    if (ev) HIP_TRY(hipEventRecord(ev[1], c->stream));
+    if (c->tunable && !c->tuned && b->n_windows >= c->tune_windows) {
+        const int rc = tune_pruned(c, b);
+        if (rc != BMF_OK) return rc;
+    }
+    if (c->guard_pending && hipEventQuery(c->guard_ev) == hipSuccess) {
+        c->guard_pending = false;
+        // more than 2 % of the last run's items overflowed the recount kernel's lanes (the env: tests)
+        const bool trip = (uint64_t)c->h_guard[1] * 50u > c->guard_items || getenv("BMF_GUARD_TRIP");
+        if (c->tunable && c->tuned) {
+            // under a measured choice the share of slow items is whatever the reads make it: the first sample after
+            // tuning is the baseline, and a later run with more than twice that share (+ 2 %) means the reads have
+            // changed -- measure again on the next large batch
+            const double share = c->guard_items ? (double)c->h_guard[1] / (double)c->guard_items : 0.0;
+            if (c->guard_baseline < 0.0) c->guard_baseline = share;
+            else if (share > 2.0 * c->guard_baseline + 0.02) c->tuned = false;
+        } else if (c->pass1_fold && trip && !getenv("BMF_FOLD")) {
+            c->pass1_fold = nullptr;                     // the folded pass lets too much through on this index:
+            c->dp.pass1_rows = c->unfolded_rows;         // back to the unfolded choice (0 = the single-pass pruning kernel)
+            if (c->unfolded_rows && !getenv("BMF_MAX_LIVE")) {   // ... and to the recount form that was chosen WITH it
+                c->dp.max_live = (uint32_t)c->unfolded_max_live;
+                c->two_pass = pick_vote2(c->cpl, c->planes, c->unfolded_max_live);
+            }
+        }
+    }
+    const int rc = launch_vote_stage(c, b, b->n_windows);
+    if (rc != BMF_OK) return rc;
     if (ev) HIP_TRY(hipEventRecord(ev[2], c->stream));
     HIP_TRY(hipGetLastError());
     return BMF_OK;

@@ -43,16 +43,96 @@ struct Pass2Queue {
     uint32_t *counters;         // [0] items bmf_recount_kernel has work for (statistics), [1] length of slow_items,
                                 // [2] 16-byte column loads bmf_recount_kernel issued (statistics: one 64-byte sector each)
     uint32_t *slow_items;
-    uint32_t *live_n;           // per item: live chunks after pass 1 (0: result already final), or kSlowItem
-    uint16_t *live_chunks;      // per item: max_live chunk ids, ascending
-    uint4 *live_mask;           // per live chunk: which of its 128 buckets were still below F misses after pass 1
+    uint32_t *live_n;           // per item: 0 (result already final), kSlowItem, or n | L << 8 | T << 16 -- n chunks are
+                                // stored, every chunk whose LEVEL (lowest pass-1 counter among its buckets) is <= T; L is
+                                // the item's lowest level (counters biased as below, so 2^PLANES - 1 is "F misses or more")
+    uint16_t *live_chunks;      // per item: max_live entries, ascending chunk ids: id | level << 10
+    uint4 *live_mask;           // per stored chunk: which of its 128 buckets had a pass-1 counter <= T
 };
+
+// THE LEVELS.  best_results wants the buckets with the MINIMUM miss count m* (if m* < F), so a bucket whose lower bound
+// from pass 1 exceeds m* is as dead as one at F -- and m* is small whenever the read really comes from somewhere
+// (0 or 1 for most reads on their true strand, a few for a read whose reverse complement meets an inverted copy of a
+// repeat).  On a repetitive genome that is the difference between "every copy of the repeat family is still below F"
+// and "the read's own bucket and its recent duplicates".  m* is not known after pass 1, but an upper bound is cheap:
+// the exact count of the chunks at the item's lowest level L (usually one chunk, the read's own).  So the recount
+// kernel works in two rounds -- (A) the level-L chunks exactly, giving U = min(their best count, F - 1) >= m*;
+// (B) the chunks with L < level <= U, thin pass first, judged against U instead of F -- and pass 1, when more chunks
+// are below F than the recount kernel has lanes, keeps those up to the highest level T that fits; only an item whose
+// U turns out above its T (a needed chunk was not kept) or whose level-L chunks alone do not fit goes to the slow kernel.
+constexpr uint32_t kChunkIdBits = 10;   // a slice has at most 512 chunks of 128 buckets
+
+// lowest counter among the buckets of `words` 32-bit words (bits that are no bucket are saturated and lose)
+template <int PLANES, int NW>
+__device__ __forceinline__ uint32_t min_level(const uint32_t (&c)[PLANES][NW]) {
+    uint32_t cand[NW], level = 0;
+#pragma unroll
+    for (int w = 0; w < NW; w++) cand[w] = 0xFFFFFFFFu;
+#pragma unroll
+    for (int p = PLANES - 1; p >= 0; p--) {
+        uint32_t any = 0;
+#pragma unroll
+        for (int w = 0; w < NW; w++) any |= cand[w] & ~c[p][w];
+        const bool some = any != 0;
+#pragma unroll
+        for (int w = 0; w < NW; w++) cand[w] = some ? cand[w] & ~c[p][w] : cand[w];
+        level |= some ? 0u : 1u << p;
+    }
+    return level;
+}
+
+// bits of one word whose PLANES-bit counter is <= T
+template <int PLANES>
+__device__ __forceinline__ uint32_t count_le(const uint32_t (&c)[PLANES], uint32_t T) {
+    uint32_t lt = 0, eq = 0xFFFFFFFFu;
+#pragma unroll
+    for (int p = PLANES - 1; p >= 0; p--) {
+        if ((T >> p) & 1u) {
+            lt |= eq & ~c[p];
+            eq &= c[p];
+        } else {
+            eq &= ~c[p];
+        }
+    }
+    return lt | eq;
+}
 
 // The row-id list of an item holds each sample's G rows in the order DevParams::row_order gives (the sample kernel
 // writes them so): 0, G-1, then the middles.  The q-grams of a k-mer overlap -- q-gram g and g+1 share q-1 bases, so a
 // bucket that holds one holds the other far more often than chance (an occurrence of the first continues into the
 // second with probability 1/4) -- and the rows of NEIGHBOURING q-grams AND to much less of a filter than independent
 // rows would.  The passes that read only the first few entries of a sample therefore get rows that lie far apart.
+
+// ... and SPARSEST FIRST (bmf_order_rows_kernel, run between the sample kernel and pass 1 when a two-pass form serves
+// the index): on a real genome the rows a read meets differ widely in density (a q-gram is met in proportion to how often
+// it occurs, so reads meet the dense rows), and the row with the most zeros is the one that tells the most buckets
+// apart for the same bytes.  One thread per (item, sample) re-orders the sample's G entries by zeros[row], most zeros
+// first; ties keep the far-apart order.  The vote ANDs all G rows and does not care; rows_anded does not change.
+template <int G>
+__global__ __launch_bounds__(256) void bmf_order_rows_kernel(DevParams P, uint32_t n_items, const uint32_t *__restrict__ list_n,
+                                                           const uint32_t *__restrict__ zeros, uint32_t *__restrict__ row_lists) {
+    const uint64_t t = (uint64_t)blockIdx.x * 256u + threadIdx.x;   // up to 2^26 items x 64 samples
+    const uint32_t item = (uint32_t)(t / P.S), s = (uint32_t)(t - (uint64_t)item * P.S);
+    if (item >= n_items || list_n[item >> 1] == 0) return;          // a rejected window has no lists
+    uint32_t *e = row_lists + (size_t)item * P.list_len + s * G;
+    uint32_t id[G], z[G];
+#pragma unroll
+    for (int g = 0; g < G; g++) {
+        id[g] = e[g];
+        z[g] = id[g] == P.ones_row ? 0u : zeros[id[g]];             // a q-gram that is not indexed tells nothing
+    }
+#pragma unroll
+    for (int i = 1; i < G; i++)                                     // stable insertion sort, G <= 8
+#pragma unroll
+        for (int j = i; j > 0; j--) {
+            const bool sw = z[j] > z[j - 1];
+            const uint32_t zi = sw ? z[j - 1] : z[j], zj = sw ? z[j] : z[j - 1];
+            const uint32_t ii = sw ? id[j - 1] : id[j], ij = sw ? id[j] : id[j - 1];
+            z[j] = zi; z[j - 1] = zj; id[j] = ii; id[j - 1] = ij;
+        }
+#pragma unroll
+    for (int g = 0; g < G; g++) e[g] = id[g];
+}
 
 // Counters in this file are BIASED: a bucket starts at 2^PLANES-1-F instead of 0, so that "F misses or more"
 // is exactly "the saturating counter is all ones" -- one AND per plane instead of a bit-sliced comparison
@@ -264,69 +344,106 @@ __device__ __forceinline__ void pass1_item(const DevParams &P, const uint8_t *__
         }
         return;
     }
-    // chunks that still hold a bucket with < F misses, in ascending chunk order
-    uint32_t n_live = 0;
-    if (FOLD == 1) {
+    // Level of every chunk of the index under this lane's slots: the lowest counter among its buckets (or groups).
+    constexpr int kSub = FOLD == 1 ? 1 : (FOLD == 4 ? 4 : 2);      // chunks of the index under one (folded) chunk
+    constexpr int kWords = 4 / kSub;                                // words of the folded chunk per chunk of the index
+    constexpr uint32_t kSat = (1u << PLANES) - 1u;
+    uint32_t lvl[CPL][kSub], lo = kSat;
 #pragma unroll
-        for (int j = 0; j < CPL; j++) {
-            uint32_t a = 0;
+    for (int j = 0; j < CPL; j++)
 #pragma unroll
-            for (int x = 0; x < 4; x++) a |= alive_word<CPL, PLANES>(cnt, j, x);
-            const bool live = a != 0;
-            const uint64_t m = __ballot(live);
-            const uint32_t at = n_live + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-            if (live && at < P.max_live) {
-                Q.live_chunks[(size_t)item * P.max_live + at] = (uint16_t)cidx[j];
-                Q.live_mask[(size_t)item * P.max_live + at] =
-                    make_uint4(alive_word<CPL, PLANES>(cnt, j, 0), alive_word<CPL, PLANES>(cnt, j, 1),
-                               alive_word<CPL, PLANES>(cnt, j, 2), alive_word<CPL, PLANES>(cnt, j, 3));
-            }
-            n_live += (uint32_t)__popcll(m);
+        for (int h = 0; h < kSub; h++) {
+            uint32_t c[PLANES][kWords];
+#pragma unroll
+            for (int p = 0; p < PLANES; p++)
+#pragma unroll
+                for (int w = 0; w < kWords; w++) c[p][w] = cnt[p][j].v[h * kWords + w];
+            lvl[j][h] = min_level<PLANES, kWords>(c);
+            lo = min(lo, lvl[j][h]);
         }
-    } else {
-        constexpr int kSub = FOLD == 4 ? 4 : 2;         // chunks of the index under one folded chunk
 #pragma unroll
-        for (int j = 0; j < CPL; j++) {
-            uint32_t aw[4], mine = 0;
+    for (int o = 32; o > 0; o >>= 1) lo = min(lo, (uint32_t)__shfl_xor((int)lo, o, kWave));
+    if (lo == kSat) {                          // nothing below F: the result is empty
+        if (lane == 0) {
+            out_counts[item] = 0;
+            Q.live_n[item] = 0;
+        }
+        return;
+    }
+    // How many chunks lie at or below L, L + 1, L + 2 and F - 1: the highest of these that fits the recount kernel's
+    // lanes is T.  (Wave-uniform; L alone not fitting sends the item to the slow kernel.)
+    const uint32_t cand_t[4] = {lo, min(lo + 1u, kSat - 1u), min(lo + 2u, kSat - 1u), kSat - 1u};
+    uint32_t T = kSat, n_store = 0;
 #pragma unroll
-            for (int x = 0; x < 4; x++) aw[x] = alive_word<CPL, PLANES>(cnt, j, x);
-            bool live[kSub];
+    for (int i = 0; i < 4; i++) {
+        uint32_t n = 0;
 #pragma unroll
-            for (int h = 0; h < kSub; h++) {
-                live[h] = FOLD == 4 ? aw[h] != 0 : (aw[2 * h] | aw[2 * h + 1]) != 0;
-                mine += live[h] ? 1u : 0u;
-            }
-            uint32_t incl = mine;                       // lanes in order, a lane's chunks in order: ascending chunk ids
+        for (int j = 0; j < CPL; j++)
+#pragma unroll
+            for (int h = 0; h < kSub; h++) n += (uint32_t)__popcll(__ballot(lvl[j][h] <= cand_t[i]));
+        if (n <= P.max_live) {
+            T = cand_t[i];
+            n_store = n;
+        }
+    }
+    if (T == kSat) {
+        if (lane == 0) {
+            Q.slow_items[atomicAdd(&Q.counters[1], 1u)] = item;
+            Q.live_n[item] = kSlowItem;
+        }
+        return;
+    }
+    // the kept chunks in ascending order: lanes in order, a lane's sub-chunks in order, slot rounds in order
+    uint32_t n_before = 0;
+#pragma unroll
+    for (int j = 0; j < CPL; j++) {
+        bool keep[kSub];
+        uint32_t mine = 0;
+#pragma unroll
+        for (int h = 0; h < kSub; h++) {
+            keep[h] = lvl[j][h] <= T;
+            mine += keep[h] ? 1u : 0u;
+        }
+        uint32_t at, total;
+        if (kSub == 1) {
+            const uint64_t m = __ballot(keep[0]);
+            at = n_before + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+            total = (uint32_t)__popcll(m);
+        } else {
+            uint32_t incl = mine;
 #pragma unroll
             for (int o = 1; o < kWave; o <<= 1) {
                 const uint32_t t = __shfl_up(incl, o, kWave);
                 if (lane >= (uint32_t)o) incl += t;
             }
-            uint32_t at = n_live + incl - mine;
+            at = n_before + incl - mine;
+            total = (uint32_t)__shfl((int)incl, kWave - 1, kWave);
+        }
 #pragma unroll
-            for (int h = 0; h < kSub; h++)
-                if (live[h]) {
-                    if (at < P.max_live) {
-                        Q.live_chunks[(size_t)item * P.max_live + at] = (uint16_t)(cidx[j] * (uint32_t)kSub + (uint32_t)h);
-                        Q.live_mask[(size_t)item * P.max_live + at] =
-                            FOLD == 4 ? make_uint4(spread4_byte(aw[h] & 0xFFu), spread4_byte((aw[h] >> 8) & 0xFFu),
-                                                   spread4_byte((aw[h] >> 16) & 0xFFu), spread4_byte(aw[h] >> 24))
-                                      : make_uint4(spread2_half(aw[2 * h] & 0xFFFFu), spread2_half(aw[2 * h] >> 16),
-                                                   spread2_half(aw[2 * h + 1] & 0xFFFFu), spread2_half(aw[2 * h + 1] >> 16));
-                    }
-                    at++;
+        for (int h = 0; h < kSub; h++)
+            if (keep[h]) {
+                uint32_t le[kWords];
+#pragma unroll
+                for (int w = 0; w < kWords; w++) {
+                    uint32_t c[PLANES];
+#pragma unroll
+                    for (int p = 0; p < PLANES; p++) c[p] = cnt[p][j].v[h * kWords + w];
+                    le[w] = count_le<PLANES>(c, T);
                 }
-            n_live += (uint32_t)__shfl((int)incl, kWave - 1, kWave);
-        }
+                uint4 mask;
+                if (FOLD == 1) mask = make_uint4(le[0], le[kWords > 1 ? 1 : 0], le[kWords > 2 ? 2 : 0], le[kWords > 3 ? 3 : 0]);
+                else if (FOLD == 2) mask = make_uint4(spread2_half(le[0] & 0xFFFFu), spread2_half(le[0] >> 16),
+                                                      spread2_half(le[kWords > 1 ? 1 : 0] & 0xFFFFu), spread2_half(le[kWords > 1 ? 1 : 0] >> 16));
+                else mask = make_uint4(spread4_byte(le[0] & 0xFFu), spread4_byte((le[0] >> 8) & 0xFFu),
+                                       spread4_byte((le[0] >> 16) & 0xFFu), spread4_byte(le[0] >> 24));
+                Q.live_chunks[(size_t)item * P.max_live + at] =
+                    (uint16_t)((cidx[j] * (uint32_t)kSub + (uint32_t)h) | (lvl[j][h] << kChunkIdBits));
+                Q.live_mask[(size_t)item * P.max_live + at] = mask;
+                at++;
+            }
+        n_before += total;
     }
-    if (lane == 0) {
-        if (n_live == 0) out_counts[item] = 0;
-        if (n_live > P.max_live) {
-            Q.slow_items[atomicAdd(&Q.counters[1], 1u)] = item;
-            n_live = kSlowItem;
-        }
-        Q.live_n[item] = n_live;
-    }
+    if (lane == 0) Q.live_n[item] = n_store | (lo << 8) | (T << 16);
 }
 
 template <int CPL, int PLANES, int DEPTH, int FOLD = 1>
@@ -385,17 +502,19 @@ __device__ __forceinline__ void emit_best_group(const DevParams &P, const u128 (
 }
 
 // Rows of a 16-byte column per lane -- rows g0 .. g0+r-1 of the samples s0 .. s1-1; every lane has its own row-id
-// list (its item's).  The counters carry on from what they hold.
+// list (its item's).  The counters carry on from what they hold; a lane that is not `act` keeps its counters as they
+// are (its ring stays all ones: no misses), and a wave without an active lane skips the stream.
 template <int PLANES>
 __device__ __forceinline__ uint32_t stream_column(const DevParams &P, const uint8_t *__restrict__ rows,
                                                   const uint32_t *__restrict__ list, uint32_t g0, uint32_t r, uint32_t off,
                                                   bool act, u128 (&cnt)[PLANES], uint32_t s0, uint32_t s1) {
     const uint32_t n_rows = (s1 - s0) * r;
+    if (__ballot(act) == 0) return 0u;
     u128 ring[kDepthCol];
 #pragma unroll
     for (int d = 0; d < kDepthCol; d++)
 #pragma unroll
-        for (int x = 0; x < 4; x++) ring[d].v[x] = 0;
+        for (int x = 0; x < 4; x++) ring[d].v[x] = 0xFFFFFFFFu;
     uint32_t ps = s0, pg = 0;
     auto fetch = [&](u128 &dst) {
         if (act) dst = load_chunk(rows + (size_t)list[ps * P.G + g0 + pg] * P.pitch + off);
@@ -463,26 +582,53 @@ __global__ __launch_bounds__(kWave, BMF_RECOUNT_OCC) void bmf_recount_kernel(Dev
         if (have)
             for (uint32_t i = gl; i < n_ids; i += LIVE) list[i] = row_lists[(size_t)item * P.list_len + i];
         __syncthreads();
+        const uint32_t lv_lo = (n_live >> 8) & 0xFFu, lv_T = (n_live >> 16) & 0xFFu;
+        n_live &= 0xFFu;
         const bool mine = gl < n_live;
-        const uint32_t chunk = mine ? Q.live_chunks[(size_t)item * LIVE + gl] : 0u;
+        const uint32_t entry = mine ? Q.live_chunks[(size_t)item * LIVE + gl] : 0u;
+        const uint32_t chunk = entry & ((1u << kChunkIdBits) - 1u), level = entry >> kChunkIdBits;
+        constexpr uint32_t kSat = (1u << PLANES) - 1u;
+        const uint64_t gmask = ((LIVE == 64 ? 0ull : (1ull << (LIVE % 64))) - 1ull) << (lane - gl);
         u128 cnt[PLANES];
-        auto reset = [&](bool on) {
+        // counters at "no sample seen": `bias` misses short of saturation (bits that are no bucket: saturated)
+        auto reset = [&](bool on, uint32_t bias) {
 #pragma unroll
             for (int x = 0; x < 4; x++) {
                 const uint32_t bits = on ? bucket_mask(P, chunk, x) : 0u;
 #pragma unroll
-                for (int p = 0; p < PLANES; p++) cnt[p].v[x] = start_word<PLANES>(P, bits, p);
+                for (int p = 0; p < PLANES; p++) cnt[p].v[x] = ~bits | (((bias >> p) & 1u) ? 0xFFFFFFFFu : 0u);
             }
         };
-        reset(mine);
-        bool act = mine;
-        // First one row per sample that pass 1 has NOT seen, on its own: its miss count is an independent lower
-        // bound, so a chunk that survived pass 1 by chance (probability ~1e-4 per bucket) dies here with the
-        // same odds, for at most S sectors instead of G*S.  Only the buckets pass 1 left alive matter (its mask), so
-        // the stream is cut in two: after F + 2 samples three chunks in four are already dead and skip the rest.
-        // Not worth a dependent round of loads when there is next to nothing to kill.
-        if (P.pass1_rows + 1u < P.G) {
-            const bool thin = mine && n_live > 3u;
+        const uint32_t bias_f = kSat - P.F;          // saturated = F misses or more (start_word's bias)
+        // Round A: the chunks at the item's lowest level, exactly.  Their best count bounds m* from above.
+        const bool in_a = mine && level == lv_lo;
+        reset(in_a, bias_f);
+        loads += stream_column<PLANES>(P, rows, list, 0u, P.G, chunk * 16u, in_a, cnt, 0u, P.S);
+        uint32_t best;
+        {
+            uint32_t c[PLANES][4];
+#pragma unroll
+            for (int p = 0; p < PLANES; p++)
+#pragma unroll
+                for (int x = 0; x < 4; x++) c[p][x] = cnt[p].v[x];
+            best = min_level<PLANES, 4>(c);          // lanes outside round A are saturated
+        }
+#pragma unroll
+        for (int o = 1; o < LIVE; o <<= 1) best = min(best, (uint32_t)__shfl_xor((int)best, o, LIVE));
+        const uint32_t U = min(best, kSat - 1u);      // every bucket with a lower bound above U is dead
+        // a chunk the result may need was not kept by pass 1: the slow kernel takes the item
+        const bool to_slow = have && U > lv_T;
+        if (to_slow && gl == 0) Q.slow_items[atomicAdd(&Q.counters[1], 1u)] = item;
+        // Round B: the other chunks with a level <= U.  First one row per sample that pass 1 has NOT seen, on its own:
+        // its miss count is an independent lower bound, so a chunk that survived pass 1 by chance dies here for at most
+        // S sectors instead of G*S -- judged against U, on the buckets pass 1 left at or below T (its mask), in two
+        // stretches: after F + 2 samples three chunks in four are already dead and skip the rest.  Not worth a
+        // dependent round of loads when there is next to nothing to kill.
+        const bool in_b = mine && !to_slow && level > lv_lo && level <= U;
+        bool act = in_b;
+        const uint32_t n_b = (uint32_t)__popcll(__ballot(in_b) & gmask);
+        if (P.pass1_rows + 1u < P.G && __ballot(in_b && n_b > 3u) != 0) {
+            const bool thin = in_b && n_b > 3u;
             uint4 mask = make_uint4(0, 0, 0, 0);
             if (thin) mask = Q.live_mask[(size_t)item * LIVE + gl];
             auto still_alive = [&]() {
@@ -492,15 +638,17 @@ __global__ __launch_bounds__(kWave, BMF_RECOUNT_OCC) void bmf_recount_kernel(Dev
                 return ((alive_word<1, PLANES>(c1, 0, 0) & mask.x) | (alive_word<1, PLANES>(c1, 0, 1) & mask.y) |
                         (alive_word<1, PLANES>(c1, 0, 2) & mask.z) | (alive_word<1, PLANES>(c1, 0, 3) & mask.w)) != 0;
             };
+            // biased so that saturation is "more than U misses" (U is in pass 1's biased terms: U - bias_f misses)
+            if (thin) reset(true, kSat - 1u - (U - bias_f));
             const uint32_t s_cut = min(P.S, P.F + 2u);
             loads += stream_column<PLANES>(P, rows, list, P.pass1_rows, 1u, chunk * 16u, thin, cnt, 0u, s_cut);
             const bool more = thin && still_alive();
             loads += stream_column<PLANES>(P, rows, list, P.pass1_rows, 1u, chunk * 16u, more, cnt, s_cut, P.S);
             if (thin) act = more && still_alive();
-            reset(act);
         }
+        if (in_b) reset(act, bias_f);                 // survivors start their exact count; the killed ones are saturated
         loads += stream_column<PLANES>(P, rows, list, 0u, P.G, chunk * 16u, act, cnt, 0u, P.S);
-        emit_best_group<PLANES, LIVE>(P, cnt, have, item, lane, chunk, out_counts, out_buckets);
+        emit_best_group<PLANES, LIVE>(P, cnt, have && !to_slow, item, lane, chunk, out_counts, out_buckets);
     }
     // statistics only (bmf_batch_pass2_counts): one atomic per wave, not per item
     recounted = wave_sum(recounted);
