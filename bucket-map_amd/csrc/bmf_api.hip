@@ -7,8 +7,7 @@
 #include "bmf_vote2.hip.h"
 #include "bmi_kernels.hip.h"
 #include "bm_hip_util.h"
-
-#include <hipcub/hipcub.hpp>
+#include "bm_scan.hip.h"
 
 #include "../../include/bmf.h"
 
@@ -1412,11 +1411,9 @@ int bmf_batch_download(bmf_ctx *c, bmf_batch *b, uint32_t *out_counts, uint32_t 
     // only that (2 x 4 B per window + the ids instead of 2 x max_candidates x 4 B per window).
     const size_t n_items = 2 * n;
     const uint32_t mc = c->p.max_candidates;
-    HIP_TRY(b->offsets.need(n_items));
-    size_t tmp_bytes = 0;
-    HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, b->counts.p, b->offsets.p, (int)n_items, c->stream));
-    HIP_TRY(b->scan_tmp.need(tmp_bytes));
-    HIP_TRY(hipcub::DeviceScan::ExclusiveSum(b->scan_tmp.p, tmp_bytes, b->counts.p, b->offsets.p, (int)n_items, c->stream));
+    HIP_TRY(b->offsets.need(n_items + 1));
+    HIP_TRY(b->scan_tmp.need(bmscan::tmp_elems(n_items) * sizeof(uint32_t)));
+    HIP_TRY(bmscan::exclusive_sum<uint32_t>(b->counts.p, b->offsets.p, n_items, reinterpret_cast<uint32_t *>(b->scan_tmp.p), c->stream));
     HIP_TRY(hipMemcpyAsync(out_counts, b->counts.p, n_items * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     uint64_t total = 0;
@@ -1519,7 +1516,7 @@ static int map_piece_issue(bmf_ctx *c, bmf_ctx::MapSlot *sl, const uint8_t *base
     b->n_bytes = span;
     HIP_TRY(batch_reserve(c, b, n, span));
     const size_t n_items = 2 * (size_t)n, mc = c->p.max_candidates;
-    HIP_TRY(b->offsets.need(n_items));
+    HIP_TRY(b->offsets.need(n_items + 1));
     HIP_TRY(sl->pack.need(1 + n_items * mc));
     HIP_TRY(pinned_need(reinterpret_cast<void **>(&sl->h_views), &sl->h_views_cap, (size_t)n * 12));
     sl->ids_copied = kIdsPerItemCopied * n_items;
@@ -1540,10 +1537,8 @@ static int map_piece_issue(bmf_ctx *c, bmf_ctx::MapSlot *sl, const uint8_t *base
     if (rc != BMF_OK) return rc;
     // The dense result buffer (max_candidates slots per list) holds < 1 id per list on average: exclusive-scan
     // the counts, gather the defined ids behind their total, copy only counts + the head of that.
-    size_t tmp_bytes = 0;
-    HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, b->counts.p, b->offsets.p, (int)n_items, c->stream));
-    HIP_TRY(b->scan_tmp.need(tmp_bytes));
-    HIP_TRY(hipcub::DeviceScan::ExclusiveSum(b->scan_tmp.p, tmp_bytes, b->counts.p, b->offsets.p, (int)n_items, c->stream));
+    HIP_TRY(b->scan_tmp.need(bmscan::tmp_elems(n_items) * sizeof(uint32_t)));
+    HIP_TRY(bmscan::exclusive_sum<uint32_t>(b->counts.p, b->offsets.p, n_items, reinterpret_cast<uint32_t *>(b->scan_tmp.p), c->stream));
     hipLaunchKernelGGL(bmf::bmf_compact_total_kernel, dim3((unsigned)((n_items + 255) / 256)), dim3(256), 0, c->stream,
                        b->counts.p, b->offsets.p, b->buckets.p, (uint32_t)mc, (uint32_t)n_items, sl->pack.p);
     HIP_TRY(hipGetLastError());

@@ -1,12 +1,11 @@
 // bml_api.hip -- C ABI (include/bml.h) over the locator-scan kernels in bml_kernels.hip.h.
-// Host side only: chunking of candidates per bucket, buffers, the occurrence sort (hipCUB radix sort,
-// a library primitive) and the automatic re-run when the occurrence buffer was too small.
+// Host side only: chunking of candidates per bucket, buffers, the two replay kernels (one thread or one workgroup per
+// candidate) and the automatic re-run when the occurrence buffer was too small.  No device-wide sort: the scan kernel
+// writes every candidate's occurrences to a segment of their own.
 #include "bml_kernels.hip.h"
 #include "bm_hip_util.h"
 
 #include "../../include/bml.h"
-
-#include <hipcub/hipcub.hpp>
 
 #include <math.h>
 #include <stdarg.h>
@@ -76,11 +75,14 @@ struct bml_ctx {
     bool loaded = false;
     uint32_t n_buckets = 0;
     std::vector<uint32_t> h_bucket_len;
-    DevBuf<uint8_t> genome, lut, pair_rc, sort_tmp;
-    DevBuf<uint64_t> bucket_start, occ_a, occ_b;
-    DevBuf<uint32_t> bucket_len, sample_hash, seg_len, pair_window, prop_votes, out_votes;
+    DevBuf<uint8_t> genome, lut, pair_rc;
+    DevBuf<uint64_t> bucket_start, occ_a, occ_b, cand_start;
+    DevBuf<uint32_t> bucket_len, sample_hash, seg_len, pair_window, out_votes;
+    DevBuf<uint32_t> cand_count, heavy, n_heavy, heavy_votes, heavy_bitmaps;
+    int n_cu = 256;
+    uint32_t last_heavy = 0;
     DevBuf<uint16_t> sample_pos;
-    DevBuf<int32_t> prop_key, out_offset;
+    DevBuf<int32_t> out_offset;
     DevBuf<bml::Chunk> chunks;
     // bml_sample_windows
     DevBuf<uint8_t> s_bases, s_quals, s_has;
@@ -105,8 +107,10 @@ int bml_create(const bml_params *params, bml_ctx **out) {
     if (p.k == 0 || p.k > 16) return fail(BML_ERR_ARG, "k must be in 1..16 (got %u)", p.k);
     if (p.num_samples == 0 || p.num_samples > 64) return fail(BML_ERR_UNSUPPORTED, "num_samples must be in 1..64");
     if (p.max_bucket_bases == 0) return fail(BML_ERR_ARG, "max_bucket_bases must be > 0");
+    if (p.max_bucket_bases >= (1u << 20)) return fail(BML_ERR_UNSUPPORTED, "buckets of 2^20 bases or more are not supported");   // 20-bit offsets in the light replay's sort keys
     const uint32_t max_words = (p.max_bucket_bases + 15u) / 16u;
-    const size_t lds = bml::scan_lds_bytes(max_words);
+    const uint32_t max_pairs = (bml::kTableSlots / 2) / p.num_samples;
+    const size_t lds = bml::scan_lds_bytes(max_words, max_pairs);
     if (lds > 160 * 1024) return fail(BML_ERR_UNSUPPORTED, "buckets of %u bases do not fit the 160 KiB LDS", p.max_bucket_bases);
     int n_dev = 0;
     HIP_TRY(hipGetDeviceCount(&n_dev));
@@ -119,8 +123,9 @@ int bml_create(const bml_params *params, bml_ctx **out) {
     c->lp.allowed_mismatch = p.allowed_mismatch;
     c->lp.allowed_indel = p.allowed_indel;
     c->lp.max_words = max_words;
+    c->lp.max_pairs = max_pairs;
     c->scan_lds = lds;
-    c->max_pairs_per_chunk = (bml::kTableSlots / 2) / p.num_samples;
+    c->max_pairs_per_chunk = max_pairs;
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     for (int i = 0; i < 4 && e == hipSuccess; i++) e = hipEventCreate(&c->ev[i]);
     if (e == hipSuccess && lds > 48 * 1024)
@@ -130,6 +135,9 @@ int bml_create(const bml_params *params, bml_ctx **out) {
     if (e == hipSuccess) e = c->lut.need(256);
     if (e == hipSuccess) e = hipMemcpy(c->lut.p, lut, 256, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = c->occ_count.need(1);
+    if (e == hipSuccess) e = c->n_heavy.need(1);
+    if (e == hipSuccess) (void)hipDeviceGetAttribute(&c->n_cu, hipDeviceAttributeMultiprocessorCount, p.device);
+    if (c->n_cu <= 0) c->n_cu = 256;
     if (e != hipSuccess) {
         bml_destroy(c);
         return fail(BML_ERR_HIP, "bml_create: %s", hipGetErrorString(e));
@@ -142,10 +150,12 @@ void bml_destroy(bml_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->p.device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    c->genome.release(); c->lut.release(); c->pair_rc.release(); c->sort_tmp.release();
-    c->bucket_start.release(); c->occ_a.release(); c->occ_b.release();
+    c->genome.release(); c->lut.release(); c->pair_rc.release();
+    c->bucket_start.release(); c->occ_a.release(); c->occ_b.release(); c->cand_start.release();
+    c->cand_count.release(); c->heavy.release(); c->n_heavy.release(); c->heavy_votes.release();
+    c->heavy_bitmaps.release();
     c->bucket_len.release(); c->sample_hash.release(); c->seg_len.release(); c->pair_window.release();
-    c->prop_votes.release(); c->out_votes.release(); c->sample_pos.release(); c->prop_key.release();
+    c->out_votes.release(); c->sample_pos.release();
     c->out_offset.release(); c->chunks.release(); c->occ_count.release();
     c->s_bases.release(); c->s_quals.release(); c->s_has.release(); c->s_win_start.release(); c->s_win_len.release();
     c->s_hash.release(); c->s_pos.release(); c->s_table.release();
@@ -228,7 +238,9 @@ int bml_load_genome(bml_ctx *c, const uint8_t *bases, uint64_t n_bases, const ui
             return fail(BML_ERR_ARG, "bucket %u lies outside the genome buffer", b);
     }
     HIP_TRY(hipSetDevice(c->p.device));
-    HIP_TRY(c->genome.need((size_t)n_bases));
+    // the scan kernel packs a bucket with aligned 16-byte loads, which read up to 15 bytes past its last base
+    HIP_TRY(c->genome.need((size_t)n_bases + 64));
+    HIP_TRY(hipMemset(c->genome.p + n_bases, 'A', 64));
     HIP_TRY(c->bucket_start.need(n_buckets));
     HIP_TRY(c->bucket_len.need(n_buckets));
     if (n_bases) HIP_TRY(hipMemcpy(c->genome.p, bases, (size_t)n_bases, hipMemcpyHostToDevice));
@@ -287,6 +299,8 @@ int bml_locate(bml_ctx *c, const uint32_t *sample_hash, const uint16_t *sample_p
     HIP_TRY(hipMemcpyAsync(c->chunks.p, chunks.data(), chunks.size() * sizeof(bml::Chunk), hipMemcpyHostToDevice, c->stream));
 
     // occurrence buffer: a true match per sample is the common case; grow and re-scan when it was too small
+    HIP_TRY(c->cand_count.need(n_pairs));
+    HIP_TRY(c->cand_start.need(n_pairs));
     unsigned long long cap = std::max<unsigned long long>(1ull << 20, 2ull * n_pairs * p);
     unsigned long long n_occ = 0;
     for (int attempt = 0; attempt < 3; attempt++) {
@@ -295,7 +309,7 @@ int bml_locate(bml_ctx *c, const uint32_t *sample_hash, const uint16_t *sample_p
         HIP_TRY(hipEventRecord(c->ev[0], c->stream));
         hipLaunchKernelGGL(bml::bml_scan_kernel, dim3((unsigned)chunks.size()), dim3(bml::kScanThreads), c->scan_lds, c->stream,
                            c->lp, c->genome.p, c->bucket_start.p, c->bucket_len.p, c->lut.p, c->chunks.p, c->sample_hash.p,
-                           c->pair_window.p, c->pair_rc.p, c->occ_a.p, c->occ_count.p, cap);
+                           c->pair_window.p, c->pair_rc.p, c->occ_a.p, c->occ_count.p, cap, c->cand_start.p, c->cand_count.p);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(c->ev[1], c->stream));
         HIP_TRY(hipMemcpyAsync(&n_occ, c->occ_count.p, sizeof n_occ, hipMemcpyDeviceToHost, c->stream));
@@ -305,22 +319,42 @@ int bml_locate(bml_ctx *c, const uint32_t *sample_hash, const uint16_t *sample_p
         if (attempt == 2) return fail(BML_ERR_HIP, "occurrence buffer still too small after re-scan");
     }
     c->last_occ = n_occ;
-    // sort: (candidate, sample in processing order) ascending, offset descending (encoded in the key)
-    const uint64_t *sorted = c->occ_a.p;
-    if (n_occ > 1) {
-        HIP_TRY(c->occ_b.need((size_t)n_occ));
-        size_t tmp_bytes = 0;
-        HIP_TRY(hipcub::DeviceRadixSort::SortKeys(nullptr, tmp_bytes, c->occ_a.p, c->occ_b.p, (int64_t)n_occ, 0, 64, c->stream));
-        HIP_TRY(c->sort_tmp.need(tmp_bytes));
-        HIP_TRY(hipcub::DeviceRadixSort::SortKeys(c->sort_tmp.p, tmp_bytes, c->occ_a.p, c->occ_b.p, (int64_t)n_occ, 0, 64, c->stream));
-        sorted = c->occ_b.p;
-    }
+    HIP_TRY(c->heavy.need(n_pairs));
+    HIP_TRY(hipMemsetAsync(c->n_heavy.p, 0, sizeof(uint32_t), c->stream));
     HIP_TRY(hipEventRecord(c->ev[2], c->stream));
-    HIP_TRY(c->prop_key.need((size_t)n_occ));
-    HIP_TRY(c->prop_votes.need((size_t)n_occ));
-    hipLaunchKernelGGL(bml::bml_replay_kernel, dim3((n_pairs + bml::kThreads - 1) / bml::kThreads), dim3(bml::kThreads), 0,
-                       c->stream, c->lp, sorted, (uint64_t)n_occ, c->sample_pos.p, c->seg_len.p, c->pair_window.p,
-                       c->pair_rc.p, n_pairs, c->prop_key.p, c->prop_votes.p, c->out_offset.p, c->out_votes.p);
+    {
+        auto light = [&](auto kernel, unsigned threads) {
+            hipLaunchKernelGGL(kernel, dim3((n_pairs + threads - 1) / threads), dim3(threads), 0, c->stream, c->lp, c->occ_a.p,
+                               c->cand_start.p, c->cand_count.p, c->sample_pos.p, c->seg_len.p, c->pair_window.p, c->pair_rc.p,
+                               n_pairs, c->out_offset.p, c->out_votes.p, c->heavy.p, c->n_heavy.p);
+        };
+        if (p <= 10) light(bml::bml_replay_light_kernel<16, 256>, 256);
+        else if (p <= 24) light(bml::bml_replay_light_kernel<32, 256>, 256);
+        else light(bml::bml_replay_light_kernel<64, 128>, 128);
+    }
+    HIP_TRY(hipGetLastError());
+    // candidates with more occurrences than the light kernel takes (repeats): one workgroup each, dense bitmaps of the start positions
+    uint32_t n_heavy = 0;
+    HIP_TRY(hipMemcpyAsync(&n_heavy, c->n_heavy.p, sizeof n_heavy, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->last_heavy = n_heavy;
+    if (n_heavy) {
+        uint32_t max_seg = 0;
+        for (uint32_t w = 0; w < n_windows; w++) max_seg = std::max(max_seg, seg_len[w]);
+        const uint32_t range = c->p.max_bucket_bases + max_seg, words = (range + 31u) / 32u;
+        const unsigned grid = (unsigned)std::min<uint32_t>(n_heavy, 2u * (uint32_t)c->n_cu);
+        const size_t lds = (size_t)3 * words * sizeof(uint32_t);
+        const bool in_lds = lds <= 150 * 1024;
+        if (in_lds && lds > 48 * 1024)
+            HIP_TRY(bmhip::raise_dynamic_lds(reinterpret_cast<const void *>(bml::bml_replay_heavy_kernel), lds));
+        HIP_TRY(c->heavy_votes.need((size_t)grid * range));
+        if (!in_lds) HIP_TRY(c->heavy_bitmaps.need((size_t)grid * 3 * words));
+        HIP_TRY(c->occ_b.need((size_t)n_occ));
+        const bml::HeavyScratch hs{c->heavy_votes.p, c->heavy_bitmaps.p, c->occ_b.p};
+        hipLaunchKernelGGL(bml::bml_replay_heavy_kernel, dim3(grid), dim3(bml::kThreads), in_lds ? lds : 0, c->stream, c->lp,
+                           c->occ_a.p, c->cand_start.p, c->cand_count.p, c->sample_pos.p, c->seg_len.p, c->pair_window.p, c->pair_rc.p, c->heavy.p,
+                           c->n_heavy.p, range, max_seg, in_lds ? 1u : 0u, hs, c->out_offset.p, c->out_votes.p);
+    }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(c->ev[3], c->stream));
     HIP_TRY(hipMemcpyAsync(out_offset, c->out_offset.p, (size_t)n_pairs * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
@@ -336,6 +370,12 @@ int bml_last_stats(bml_ctx *c, float *ms_scan, float *ms_sort, float *ms_replay,
     if (ms_sort) *ms_sort = c->ms[1];
     if (ms_replay) *ms_replay = c->ms[2];
     if (n_occurrences) *n_occurrences = c->last_occ;
+    return BML_OK;
+}
+
+int bml_last_heavy_candidates(bml_ctx *c, uint32_t *n_heavy) {
+    if (!c || !n_heavy) return fail(BML_ERR_ARG, "bml_last_heavy_candidates: null argument");
+    *n_heavy = c->last_heavy;
     return BML_OK;
 }
 

@@ -6,11 +6,20 @@
 //                       table and emits (target, offset) occurrences -- the work the reference does by
 //                       building an unordered_multimap of ALL k-mers per bucket
 //                       (bucket_locator.h:162-177) and calling equal_range per sample (:246).
-//   (sort)            : occurrences are sorted by (candidate, sample in processing order, offset
-//                       descending) -- the order libstdc++'s equal_range yields equal keys.
-//   bml_replay_kernel : one thread per candidate replays _find_offset's order-dependent vote
-//                       (bucket_locator.h:233-288) over its sorted occurrences; its std::map<int,unsigned>
-//                       lives as a sorted array in a scratch slice as long as the candidate's occurrences.
+//                       A candidate belongs to ONE chunk, so the workgroup counts its candidates' occurrences,
+//                       reserves one stretch of the occurrence buffer and writes every candidate's occurrences
+//                       to a segment of their own in it (from the LDS staging area; a chunk with more occurrences
+//                       than that holds -- repeats -- scans its bucket a second time and writes them directly).
+//                       No device-wide sort or grouping pass: the order inside a segment is settled per candidate.
+//   bml_replay_light_kernel : one thread per candidate with at most kLightMax occurrences: orders them by
+//                       (sample in processing order, offset descending) -- the order libstdc++'s equal_range
+//                       yields equal keys -- and replays _find_offset's order-dependent vote
+//                       (bucket_locator.h:233-288); its std::map<int,unsigned> is a sorted array, all in the thread's
+//                       LDS slice.
+//   bml_replay_heavy_kernel : one workgroup per candidate with more occurrences (a k-mer of a tandem repeat, a
+//                       satellite or a poly-A stretch occurs thousands of times in a bucket, and a sorted array
+//                       costs O(n^2) then): the same vote over DENSE bitmaps of the start positions, which needs no
+//                       sorting at all -- see the kernel.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -41,10 +50,12 @@ struct LocParams {
     uint32_t k, p;
     int32_t allowed_mismatch, allowed_indel;
     uint32_t max_words;        // LDS words reserved for the packed bucket
+    uint32_t max_pairs;        // most candidates a chunk holds
 };
 
-__host__ __device__ inline size_t scan_lds_bytes(uint32_t max_words) {
-    return (size_t)kLdsOcc * 8 + 16 + (size_t)kFilterWords * 4 + (size_t)kTableSlots * 8 + ((size_t)max_words + 4) * 4;
+__host__ __device__ inline size_t scan_lds_bytes(uint32_t max_words, uint32_t max_pairs) {
+    return (size_t)kLdsOcc * 8 + 16 + (size_t)kFilterWords * 4 + (size_t)kTableSlots * 8 + (size_t)((2u * max_pairs + 3u) & ~3u) * 4 +
+           ((size_t)max_words + 4) * 4;
 }
 
 __device__ __forceinline__ uint32_t filter_bit(uint32_t h) { return (h * 2246822519u) >> 16; }   // 16 bits
@@ -62,13 +73,15 @@ __device__ __forceinline__ uint32_t hash_reverse_complement(uint32_t h, uint32_t
 __device__ __forceinline__ uint32_t slot_of(uint32_t h) { return (h * 2654435761u) >> 20; }   // 12 bits
 
 // LDS layout (all dynamic, 16-byte aligned base): locc[kLdsOcc] u64 | gbase u64 | lds_cnt u32 (+pad) |
-//                       filter[kFilterWords] u32 | tkey[kTableSlots] u32 | ttgt[kTableSlots] u32 | packed[max_words + 4] u32
+//                       filter[kFilterWords] u32 | tkey[kTableSlots] u32 | ttgt[kTableSlots] u32 |
+//                       pcnt[max_pairs] u32 (occurrences per candidate of the chunk, then their first place) |
+//                       pfill[max_pairs] u32 | packed[max_words + 4] u32
 __global__ __launch_bounds__(kScanThreads) void bml_scan_kernel(
     LocParams P, const uint8_t *__restrict__ genome, const uint64_t *__restrict__ bucket_start,
     const uint32_t *__restrict__ bucket_len, const uint8_t *__restrict__ dna4_lut, const Chunk *__restrict__ chunks,
     const uint32_t *__restrict__ sample_hash, const uint32_t *__restrict__ pair_window,
     const uint8_t *__restrict__ pair_rc, uint64_t *__restrict__ occ_keys, unsigned long long *__restrict__ occ_count,
-    unsigned long long occ_cap) {
+    unsigned long long occ_cap, uint64_t *__restrict__ cand_start, uint32_t *__restrict__ cand_count) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint64_t *locc = reinterpret_cast<uint64_t *>(smem);
     unsigned long long &gbase = *reinterpret_cast<unsigned long long *>(locc + kLdsOcc);
@@ -76,7 +89,9 @@ __global__ __launch_bounds__(kScanThreads) void bml_scan_kernel(
     uint32_t *filter = reinterpret_cast<uint32_t *>(locc + kLdsOcc + 2);
     uint32_t *tkey = filter + kFilterWords;
     uint32_t *ttgt = tkey + kTableSlots;
-    uint32_t *packed = ttgt + kTableSlots;
+    uint32_t *pcnt = ttgt + kTableSlots;
+    uint32_t *pfill = pcnt + P.max_pairs;
+    uint32_t *packed = pcnt + ((2u * P.max_pairs + 3u) & ~3u);
     (void)dna4_lut;
 
     const Chunk ch = chunks[blockIdx.x];
@@ -87,6 +102,7 @@ __global__ __launch_bounds__(kScanThreads) void bml_scan_kernel(
     if (tid == 0) lds_cnt = 0;
     for (uint32_t s = tid; s < kTableSlots; s += kScanThreads) ttgt[s] = kEmpty;
     for (uint32_t s = tid; s < kFilterWords; s += kScanThreads) filter[s] = 0;
+    for (uint32_t s = tid; s < ch.pair_count; s += kScanThreads) pcnt[s] = pfill[s] = 0;
 
     // 2-bit packing, first base in the most significant bits of each word: one aligned 16-byte load per stream
     // word (the bucket may start at any byte: the stream starts at the aligned chunk that holds its first base,
@@ -121,96 +137,144 @@ __global__ __launch_bounds__(kScanThreads) void bml_scan_kernel(
     }
     __syncthreads();
 
-    // scan every k-mer of the bucket (bucket_locator.h:172-176 enumerates the same k-mers)
+    // scan every k-mer of the bucket (bucket_locator.h:172-176 enumerates the same k-mers); found(t, j) for every
+    // k-mer j that target t asked for
     const uint32_t nk = nb >= P.k ? nb - P.k + 1u : 0u;
     const uint32_t kmask = P.k >= 16 ? 0xFFFFFFFFu : ((1u << (2u * P.k)) - 1u);
-    for (uint32_t j = tid; j < nk; j += kScanThreads) {
-        const uint32_t at = shift + j;
-        const uint64_t two = ((uint64_t)packed[at >> 4] << 32) | packed[(at >> 4) + 1];
-        const uint32_t h = (uint32_t)(two >> (64u - 2u * (at & 15u) - 2u * P.k)) & kmask;
-        const uint32_t fb = filter_bit(h);
-        if (!((filter[fb >> 5] >> (fb & 31u)) & 1u)) continue;          // nobody asked for this k-mer
-        uint32_t slot = slot_of(h), t;
-        while ((t = ttgt[slot]) != kEmpty) {
-            if (tkey[slot] == h) {
-                const uint32_t target = (ch.pair_begin + t / P.p) * P.p + t % P.p;
-                const uint64_t key = ((uint64_t)target << 32) | (uint32_t)(0x7FFFFFFFu - j);   // offset descending
-                const uint32_t at_l = atomicAdd(&lds_cnt, 1u);
-                if (at_l < kLdsOcc) {
-                    locc[at_l] = key;
-                } else {   // rare (repeats): past the LDS staging area, go to HBM directly
-                    const unsigned long long g = atomicAdd(occ_count, 1ull);
-                    if (g < occ_cap) occ_keys[g] = key;
-                }
+    auto scan_bucket = [&](auto found) {
+        for (uint32_t j = tid; j < nk; j += kScanThreads) {
+            const uint32_t at = shift + j;
+            const uint64_t two = ((uint64_t)packed[at >> 4] << 32) | packed[(at >> 4) + 1];
+            const uint32_t h = (uint32_t)(two >> (64u - 2u * (at & 15u) - 2u * P.k)) & kmask;
+            const uint32_t fb = filter_bit(h);
+            if (!((filter[fb >> 5] >> (fb & 31u)) & 1u)) continue;          // nobody asked for this k-mer
+            uint32_t slot = slot_of(h), t;
+            while ((t = ttgt[slot]) != kEmpty) {
+                if (tkey[slot] == h) found(t, j);
+                slot = (slot + 1u) & (kTableSlots - 1u);
             }
-            slot = (slot + 1u) & (kTableSlots - 1u);
+        }
+    };
+    auto key_of = [&](uint32_t t, uint32_t j) {                             // (target, offset descending)
+        return ((uint64_t)((ch.pair_begin + t / P.p) * P.p + t % P.p) << 32) | (uint32_t)(0x7FFFFFFFu - j);
+    };
+    scan_bucket([&](uint32_t t, uint32_t j) {
+        atomicAdd(&pcnt[t / P.p], 1u);
+        const uint32_t at_l = atomicAdd(&lds_cnt, 1u);
+        if (at_l < kLdsOcc) locc[at_l] = key_of(t, j);
+    });
+    __syncthreads();
+    // one stretch of the occurrence buffer for the chunk, one segment in it per candidate
+    const uint32_t total = lds_cnt;
+    if (tid == 0) gbase = atomicAdd(occ_count, (unsigned long long)total);
+    if (tid < 64) {                                                         // exclusive prefix of pcnt, one wave
+        uint32_t carry = 0;
+        for (uint32_t c0 = 0; c0 < ch.pair_count; c0 += 64) {
+            const uint32_t c = c0 + tid, v = c < ch.pair_count ? pcnt[c] : 0u;
+            uint32_t incl = v;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const uint32_t u = __shfl_up(incl, o, 64);
+                if (tid >= (uint32_t)o) incl += u;
+            }
+            if (c < ch.pair_count) {
+                cand_count[ch.pair_begin + c] = v;
+                pcnt[c] = carry + incl - v;
+            }
+            carry += (uint32_t)__shfl((int)incl, 63, 64);
         }
     }
     __syncthreads();
-    const uint32_t n_l = lds_cnt < kLdsOcc ? lds_cnt : kLdsOcc;
-    if (tid == 0 && n_l) gbase = atomicAdd(occ_count, (unsigned long long)n_l);
-    __syncthreads();
-    for (uint32_t i = tid; i < n_l; i += kScanThreads)
-        if (gbase + i < occ_cap) occ_keys[gbase + i] = locc[i];
-}
-
-__device__ __forceinline__ uint64_t lower_bound_key(const uint64_t *keys, uint64_t n, uint64_t v) {
-    uint64_t lo = 0, hi = n;
-    while (lo < hi) {
-        const uint64_t mid = lo + (hi - lo) / 2;
-        if (keys[mid] < v) lo = mid + 1; else hi = mid;
+    const bool fits = gbase + total <= occ_cap;                            // else the host grows the buffer and scans again
+    for (uint32_t c = tid; c < ch.pair_count; c += kScanThreads) cand_start[ch.pair_begin + c] = gbase + pcnt[c];
+    if (!fits) return;
+    if (total <= kLdsOcc) {
+        for (uint32_t i = tid; i < total; i += kScanThreads) {
+            const uint64_t key = locc[i];
+            const uint32_t c = (uint32_t)(key >> 32) / P.p - ch.pair_begin;
+            occ_keys[gbase + pcnt[c] + atomicAdd(&pfill[c], 1u)] = key;
+        }
+    } else {                                                               // repeats: more than the staging area holds
+        scan_bucket([&](uint32_t t, uint32_t j) {
+            const uint32_t c = t / P.p;
+            occ_keys[gbase + pcnt[c] + atomicAdd(&pfill[c], 1u)] = key_of(t, j);
+        });
     }
-    return lo;
 }
 
-// _find_offset (bucket_locator.h:209-290) for one candidate per thread.
-__global__ __launch_bounds__(kThreads) void bml_replay_kernel(
-    LocParams P, const uint64_t *__restrict__ keys, uint64_t n_occ, const uint16_t *__restrict__ sample_pos,
-    const uint32_t *__restrict__ seg_len, const uint32_t *__restrict__ pair_window, const uint8_t *__restrict__ pair_rc,
-    uint32_t n_pairs, int32_t *__restrict__ prop_key, uint32_t *__restrict__ prop_votes, int32_t *__restrict__ out_offset,
-    uint32_t *__restrict__ out_votes) {
-    const uint32_t pair = blockIdx.x * kThreads + threadIdx.x;
+// Occurrences a candidate may have for the one-thread replay: room for one true occurrence per sample and a few chance
+// ones -- 16 up to p = 10 samples, 32 up to p = 24, 64 beyond (the LDS slice grows with it: fewer threads per CU).
+
+// _find_offset (bucket_locator.h:209-290) for one candidate per thread: candidates with at most kLightMax occurrences
+// (the common case: one true occurrence per sample and a few chance ones).  The others go to `heavy`.
+// Everything a thread touches more than once lives in its LDS slice -- its occurrences as 32-bit sort keys
+// (sample << 20 | 0xFFFFF - offset: buckets are shorter than 2^20 bases, bml_create), the proposal map as a sorted
+// array of starts with 8-bit votes -- laid out entry-major ([entry][thread]), so that the threads of a wave that are
+// at the same entry hit 64 different banks.  9 bytes x 16 entries x 256 threads = 36 KB per workgroup.
+template <int kLightMax, int kLightThreads>
+__global__ __launch_bounds__(kLightThreads) void bml_replay_light_kernel(
+    LocParams P, const uint64_t *__restrict__ keys, const uint64_t *__restrict__ cand_start, const uint32_t *__restrict__ cand_count,
+    const uint16_t *__restrict__ sample_pos, const uint32_t *__restrict__ seg_len, const uint32_t *__restrict__ pair_window,
+    const uint8_t *__restrict__ pair_rc, uint32_t n_pairs, int32_t *__restrict__ out_offset, uint32_t *__restrict__ out_votes,
+    uint32_t *__restrict__ heavy, uint32_t *__restrict__ n_heavy) {
+    __shared__ uint32_t s_key[kLightMax][kLightThreads];
+    __shared__ int32_t s_pk[kLightMax][kLightThreads];
+    __shared__ uint8_t s_pv[kLightMax][kLightThreads];
+    const uint32_t tid = threadIdx.x, pair = blockIdx.x * kLightThreads + tid;
     if (pair >= n_pairs) return;
-    const uint64_t first = lower_bound_key(keys, n_occ, (uint64_t)pair * P.p << 32);
-    const uint64_t end = lower_bound_key(keys, n_occ, (uint64_t)(pair + 1u) * P.p << 32);
-    int32_t *pk = prop_key + first;      // the vote_counter map: sorted keys ...
-    uint32_t *pv = prop_votes + first;   // ... and their votes; never more entries than occurrences
+    const uint32_t n = cand_count[pair];
+    if (n > kLightMax) {
+        heavy[atomicAdd(n_heavy, 1u)] = pair;
+        return;
+    }
+    // (sample in processing order) ascending, offset descending: insertion sort while loading
+    const uint64_t *mine = keys + cand_start[pair];
+    for (uint32_t a = 0; a < n; a++) {
+        const uint64_t key = mine[a];
+        const uint32_t v = (((uint32_t)(key >> 32) - pair * P.p) << 20) | (0xFFFFFu - (0x7FFFFFFFu - (uint32_t)key));
+        uint32_t b = a;
+        while (b > 0 && s_key[b - 1][tid] > v) {
+            s_key[b][tid] = s_key[b - 1][tid];
+            b--;
+        }
+        s_key[b][tid] = v;
+    }
     uint32_t np = 0;
     const uint32_t w = pair_window[pair];
     const bool rc = pair_rc[pair] != 0;
     const uint32_t length = seg_len[w];
-    uint64_t cur = first;
-    for (uint32_t i = 0; i < P.p; i++) {
+    uint32_t cur = 0;
+    for (uint32_t i = 0; i < P.p && cur < n; i++) {
+        if ((s_key[cur][tid] >> 20) != i) continue;               // no occurrence of this sample
         uint32_t idx = sample_pos[(size_t)w * P.p + (rc ? P.p - 1u - i : i)];
         if (rc) idx = length - P.k - idx;                        // :242 where the k-mer starts on the other strand
-        const uint32_t target = pair * P.p + i;
         const bool was_empty = np == 0;                          // :247 evaluated once per sample
-        while (cur < end && (uint32_t)(keys[cur] >> 32) == target) {
-            const uint32_t occ = 0x7FFFFFFFu - (uint32_t)keys[cur];
+        while (cur < n && (s_key[cur][tid] >> 20) == i) {
+            const uint32_t occ = 0xFFFFFu - (s_key[cur][tid] & 0xFFFFFu);
             const int32_t position = (int32_t)(occ - idx);       // :250,257 (unsigned arithmetic, wraps like int)
-            // lower_bound(position - indel) .. upper_bound(position + indel)  (:259-260)
-            uint32_t lb = 0, ub = np;
+            // lower_bound(position - indel) .. upper_bound(position + indel)  (:259-260); the map is small: linear
+            uint32_t lb = 0, ub = 0;
             if (!was_empty) {
                 const int32_t lo_key = position - P.allowed_indel, hi_key = position + P.allowed_indel;
-                uint32_t a = 0, b = np;
-                while (a < b) { const uint32_t m = (a + b) / 2; if (pk[m] < lo_key) a = m + 1; else b = m; }
-                lb = a;
-                b = np;
-                while (a < b) { const uint32_t m = (a + b) / 2; if (pk[m] <= hi_key) a = m + 1; else b = m; }
-                ub = a;
+                while (lb < np && s_pk[lb][tid] < lo_key) lb++;
+                ub = lb;
+                while (ub < np && s_pk[ub][tid] <= hi_key) ub++;
             }
             if (!was_empty && lb < ub) {
-                for (uint32_t v = lb; v < ub; v++) pv[v]++;     // :262-265 every proposal in range gets the vote
+                for (uint32_t v = lb; v < ub; v++) s_pv[v][tid]++;     // :262-265 every proposal in range gets the vote
             } else {
                 // vote_counter[position]++ (:251,269): insert, or increment when the key exists
-                uint32_t a = 0, b = np;
-                while (a < b) { const uint32_t m = (a + b) / 2; if (pk[m] < position) a = m + 1; else b = m; }
-                if (a < np && pk[a] == position) {
-                    pv[a]++;
+                uint32_t a = 0;
+                while (a < np && s_pk[a][tid] < position) a++;
+                if (a < np && s_pk[a][tid] == position) {
+                    s_pv[a][tid]++;
                 } else {
-                    for (uint32_t v = np; v > a; v--) { pk[v] = pk[v - 1]; pv[v] = pv[v - 1]; }
-                    pk[a] = position;
-                    pv[a] = 1;
+                    for (uint32_t v = np; v > a; v--) {
+                        s_pk[v][tid] = s_pk[v - 1][tid];
+                        s_pv[v][tid] = s_pv[v - 1][tid];
+                    }
+                    s_pk[a][tid] = position;
+                    s_pv[a][tid] = 1;
                     np++;
                 }
             }
@@ -222,15 +286,203 @@ __global__ __launch_bounds__(kThreads) void bml_replay_kernel(
     if (np) {
         uint32_t best = 0;                                       // :281-283 most votes, ties -> smallest offset
         for (uint32_t v = 1; v < np; v++)
-            if (pv[v] > pv[best]) best = v;
+            if (s_pv[v][tid] > s_pv[best][tid]) best = v;
         // :284 unsigned >= int compares as unsigned
-        if (pv[best] >= (uint32_t)((int32_t)P.p - P.allowed_mismatch) && pk[best] >= 0) {
-            off = pk[best];
-            votes = pv[best];
+        if ((uint32_t)s_pv[best][tid] >= (uint32_t)((int32_t)P.p - P.allowed_mismatch) && s_pk[best][tid] >= 0) {
+            off = s_pk[best][tid];
+            votes = s_pv[best][tid];
         }
     }
     out_offset[pair] = off;
     out_votes[pair] = votes;
+}
+
+// _find_offset for a candidate with MANY occurrences, one workgroup per candidate, without sorting anything.
+//
+// The reference keeps its proposals in a std::map and, for every occurrence of sample i in descending offset order:
+// if the map was empty when the sample began the start position is inserted; else every proposal within +-indel of
+// the start gets a vote, or -- if there is none -- the start is inserted with one vote (:247-270).  Start positions
+// lie in [-window length, bucket length): a DENSE bitmap `exists` of that range and a dense vote array replace the
+// map, and the sample's occurrences are handled in four order-free steps:
+//   1. against the proposals that existed BEFORE the sample (K): every occurrence votes for each of them within
+//      +-indel (atomic adds); an occurrence that finds none is marked in `fresh`.
+//   2. the occurrences in `fresh`, highest first (= the reference's processing order): one becomes a new proposal iff
+//      the proposal inserted last lies more than indel above it (proposals made earlier in this sample are all above
+//      it, the last one is the nearest; those of K are not in range by step 1).  One wave walks the bitmap.
+//   3. every occurrence votes for the NEW proposal within indel ABOVE it, if there is one (new proposals are more than
+//      indel apart, so at most one): that proposal was inserted before the occurrence was processed.  Proposals below
+//      an occurrence were inserted after it and get nothing from it.
+//   4. the new proposals join `exists`.
+// Winner: most votes, ties -> smallest start (:281-283), accepted as in the light kernel.
+// Bitmaps live in LDS when 3 of them fit (`lds_bitmaps`), else in the workgroup's global scratch.
+struct HeavyScratch {
+    uint32_t *votes;        // per workgroup: range entries
+    uint32_t *bitmaps;      // per workgroup: 3 x words (used when the bitmaps do not fit LDS)
+    uint64_t *by_sample;    // the candidate's occurrences grouped by sample: same layout as the grouped buffer
+};
+
+__global__ __launch_bounds__(kThreads) void bml_replay_heavy_kernel(
+    LocParams P, const uint64_t *__restrict__ keys, const uint64_t *__restrict__ cand_start,
+    const uint32_t *__restrict__ cand_count, const uint16_t *__restrict__ sample_pos, const uint32_t *__restrict__ seg_len,
+    const uint32_t *__restrict__ pair_window,
+    const uint8_t *__restrict__ pair_rc, const uint32_t *__restrict__ heavy, const uint32_t *__restrict__ n_heavy,
+    uint32_t range, uint32_t bias, uint32_t lds_bitmaps, HeavyScratch S, int32_t *__restrict__ out_offset,
+    uint32_t *__restrict__ out_votes) {
+    extern __shared__ uint32_t heavy_lds[];
+    __shared__ uint32_t s_hist[65], s_cursor[64], s_fresh, s_new, s_np;
+    __shared__ unsigned long long s_best;
+    const uint32_t tid = threadIdx.x, words = (range + 31u) / 32u;
+    uint32_t *exists = lds_bitmaps ? heavy_lds : S.bitmaps + (size_t)blockIdx.x * 3u * words;
+    uint32_t *fresh = exists + words, *fnew = fresh + words;
+    uint32_t *votes = S.votes + (size_t)blockIdx.x * range;
+    const int32_t d = P.allowed_indel;
+    const uint32_t total = *n_heavy;
+    // any bit of bm set in [lo, hi] (inclusive, clamped to the range)?  op(pos) for every set bit.
+    auto for_bits = [&](const uint32_t *bm, int64_t lo, int64_t hi, auto op) {
+        if (lo < 0) lo = 0;
+        if (hi >= (int64_t)range) hi = (int64_t)range - 1;
+        if (lo > hi) return false;
+        bool any = false;
+        for (uint32_t wd = (uint32_t)lo >> 5; wd <= ((uint32_t)hi >> 5); wd++) {
+            uint32_t bits = bm[wd];
+            if (wd == ((uint32_t)lo >> 5)) bits &= 0xFFFFFFFFu << ((uint32_t)lo & 31u);
+            if (wd == ((uint32_t)hi >> 5)) bits &= 0xFFFFFFFFu >> (31u - ((uint32_t)hi & 31u));
+            while (bits) {
+                any = true;
+                op(wd * 32u + (uint32_t)__builtin_ctz(bits));
+                bits &= bits - 1u;
+            }
+        }
+        return any;
+    };
+    for (uint32_t h = blockIdx.x; h < total; h += gridDim.x) {
+        const uint32_t pair = heavy[h];
+        const uint64_t first = cand_start[pair], n = cand_count[pair];
+        const uint32_t w = pair_window[pair];
+        const bool rc = pair_rc[pair] != 0;
+        const uint32_t length = seg_len[w];
+        // 0. the occurrences grouped by sample (counting sort on the sample number)
+        for (uint32_t i = tid; i < 65u; i += kThreads) s_hist[i] = 0;
+        for (uint32_t i = tid; i < words; i += kThreads) exists[i] = fresh[i] = fnew[i] = 0;
+        if (tid == 0) s_np = 0;
+        __syncthreads();
+        for (uint64_t i = tid; i < n; i += kThreads) atomicAdd(&s_hist[(uint32_t)(keys[first + i] >> 32) - pair * P.p + 1u], 1u);
+        __syncthreads();
+        if (tid == 0) {
+            for (uint32_t i = 0; i < P.p; i++) s_hist[i + 1] += s_hist[i];          // s_hist[i] = first occurrence of sample i
+            for (uint32_t i = 0; i < P.p; i++) s_cursor[i] = s_hist[i];
+        }
+        __syncthreads();
+        uint64_t *mine = S.by_sample + first;
+        for (uint64_t i = tid; i < n; i += kThreads) {
+            const uint64_t key = keys[first + i];
+            mine[atomicAdd(&s_cursor[(uint32_t)(key >> 32) - pair * P.p], 1u)] = key;
+        }
+        __syncthreads();
+        for (uint32_t i = 0; i < P.p; i++) {
+            uint32_t idx = sample_pos[(size_t)w * P.p + (rc ? P.p - 1u - i : i)];
+            if (rc) idx = length - P.k - idx;
+            const uint32_t o0 = s_hist[i], o1 = s_hist[i + 1];
+            if (o0 == o1) continue;                                  // (uniform: s_hist is shared)
+            // start position of an occurrence, shifted by `bias` into [0, range)
+            auto start_of = [&](uint64_t key) { return (uint32_t)((int32_t)((0x7FFFFFFFu - (uint32_t)key) - idx) + (int32_t)bias); };
+            if (s_np == 0) {                                         // :247-251 the map was empty: every start goes in
+                __syncthreads();
+                for (uint32_t o = o0 + tid; o < o1; o += kThreads) {
+                    const uint32_t pos = start_of(mine[o]);
+                    atomicOr(&exists[pos >> 5], 1u << (pos & 31u));
+                    votes[pos] = 1;
+                }
+                if (tid == 0) s_np = o1 - o0;
+                __syncthreads();
+                continue;
+            }
+            if (tid == 0) s_fresh = s_new = 0;
+            __syncthreads();
+            // 1. votes for the proposals that were there before this sample
+            for (uint32_t o = o0 + tid; o < o1; o += kThreads) {
+                const uint32_t pos = start_of(mine[o]);
+                const bool hit = for_bits(exists, (int64_t)pos - d, (int64_t)pos + d, [&](uint32_t at) { atomicAdd(&votes[at], 1u); });
+                if (!hit) {
+                    atomicOr(&fresh[pos >> 5], 1u << (pos & 31u));
+                    atomicAdd(&s_fresh, 1u);
+                }
+            }
+            __syncthreads();
+            if (s_fresh == 0) continue;
+            // 2. new proposals among the fresh starts, highest first (one wave)
+            if (tid < 64) {
+                int64_t limit = (int64_t)range - 1;                  // the next proposal lies at or below `limit`
+                uint32_t made = 0;
+                while (limit >= 0) {
+                    // the 64 words at and below limit's word, lane l takes word (top - l)
+                    const int64_t top = limit >> 5, wd = top - (int64_t)tid;
+                    uint32_t bits = wd >= 0 ? fresh[wd] : 0u;
+                    if (tid == 0) bits &= 0xFFFFFFFFu >> (31u - ((uint32_t)limit & 31u));
+                    const uint64_t m = __ballot(bits != 0);
+                    if (m == 0) {
+                        limit = (top - 64) * 32 + 31;
+                        continue;
+                    }
+                    const int src = __builtin_ctzll(m);
+                    const uint32_t hb = 31u - (uint32_t)__builtin_clz((uint32_t)__shfl((int)bits, src, 64));
+                    const uint32_t pos = (uint32_t)(top - src) * 32u + hb;
+                    if (tid == 0) {
+                        fnew[pos >> 5] |= 1u << (pos & 31u);
+                        votes[pos] = 1;
+                    }
+                    made++;
+                    limit = (int64_t)pos - d - 1;                    // nothing within indel below a new proposal
+                }
+                if (tid == 0) s_new = made;
+            }
+            __syncthreads();
+            // 3. votes for the new proposal within indel above an occurrence
+            for (uint32_t o = o0 + tid; o < o1; o += kThreads) {
+                const uint32_t pos = start_of(mine[o]);
+                (void)for_bits(fnew, (int64_t)pos + 1, (int64_t)pos + d, [&](uint32_t at) { atomicAdd(&votes[at], 1u); });
+            }
+            __syncthreads();
+            // 4. the new proposals join the map
+            for (uint32_t wd = tid; wd < words; wd += kThreads) {
+                exists[wd] |= fnew[wd];
+                fresh[wd] = 0;
+                fnew[wd] = 0;
+            }
+            if (tid == 0) s_np += s_new;
+            __syncthreads();
+        }
+        // winner: most votes, ties -> smallest start
+        if (tid == 0) s_best = 0;
+        __syncthreads();
+        unsigned long long best = 0;
+        for (uint32_t wd = tid; wd < words; wd += kThreads) {
+            uint32_t bits = exists[wd];
+            while (bits) {
+                const uint32_t pos = wd * 32u + (uint32_t)__builtin_ctz(bits);
+                bits &= bits - 1u;
+                const unsigned long long cand = ((unsigned long long)votes[pos] << 32) | (0xFFFFFFFFu - pos);
+                best = cand > best ? cand : best;
+            }
+        }
+        atomicMax(&s_best, best);
+        __syncthreads();
+        if (tid == 0) {
+            int32_t off = -1;
+            uint32_t nv = 0;
+            if (s_best) {
+                const uint32_t v = (uint32_t)(s_best >> 32);
+                const int32_t key = (int32_t)(0xFFFFFFFFu - (uint32_t)s_best) - (int32_t)bias;
+                if (v >= (uint32_t)((int32_t)P.p - P.allowed_mismatch) && key >= 0) {
+                    off = key;
+                    nv = v;
+                }
+            }
+            out_offset[pair] = off;
+            out_votes[pair] = nv;
+        }
+        __syncthreads();
+    }
 }
 
 // --------------------------------------------------------------------------------------------------

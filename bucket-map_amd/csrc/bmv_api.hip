@@ -39,7 +39,7 @@ __global__ void bmv_gather_kernel(const uint32_t *__restrict__ ops_rev, uint32_t
 
 #include "../../include/bmv.h"
 
-#include <hipcub/hipcub.hpp>
+#include "bm_scan.hip.h"
 
 #include <stdarg.h>
 #include <stdio.h>
@@ -433,15 +433,11 @@ int bmv_align(bmv_ctx *c, const uint8_t *reads, uint64_t n_read_bytes, const uin
         uint32_t *ops_rev;
     };
     auto collect = [&](const std::vector<Piece> &pieces, uint32_t slots) -> int {
-        size_t tmp_bytes = 0;
-        HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, c->nops.p, c->offsets.p, (int)slots, c->stream));
-        HIP_TRY(c->scan_tmp.need(tmp_bytes));
-        HIP_TRY(hipcub::DeviceScan::ExclusiveSum(c->scan_tmp.p, tmp_bytes, c->nops.p, c->offsets.p, (int)slots, c->stream));
-        uint32_t last_off = 0, last_n = 0;                      // total = last offset + last count
-        HIP_TRY(hipMemcpyAsync(&last_off, c->offsets.p + (slots - 1u), 4, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipMemcpyAsync(&last_n, c->nops.p + (slots - 1u), 4, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c->scan_tmp.need(bmscan::tmp_elems(slots) * sizeof(uint32_t)));
+        HIP_TRY(bmscan::exclusive_sum<uint32_t>(c->nops.p, c->offsets.p, slots, reinterpret_cast<uint32_t *>(c->scan_tmp.p), c->stream));
+        uint32_t total = 0;                                     // the scan writes slots + 1 values: the last is the total
+        HIP_TRY(hipMemcpyAsync(&total, c->offsets.p + slots, 4, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
-        const uint32_t total = last_off + last_n;
         HIP_TRY(c->packed.need(with_headroom(total, c->packed.cap)));
         for (const Piece &pc : pieces) {
             hipLaunchKernelGGL(bmv::bmv_gather_kernel, dim3((pc.count + 31u) / 32u), dim3(256), 0, c->stream, pc.ops_rev,
@@ -487,7 +483,7 @@ int bmv_align(bmv_ctx *c, const uint8_t *reads, uint64_t n_read_bytes, const uin
         HIP_TRY(c->trace.need(with_headroom(sum_trace, c->trace.cap)));
         HIP_TRY(c->ops_rev.need(with_headroom(sum_ops, c->ops_rev.cap)));
         HIP_TRY(c->nops.need(with_headroom(n, c->nops.cap)));
-        HIP_TRY(c->offsets.need(with_headroom(n, c->offsets.cap)));
+        HIP_TRY(c->offsets.need(with_headroom((size_t)n + 1, c->offsets.cap)));
         HIP_TRY(hipEventRecord(c->ev0, c->stream));             // the uploads above
         std::vector<Piece> pieces;
         size_t trace_at = 0, ops_at = 0;
@@ -514,7 +510,7 @@ int bmv_align(bmv_ctx *c, const uint8_t *reads, uint64_t n_read_bytes, const uin
         HIP_TRY(c->trace.need(with_headroom(need_trace, c->trace.cap)));
         HIP_TRY(c->ops_rev.need(with_headroom(need_ops, c->ops_rev.cap)));
         HIP_TRY(c->nops.need(with_headroom(need_slots, c->nops.cap)));
-        HIP_TRY(c->offsets.need(with_headroom(need_slots, c->offsets.cap)));
+        HIP_TRY(c->offsets.need(with_headroom((size_t)need_slots + 1, c->offsets.cap)));
         for (const Plan &pl : plans) {
             for (uint64_t first = 0; first < pl.members; first += pl.chunk) {
                 const uint32_t count = (uint32_t)std::min<uint64_t>(pl.chunk, pl.members - first);

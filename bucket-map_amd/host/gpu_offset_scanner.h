@@ -105,7 +105,7 @@ public:
             n += occ[d];
         }
         std::cerr << "[BENCHMARK]\tGPU locator scan: " << n_pairs << " candidates, " << n << " k-mer occurrences; scan " << a
-                  << " ms, sort " << b << " ms, vote replay " << c << " ms" << (D > 1 ? " (slowest of " + std::to_string(D) + " devices)" : "")
+                  << " ms, grouping " << b << " ms, vote replay " << c << " ms" << (D > 1 ? " (slowest of " + std::to_string(D) + " devices)" : "")
                   << ".\n";
     }
 };

@@ -31,6 +31,7 @@ SYMBOLS = {
     "bml_sample_windows": (C.c_int, [C.c_void_p, _u8p, _u8p, C.c_uint64, _u64p, _u32p, C.c_uint32, C.c_uint32, _u32p, _u16p, _u8p]),
     "bml_locate": (C.c_int, [C.c_void_p, _u32p, _u16p, _u32p, C.c_uint32, _u32p, _u32p, _u8p, C.c_uint32, _i32p, _u32p]),
     "bml_last_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float), _u64p]),
+    "bml_last_heavy_candidates": (C.c_int, [C.c_void_p, _u32p]),
 }
 _ready = False
 
@@ -101,7 +102,9 @@ class LocatorScan:
     def stats(self) -> dict:
         a, b, c, n = C.c_float(), C.c_float(), C.c_float(), C.c_uint64()
         _check(lib().bml_last_stats(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(n)))
-        return {"ms_scan": a.value, "ms_sort": b.value, "ms_replay": c.value, "occurrences": n.value}
+        h = C.c_uint32()
+        _check(lib().bml_last_heavy_candidates(self._h, C.byref(h)))
+        return {"ms_scan": a.value, "ms_sort": b.value, "ms_replay": c.value, "occurrences": n.value, "heavy_candidates": h.value}
 
     def close(self) -> None:
         if self._h:

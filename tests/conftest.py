@@ -46,9 +46,9 @@ class Case:
 
     def __init__(self, *, record_lengths, bucket_len, read_len, n_reads, q=9, k=12, samples=15, error_rate=0.4,
                  distinguishability=0.5, base_quality=25, kmer_frac=1.0, sub=0.002, ins=0.00025, dele=0.00025,
-                 noisy_quals=False, seed=20240001, extra_buckets=0, sim_read_len=None):
+                 noisy_quals=False, seed=20240001, extra_buckets=0, sim_read_len=None, profile="uniform"):
         from bucket_map_amd import host
-        self.genome = host.Genome.synth(seed, record_lengths)
+        self.genome = host.Genome.synth(seed, record_lengths, profile=profile)
         self.bucket_len, self.read_len = bucket_len, read_len
         # NB as the reference's CMake awk rule gives it (can exceed the kept buckets) + optional padding
         self.num_buckets = self.genome.awk_bucket_num(bucket_len) + extra_buckets

@@ -8,11 +8,14 @@
   configs[4]  the same genome at bucket_len 262 144 with the reference's long-read flags
               (benchmark/long_read/benchmark_map.sh:25: -s 30 -e 0.9 -n 0.1 -l 12 -p 20 -u 5), 10-kbp ONT-profile reads
               through `bucketmap_align`: == the oracle-backed tool on a handful (the CPU verifier fills a 440 MB matrix per
-              alignment), properties and the --gpus split on 1 500.  One flag differs from the script: -k 10.  A
-              262 444-base bucket of a UNIFORM random genome holds 63 % of all 4^9 9-mers, so no row of a q = 9 index
-              has the 50 % zeros the distinguishability filter asks for (q_gram_mapper.h:189-196) and the reference's
-              algorithm -- oracle and GPU alike, checked -- maps nothing; real genomes are skewed enough for q = 9.
-              With q = 10 a bucket holds 22 % of the 10-mers and the path is exercised.
+              alignment), properties and the --gpus split on 1 500.  The script's flags VERBATIM, default -k 9 included:
+              the genome is bm_synth.h's genome-like one (skewed q-gram spectrum, repeat families, satellites), on which
+              about half of the q = 9 rows pass the distinguishability threshold at this bucket length -- a 262 444-base
+              bucket of a UNIFORM random genome holds 63 % of all 4^9 9-mers, no row passes and nothing maps (round 2 had
+              to run this configuration with -k 10 for that reason).
+  configs[1]  on the genome-like genome as well: 1.70 Gbp, 100 000 x 300 bp, every read GPU == oracle with the default,
+              the measured pruning form and the forced two-pass kernels (the uniform-genome form of configs[1] lives in
+              test_cli_gpu.py and bench.py).
 
 Synthetic data as SURVEY.md 8d prescribes (real genomes are not available offline).
 """
@@ -35,9 +38,12 @@ TOOL = {"gpu": os.path.join(ROOT, "bucket-map_amd", "bucketmap"), "oracle": os.p
 
 
 def run(exe, args, cwd, env=None):
+    import time
+    t0 = time.perf_counter()
     r = subprocess.run([TOOL[exe], *args], cwd=str(cwd), capture_output=True, text=True,
                        env=None if env is None else {**os.environ, **env})
     assert r.returncode == 0, r.stderr[-2000:]
+    print(f"[run] {exe} {' '.join(a for a in args if a.endswith(('.sam', '.fastq')) or a == '-x')}: {time.perf_counter() - t0:.1f} s", flush=True)
     return r.stderr
 
 
@@ -169,6 +175,49 @@ def test_config3_grch38_like_full_index(grch38_like):
         f.close()
 
 
+def test_config1_on_a_genome_like_genome():
+    """BASELINE configs[1] geometry on the skewed, repetitive genome: what the filter's data-dependent branches see on
+    real data -- rows that fail the distinguishability threshold, reads in repeats (ties, > 30 candidates, rejections),
+    items with hundreds of live chunks for the pruning kernels."""
+    import bench
+    import bucket_map_amd as bma
+    from bucket_map_amd import host
+    from oracle import oracle_c
+    genome = host.Genome.synth(20240001, bench.egu_like_record_lengths(1_701_312_507), 16, profile="genome")
+    nb = genome.awk_bucket_num(65536)
+    cli = dict(read_len=300)
+    k2i = host.select_qgrams(9)
+    flat, _ = genome.flat()
+    bstart, blen = genome.bucket_views(65536, 300)
+    filters = three_kernels(nb, cli, lambda f: f.build_index(flat, bstart, blen, k2i))
+    del flat
+    rows = filters[0].index_download()
+    zeros = filters[0].zeros()
+    share = (zeros >= int(np.float32(0.5) * np.float32(nb))).mean()
+    assert 0.90 < share < 0.985, share                                   # reference log on GRCh38: 95.8 % (bucketmap_3_map.log:8)
+    reads = host.Reads(genome, 65536, 300, 300, 100_000, seed=20240003, threads=16)
+    ws, wl, _, _ = bma.windows_for_reads(reads.offsets, 300)
+    ora = oracle_c.Index(oracle_c.params_from_cli(nb, **cli), rows, k2i)
+    c_ref, b_ref, rows_ref = oracle_map_windows(ora, reads.bases, reads.quals, ws, wl)
+    for f, what in zip(filters, ("default", "pruned (measured form)", "two-pass forced")):
+        for again in (0, 1):                                             # (the first pruned call is the one that tunes)
+            c, b = f.map_windows(reads.bases, reads.quals, ws, wl)
+            assert_same_candidates(c_ref, b_ref, c, b, f"genome-like Egu, 100 000 reads, {what}, call {again}")
+    batch = filters[0].batch(reads.bases, reads.quals, ws, wl)
+    batch.run()
+    assert batch.rows_anded() == rows_ref
+    batch.close()
+    mapped = (c_ref.sum(axis=1) > 0).mean()
+    s = reads.truth_rc.astype(np.int64)
+    i = np.arange(reads.n)
+    own, valid = b_ref[i, s], np.arange(b_ref.shape[2])[None, :] < c_ref[i, s][:, None]
+    recovered = ((own == reads.truth_bucket[:, None]) & valid).any(axis=1).mean()
+    assert 0.9 < mapped < 0.9999 and recovered > 0.9, (mapped, recovered)     # some reads sit in repeats: not all map
+    assert (c_ref.max(axis=1) > 1).mean() > 0.01                              # ... and some tie across buckets
+    for f in filters:
+        f.close()
+
+
 def parse_sam(path):
     recs = []
     for line in open(path):
@@ -178,11 +227,13 @@ def parse_sam(path):
     return recs
 
 
-def test_config4_long_reads_bucketmap_align(grch38_like, tmp_path):
+def test_config4_long_reads_bucketmap_align(tmp_path):
+    import bench
     from bucket_map_amd import host
-    genome = grch38_like
+    genome = host.Genome.synth(20240001, bench.workload_record_lengths("grch38", 3_100_000_000), 16, profile="genome")
     genome.write_fasta(str(tmp_path / "g.fa"))
-    flags = ["--genome", "g.fa", "--bucket-len", "262144", "-f", "1", "-k", "10", "-s", "30", "-e", "0.9", "-n", "0.1", "-l", "12", "-p", "20",
+    # bucket_map/benchmark/long_read/benchmark_map.sh:25, verbatim (-k stays at its default, 9)
+    flags = ["--genome", "g.fa", "--bucket-len", "262144", "-f", "1", "-s", "30", "-e", "0.9", "-n", "0.1", "-l", "12", "-p", "20",
              "-u", "5", "--version-check", "0"]
     err = run("gpu_align", ["-x", "-i", "idx", *flags], tmp_path)
     nb = genome.awk_bucket_num(262144)

@@ -156,6 +156,25 @@ def test_gpu_scan_equals_oracle(name, kw):
     assert st["occurrences"] >= (o_ref >= 0).sum()
     if "motif" in kw:
         assert st["occurrences"] > 20 * len(case["pb"])          # repeats really produce many occurrences
+        assert st["heavy_candidates"] > 0.3 * len(case["pb"])    # ... and their candidates take the dense-bitmap kernel
+    else:
+        assert st["heavy_candidates"] < 0.05 * len(case["pb"])   # one thread each (the light kernel's room grows with p)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bucket_len,read_len,indel", [(262144, 300, 30), (300000, 40000, 700)])
+def test_gpu_scan_heavy_candidates_at_long_read_geometry(bucket_len, read_len, indel):
+    """BASELINE configs[4]'s bucket length with satellite-like content: a 171-base monomer fills the bucket, every sampled
+    k-mer occurs ~1 500 times, a candidate has tens of thousands of occurrences.  (One thread per candidate and a sorted
+    array took minutes here.)  Second case: windows so long that the three start-position bitmaps no longer fit LDS and live
+    in the workgroup's global scratch."""
+    rng = np.random.default_rng(bucket_len)
+    case = make_case(rng, n_buckets=2, bucket_len=bucket_len, read_len=read_len, n_reads=12, p=20, motif=171, sub=0.02)
+    mismatch = 18                                                # -e 0.9 x -p 20 (benchmark/long_read/benchmark_map.sh:25)
+    o_ref, v_ref = oracle(case, mismatch, indel)
+    o_got, v_got, st = gpu_scan(case, mismatch, indel)
+    assert np.array_equal(o_ref, o_got) and np.array_equal(v_ref, v_got)
+    assert st["heavy_candidates"] > 0.5 * len(case["pb"]) and st["occurrences"] > 5000 * len(case["pb"])
 
 
 @pytest.mark.gpu

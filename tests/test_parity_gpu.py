@@ -184,6 +184,52 @@ def test_folded_first_pass_and_its_fallback_guard():
     assert flt.info()["pass1_fold"] == 1                    # ... for good
     c, b = flt.map_windows(rd.bases, rd.quals, ws, wl)
     assert_same_candidates(c_ref, b_ref, c, b, "after the fallback")
+    # the fallback restores the WHOLE unfolded choice -- rows of the first pass and the recount kernel's lanes per item --
+    # so the context now does exactly what one that never had a folded copy does: same items through the recount and the
+    # slow kernels
+    batch = flt.batch(rd.bases, rd.quals, ws, wl)
+    batch.run()
+    after_trip = batch.pass2_counts()
+    batch.close()
+    flt.close()
+    os.environ["BMF_FOLD"] = "0"
+    try:
+        plain2 = case.gpu_filter(flags=bma.BMF_FLAG_EARLY_EXIT)
+    finally:
+        del os.environ["BMF_FOLD"]
+    batch = plain2.batch(rd.bases, rd.quals, ws, wl)
+    batch.run()
+    assert batch.pass2_counts() == after_trip
+    batch.close()
+    plain2.close()
+
+
+def test_pruning_form_is_measured_on_the_first_large_batch():
+    """tune_pruned: the first batch of at least BMF_TUNE_WINDOWS windows times every pruning form on its own first
+    windows and keeps the fastest; every form writes the oracle's outputs, before, while and after.  On a genome-like
+    genome (rows of very different densities, reads in repeats) so that the slow path and the level rounds all run."""
+    import bucket_map_amd as bma
+    case = Case(record_lengths=[9_000_000], bucket_len=1024, read_len=100, n_reads=9000, q=7, k=10, sub=0.01, seed=20240300,
+                profile="genome")
+    rd = case.reads
+    ws, wl, _ = _windows(case)
+    c_ref, b_ref, _ = oracle_map_windows(case.oracle_index(), rd.bases, rd.quals, ws, wl)
+    assert 0.001 < (c_ref.sum(axis=1) == 0).mean() < 0.9 and (c_ref.max(axis=1) > 1).mean() > 0.01   # repeats: ties, rejections
+    os.environ["BMF_TUNE_WINDOWS"] = "4096"
+    try:
+        flt = case.gpu_filter(flags=bma.BMF_FLAG_EARLY_EXIT)
+    finally:
+        del os.environ["BMF_TUNE_WINDOWS"]
+    before = flt.info()
+    c, b = flt.map_windows(rd.bases[: int(rd.offsets[1000])], rd.quals[: int(rd.offsets[1000])], ws[:1000], wl[:1000])
+    assert_same_candidates(c_ref[:1000], b_ref[:1000], c, b, "small batch: the model's choice")
+    assert flt.info() == before
+    c, b = flt.map_windows(rd.bases, rd.quals, ws, wl)                       # large enough: this call measures
+    assert_same_candidates(c_ref, b_ref, c, b, "the batch that tunes")
+    chosen = flt.info()
+    c, b = flt.map_windows(rd.bases, rd.quals, ws, wl)
+    assert_same_candidates(c_ref, b_ref, c, b, "after tuning")
+    assert flt.info() == chosen                                              # measured once
     flt.close()
 
 

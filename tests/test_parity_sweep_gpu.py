@@ -12,14 +12,21 @@ from conftest import assert_same_candidates
 pytestmark = pytest.mark.gpu
 
 
-def random_case(rng, *, nb, q, k, S, F, max_cand, kmer_frac, density, read_len, n_reads, threshold, minq):
+def random_case(rng, *, nb, q, k, S, F, max_cand, kmer_frac, density, read_len, n_reads, threshold, minq, skew=False):
     import bucket_map_amd as bma
     from oracle import oracle_c as oc
     n_q = 4 ** q
     kept = rng.random(n_q) < kmer_frac
     k2i = np.full(n_q, -1, np.int32)
     k2i[kept] = np.arange(kept.sum())
-    bits = rng.random((int(kept.sum()), nb)) < density
+    # rows of one density, or -- as on a real genome -- rows whose densities differ widely, over buckets some of which hold
+    # nearly every q-gram (the pruning kernels then see every level between "the read's own bucket" and "unrelated")
+    p_bit = np.full((int(kept.sum()), nb), density)
+    if skew:
+        p_bit = p_bit * (rng.random((p_bit.shape[0], 1)) ** 2 * 2.0)
+        hot = rng.random(nb) < 0.02
+        p_bit[:, hot] = np.maximum(p_bit[:, hot], rng.choice([0.6, 0.9, 0.99], (1, int(hot.sum()))))
+    bits = rng.random(p_bit.shape) < np.minimum(p_bit, 1.0)
     rows = np.packbits(bits, axis=1, bitorder="little")
     letters = np.frombuffer(b"ACGTacgtN", np.uint8)
     lens = rng.integers(0, read_len + 1, n_reads)
@@ -59,12 +66,14 @@ def random_case(rng, *, nb, q, k, S, F, max_cand, kmer_frac, density, read_len, 
         os.environ["BMF_MAX_LIVE"] = str(int(rng.choice([16, 32])))
         os.environ["BMF_FOLD"] = str(fold)
         os.environ["BMF_FOLD_ROWS"] = str(int(rng.integers(1, k - q + 2)))
+        if rng.random() < 0.3:
+            os.environ["BMF_ROW_ORDER"] = "far"            # a sample's rows far apart instead of sparsest first
         try:
             f2 = bma.Filter(bma.Params(num_buckets=nb, flags=bma.BMF_FLAG_EARLY_EXIT, **kw))
             f2.load_index(rows, k2i)
         finally:
-            for name in ("BMF_PASS1_ROWS", "BMF_MAX_LIVE", "BMF_FOLD", "BMF_FOLD_ROWS"):
-                del os.environ[name]
+            for name in ("BMF_PASS1_ROWS", "BMF_MAX_LIVE", "BMF_FOLD", "BMF_FOLD_ROWS", "BMF_ROW_ORDER"):
+                os.environ.pop(name, None)
         assert f2.info()["pass1_rows"] >= 1 and f2.info()["pass1_fold"] == (fold if fold else 1)
         # ... in one piece, or in slices whose recounts run on a second stream under the next slice's first pass
         os.environ["BMF_SLICES"] = str(int(rng.choice([1, 3, 8])))
@@ -73,6 +82,18 @@ def random_case(rng, *, nb, q, k, S, F, max_cand, kmer_frac, density, read_len, 
         finally:
             del os.environ["BMF_SLICES"]
         f2.close()
+        # ... and the form the library MEASURES to be the fastest on this batch (tune_pruned; threshold lowered to fit)
+        os.environ["BMF_TUNE_WINDOWS"] = "64"
+        try:
+            f3 = bma.Filter(bma.Params(num_buckets=nb, flags=bma.BMF_FLAG_EARLY_EXIT, **kw))
+            f3.load_index(rows, k2i)
+            c_t, b_t = f3.map_windows(bases, quals, ws, wl)
+            assert_same_candidates(c_ref, b_ref, c_t, b_t, "measured choice, the batch that tunes")
+            c_t, b_t = f3.map_windows(bases, quals, ws, wl)
+            assert_same_candidates(c_ref, b_ref, c_t, b_t, "measured choice, the batch after")
+            f3.close()
+        finally:
+            del os.environ["BMF_TUNE_WINDOWS"]
     return out
 
 
@@ -91,7 +112,7 @@ def test_random_parameters(seed):
     minq = int(rng.choice([0, 15 * k, 30 * k]))
     c_ref, b_ref, c_got, b_got, c_e, b_e, *two_pass = random_case(
         rng, nb=nb, q=q, k=k, S=S, F=F, max_cand=max_cand, kmer_frac=float(rng.choice([0.3, 1.0])), density=density,
-        read_len=read_len, n_reads=160, threshold=threshold, minq=minq)
+        read_len=read_len, n_reads=160, threshold=threshold, minq=minq, skew=bool(seed % 2))
     what = f"q={q} k={k} S={S} F={F} NB={nb} mc={max_cand} dens={density} L={read_len} thr={threshold} minq={minq}"
     assert_same_candidates(c_ref, b_ref, c_got, b_got, what)
     assert_same_candidates(c_ref, b_ref, c_e, b_e, what + " (early exit)")

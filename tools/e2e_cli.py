@@ -28,6 +28,8 @@ ap.add_argument("--kmer-frac", default="1", help="-f of the index (the reference
 ap.add_argument("--bucket-len", type=int, default=0, help="override the workload's bucket length (BASELINE configs[4]: 262144)")
 ap.add_argument("--index-seed", default="", help="-k of the index (default 9; 262144-bp buckets of a uniform genome need 10)")
 ap.add_argument("--gpus", default="", help="--gpus of the tool, e.g. 0,0,0")
+ap.add_argument("--profile", default="uniform", choices=["uniform", "genome"],
+                help="uniform = i.i.d. bases; genome = bm_synth.h's skewed, repetitive genome (q = 9 works at 262144-bp buckets)")
 ap.add_argument("--long", action="store_true",
                 help="the reference's long-read profile (benchmark/long_read/benchmark_map.sh:25): 10-kbp ONT-like reads "
                      "(sub 0.03, ins = del 0.025), -s 30 -e 0.9 -n 0.1 -l 12 -p 20 -u 5; the workload's 65536-bp buckets "
@@ -55,7 +57,7 @@ def say(msg):
 
 t = time.perf_counter()
 lens = [total_bp] if args.workload == "mini" else bench.workload_record_lengths(args.workload, total_bp)
-g = host.Genome.synth(20240001, lens, 16)
+g = host.Genome.synth(20240001, lens, 16, profile=args.profile)
 g.write_fasta(os.path.join(args.dir, "g.fa"))
 rd = host.Reads(g, bucket_len, read_len, sim_len, args.reads, seed=20240003, threads=16, **err)
 rd.write_fastq(os.path.join(args.dir, "reads"))
