@@ -18,10 +18,20 @@ Rank 0 prints ONE JSON line.  `roofline` prices the vote kernel: algorithmic byt
 reference ANDs, both orientations) x ceil(NB/8)   / mean kernel time from HIP events on
 the kernel's own stream.  `cpu_baseline` = the CPU oracle (a port: the reference cannot be built
 here) timed on one host core over a bounded sample of the same reads.
+
+Beside the headline, the default N = 1 run reports two more legs on the same card (never as `value`):
+  `skewed`                the same geometry on bm_synth.h's genome-LIKE genome (skewed q-gram spectrum, repeat families,
+                          satellites, segmental duplications): what the data-dependent parts of the path do on real data --
+                          rows that fail the distinguishability threshold, reads without a candidate, and the
+                          exact-pruning kernels, whose form the library measures on the first batch;
+  `roofline_large_index`  the vote kernel on a 4.6 GB index (2.29 Gbp at bucket_len 16 384, NB = 140 471), of which the
+                          256 MiB Infinity Cache can hold 6 %: the un-flattered HBM fraction (the 872 MB headline index
+                          is 31 % cache-resident).
 """
 import argparse
 import json
 import os
+import resource
 import sys
 import time
 
@@ -30,6 +40,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "bucket-map_amd", "python"))
 
 HBM_PEAK_GBPS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+INFINITY_CACHE_BYTES = 256 << 20
 
 WORKLOADS = {
     # name: (total genome bp, bucket_len, read_len, reads per GPU)
@@ -38,6 +49,7 @@ WORKLOADS = {
     "mini": (40_000_000, 65536, 300, 100_000),            # quick rehearsal
     "grch38": (3_100_000_000, 65536, 150, 1_000_000),     # configs[3] geometry (secondary data point)
 }
+LARGE_INDEX = dict(total_bp=2_293_760_000, bucket_len=16384)   # NB = 140 471: a 4.63 GB index, three 65 536-bucket slices
 
 # GRCh38 chromosome lengths in Mbp (1..22, X, Y): only their RATIOS are used
 GRCH38_MBP = [248.96, 242.19, 198.30, 190.21, 181.54, 170.81, 159.35, 145.14, 138.39, 133.80, 135.09, 133.28,
@@ -71,6 +83,232 @@ def egu_like_record_lengths(total):
     return big + [int(x) for x in small]
 
 
+def workload_record_lengths(workload, total_bp):
+    if workload == "ecoli":
+        return [total_bp]
+    if workload == "grch38":
+        return [int(total_bp * m / sum(GRCH38_MBP)) for m in GRCH38_MBP]
+    return egu_like_record_lengths(total_bp)
+
+
+def cli_params(params, read_len):
+    if params == "bench":       # benchmark/short_read/benchmark_map.sh:31
+        return dict(index_seed=9, query_seed=14, read_len=read_len, mapper_samples=20, max_error_rate=0.6, distinguishability=0.5,
+                    average_base_quality=10)
+    return dict(index_seed=9, query_seed=12, read_len=read_len, mapper_samples=15, max_error_rate=0.4, distinguishability=0.5,
+                average_base_quality=25)
+
+
+class Inputs:
+    """Synthetic genome + simulated reads of one workload, identical on every rank except the reads' seed."""
+
+    def __init__(self, workload, total_bp, bucket_len, read_len, n_reads, profile, threads, read_seed=20240003):
+        import bucket_map_amd as bma
+        from bucket_map_amd import host
+        self.workload, self.bucket_len, self.read_len, self.profile = workload, bucket_len, read_len, profile
+        t0 = time.perf_counter()
+        self.lens = workload_record_lengths(workload, total_bp)
+        self.genome = host.Genome.synth(20240001, self.lens, threads, profile=profile)
+        self.nb = self.genome.awk_bucket_num(bucket_len)
+        self.genome_s = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        self.reads = host.Reads(self.genome, bucket_len, read_len, read_len, n_reads, sub=0.002, ins=0.00025, dele=0.00025,
+                                seed=read_seed, threads=threads)
+        self.reads_s = time.perf_counter() - t0
+        self.win_start, self.win_len, _, _ = bma.windows_for_reads(self.reads.offsets, read_len)   # mapper::map's windowing
+        self.row_bytes = (self.nb + 7) >> 3
+
+    def new_filter(self, cli, device, flags, k2i):
+        """A filter context with the `-f` index built on the device (bmf_build_index: byte-identical to the host indexer,
+        tests/test_index_build_gpu.py)."""
+        import bucket_map_amd as bma
+        flt = bma.Filter(bma.Params.from_cli(self.nb, device=device, flags=flags, **cli))
+        flat, _ = self.genome.flat()
+        bstart, blen = self.genome.bucket_views(self.bucket_len, self.read_len)
+        flt.build_index(flat, bstart, blen, k2i)
+        return flt
+
+    def batch(self, flt, shard=None):
+        import numpy as np
+        rd = self.reads
+        if shard is None or (shard.start == 0 and shard.stop == rd.n):
+            return flt.batch(rd.bases, rd.quals, self.win_start, self.win_len)
+        lo, hi = int(rd.offsets[shard.start]), int(rd.offsets[shard.stop])
+        return flt.batch(rd.bases[lo:hi], rd.quals[lo:hi], self.win_start[shard] - np.uint64(lo), self.win_len[shard])
+
+
+def timed_steps(flt, batch, steps, warmup, barrier=None):
+    """`warmup` untimed runs, then `steps` timed ones.  Returns (wall seconds, per-step sample-kernel ms, per-step ms of
+    everything after it) -- the kernel times from HIP events on the kernels' own stream."""
+    for _ in range(warmup):
+        batch.run()
+    flt.sync()
+    if barrier:
+        barrier()
+    flt.profile_begin(steps)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        batch.run()
+    flt.sync()
+    elapsed = time.perf_counter() - t0
+    ms_sample, ms_rest = flt.profile_end(steps)
+    return elapsed, ms_sample, ms_rest
+
+
+def roofline_of(flt, inputs, rows_anded, n_rows, vote_ms):
+    """The vote kernel against the HBM peak: algorithmic row bytes (rows ANDed x ceil(NB/8)) / kernel time."""
+    algo = int(rows_anded) * inputs.row_bytes
+    achieved = algo / (vote_ms * 1e-3) / 1e9
+    index_bytes = (n_rows + 1) * flt.info()["row_pitch_bytes"]
+    # FETCH_SIZE and the algorithmic count include reads the 256 MiB Infinity Cache serves.  A uniformly gathered table of
+    # T bytes keeps about 256 MiB / T of itself there (MI355X_MICROARCH.md, Infinity Cache), so the HBM stacks themselves
+    # move roughly (1 - share) of the bytes.  No counter sits behind that cache (TCC_EA0_RDREQ_DRAM counts requests
+    # ADDRESSED to DRAM, cache hits included): the share is a model, and `roofline_large_index` is the measured answer.
+    share = min(1.0, INFINITY_CACHE_BYTES / index_bytes)
+    return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+            "traffic": None, "traffic_source": None, "kernel": "bmf_vote_kernel", "kernel_ms": vote_ms,
+            "algorithmic_bytes_per_launch": algo, "index_bytes_in_hbm": int(index_bytes), "infinity_cache_share": share,
+            "served_by": "HBM behind the 256 MiB Infinity Cache",
+            "hbm_side_estimate_GBps": achieved * (1.0 - share), "frac_hbm_side": achieved * (1.0 - share) / HBM_PEAK_GBPS,
+            "note": "achieved = algorithmic row bytes / kernel time: it counts reads the Infinity Cache serves; "
+                    "hbm_side_estimate_GBps = achieved x (1 - infinity_cache_share) is what the HBM stacks move (a model: "
+                    "see roofline_large_index for the index the cache cannot help)"}
+
+
+def candidate_checks(inputs, counts, buckets, shard):
+    import numpy as np
+    rd = inputs.reads
+    n = shard.stop - shard.start
+    strand = rd.truth_rc.astype(np.int64)[shard]
+    idx = np.arange(n)
+    own = buckets[idx, strand]                                   # candidate list on the true strand
+    valid = np.arange(own.shape[1])[None, :] < counts[idx, strand][:, None]
+    return {"reads_with_candidates": float((counts.sum(axis=1) > 0).mean()),
+            "source_bucket_recovered": float(((own == rd.truth_bucket[shard][:, None]) & valid).any(axis=1).mean()),
+            "candidates_per_read_per_strand": float(counts.mean())}
+
+
+def pruned_leg(inputs, cli, device, k2i, steps, want, shard=None, all_reduce_max=None, barrier=None):
+    """The same batch with BMF_FLAG_EARLY_EXIT: identical outputs from fewer row bytes.  Its "algorithmic
+    bytes / time" would exceed the HBM peak because bytes are skipped, not moved faster, so it is reported beside the
+    headline, never as `value`.  The first (untimed) run is the one on which the library measures which form to use."""
+    import numpy as np
+    import bucket_map_amd as bma
+    fp = inputs.new_filter(cli, device, bma.BMF_FLAG_EARLY_EXIT, k2i)
+    bp = inputs.batch(fp, shard)
+    elapsed, ms_sample, ms_rest = timed_steps(fp, bp, steps, 2, barrier)
+    if all_reduce_max:
+        elapsed = all_reduce_max(elapsed)
+    cp, bkp = bp.download()
+    same = bool(np.array_equal(cp, want[0]))
+    mask = np.arange(bkp.shape[-1])[None, None, :] < want[0][:, :, None]
+    same = same and bool(np.array_equal(bkp[mask], want[1][mask]))
+    info = fp.info()
+    out = {"unit": "reads/s", "ms_per_step": elapsed / steps * 1e3, "kernels_ms_per_step": float(np.mean(ms_sample) + np.mean(ms_rest)),
+           "outputs_identical_to_default_kernel": same, "outputs_identical_to_headline_run": same, "flag": "BMF_FLAG_EARLY_EXIT",
+           "form": ("two passes" if info["pass1_rows"] else "one kernel"),
+           "pass1_rows": info["pass1_rows"], "pass1_fold": info["pass1_fold"], "pass1_fold_rows": info["pass1_fold_rows"]}
+    if info["pass1_rows"]:
+        out["items_recounted"], out["items_slow_path"] = bp.pass2_counts()
+        out["items"] = int(2 * len(cp))
+        out["recount_column_loads"] = bp.recount_loads()
+    return out, fp, bp
+
+
+def skewed_leg(args, device, cli, k2i, threads, log):
+    """BASELINE configs[1]'s geometry on the genome-LIKE genome (bm_synth.h): default kernel, pruned kernels, parity sample."""
+    import numpy as np
+    from oracle import oracle_c
+    total_bp, bucket_len, read_len, n_reads = WORKLOADS[args.workload]
+    n_reads = args.reads or n_reads
+    t0 = time.perf_counter()
+    inp = Inputs(args.workload, args.total_bp or total_bp, args.bucket_len or bucket_len, read_len, n_reads, "genome", threads)
+    flt = inp.new_filter(cli, device, 0, k2i)
+    batch = inp.batch(flt)
+    elapsed, ms_sample, ms_vote = timed_steps(flt, batch, args.steps, 1)
+    counts, buckets = batch.download()
+    rows_anded = batch.rows_anded()
+    vote_ms = float(np.mean(ms_vote))
+    n_rows = int((k2i >= 0).sum())
+    zeros = flt.zeros()
+    thr = int(np.float32(cli["distinguishability"]) * np.float32(inp.nb))
+    roof = roofline_of(flt, inp, rows_anded, n_rows, vote_ms)
+    for k in ("note", "traffic", "traffic_source"):
+        roof.pop(k)
+    leg = {"what": f"{args.workload}-like geometry on the genome-like synthetic genome (bm_synth.h: order-6 Markov base layer, repeat "
+                   f"families, satellites, segmental duplications, gaps), NB={inp.nb}, {n_reads} x {read_len} bp reads per step, "
+                   f"params {args.params}",
+           "value": n_reads * args.steps / elapsed, "unit": "reads/s", "ms_per_step": elapsed / args.steps * 1e3,
+           "rows_passing_distinguishability": float((zeros >= thr).mean()),
+           "rows_passing_reference_log": "95.8 % on GRCh38 at bucket_len 65 536 (bucket_map/benchmark/short_read/log/bucketmap_3_map.log:8)",
+           "roofline": roof, "sample_kernel_ms": float(np.mean(ms_sample)),
+           "bytes_per_read": (rows_anded * inp.row_bytes + 2 * int(inp.win_len.sum())) / n_reads,
+           "checks": candidate_checks(inp, counts, buckets, slice(0, n_reads))}
+    leg["checks"]["reads_with_candidates_reference_log"] = "94.9 % (bucketmap_3_map.log:12)"
+    # parity on a sample: the oracle over all host threads (a checker here, not a baseline)
+    n_cpu = min(args.skewed_parity_reads, n_reads)
+    if n_cpu:
+        from concurrent.futures import ThreadPoolExecutor
+        ora = oracle_c.Index(oracle_c.params_from_cli(inp.nb, **cli), flt.index_download(), k2i)
+        n_thr = usable_cores()
+        cuts = [n_cpu * t // n_thr for t in range(n_thr + 1)]
+        with ThreadPoolExecutor(n_thr) as pool:
+            parts = list(pool.map(lambda t: ora.map_windows(inp.reads.bases, inp.reads.quals, inp.win_start[cuts[t]:cuts[t + 1]],
+                                                            inp.win_len[cuts[t]:cuts[t + 1]]), range(n_thr)))
+        c_ref = np.concatenate([p[0] for p in parts])
+        b_ref = np.concatenate([p[1] for p in parts])
+        mask = np.arange(b_ref.shape[-1])[None, None, :] < c_ref[:, :, None]
+        leg["checks"]["gpu_equals_oracle_on_sample"] = bool(np.array_equal(c_ref, counts[:n_cpu]) and
+                                                            np.array_equal(b_ref[mask], buckets[:n_cpu][mask]))
+        leg["checks"]["parity_sample_reads"] = int(n_cpu)
+        del ora
+    batch.close()
+    flt.close()
+    pruned, fp, bp = pruned_leg(inp, cli, device, k2i, args.steps, (counts, buckets))
+    pruned["value"] = n_reads / (pruned["ms_per_step"] * 1e-3)
+    bp.close()
+    fp.close()
+    leg["pruned"] = pruned
+    leg["seconds"] = time.perf_counter() - t0
+    log(f"skewed leg: vote {vote_ms:.2f} ms ({leg['roofline']['frac']:.3f} of peak), pruned {pruned['ms_per_step']:.2f} ms/step "
+        f"(fold {pruned['pass1_fold']} x {pruned['pass1_fold_rows']} rows), {leg['seconds']:.0f} s")
+    return leg
+
+
+def large_index_leg(args, device, k2i, threads, log):
+    """The vote kernel on an index the Infinity Cache cannot help: 2.29 Gbp at bucket_len 16 384 (NB = 140 471, 4.63 GB)."""
+    import numpy as np
+    t0 = time.perf_counter()
+    read_len = 300
+    inp = Inputs("egu", LARGE_INDEX["total_bp"], LARGE_INDEX["bucket_len"], read_len, args.large_index_reads, "uniform", threads)
+    flt = inp.new_filter(cli_params("default", read_len), device, 0, k2i)
+    batch = inp.batch(flt)
+    steps = max(2, min(args.steps, 3))
+    elapsed, ms_sample, ms_vote = timed_steps(flt, batch, steps, 1)
+    counts, buckets = batch.download()
+    n_rows = int((k2i >= 0).sum())
+    roof = roofline_of(flt, inp, batch.rows_anded(), n_rows, float(np.mean(ms_vote)))
+    for k in ("note", "traffic", "traffic_source"):
+        roof.pop(k)
+    leg = {"what": f"uniform synthetic genome {inp.genome.total_length()} bp at bucket_len {inp.bucket_len}: NB={inp.nb} "
+                   f"(one wave per 65 536-bucket slice + merge), {n_rows} rows x {inp.row_bytes} B, {inp.reads.n} x {read_len} bp reads, "
+                   f"params default",
+           "value": inp.reads.n * steps / elapsed, "unit": "reads/s", "ms_per_step": elapsed / steps * 1e3, "steps": steps,
+           **roof, "checks": candidate_checks(inp, counts, buckets, slice(0, inp.reads.n))}
+    batch.close()
+    flt.close()
+    leg["seconds"] = time.perf_counter() - t0
+    log(f"large-index leg: vote {leg['kernel_ms']:.1f} ms = {leg['achieved']:.0f} GB/s ({leg['frac']:.3f} of peak, "
+        f"{leg['infinity_cache_share']:.3f} of the index cacheable), {leg['seconds']:.0f} s")
+    return leg
+
+
+def under_profiler():
+    """True when this process already runs under rocprofv3 / rocprofiler-sdk (a nested profiler must not be started)."""
+    pre = os.environ.get("LD_PRELOAD", "")
+    return any(k.startswith(("ROCP_", "ROCPROF", "ROCPROFILER_")) for k in os.environ) or "rocprof" in pre
+
+
 def live_pmc_traffic(args, log):
     """Runs this file again as `--pmc-child` under rocprofv3 --pmc FETCH_SIZE and returns the roofline fields
     {traffic, traffic_source, traffic_dispatches, traffic_over_algorithmic}, or None when the profiler is not usable."""
@@ -79,6 +317,9 @@ def live_pmc_traffic(args, log):
     import shutil
     import subprocess
     import tempfile
+    if under_profiler():
+        log("already under a profiler: no nested rocprofv3 child")
+        return None
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(exe):
         return None
@@ -107,7 +348,8 @@ def live_pmc_traffic(args, log):
         return {"traffic": int(traffic), "traffic_dispatches_KiB": vals,
                 "traffic_over_algorithmic": traffic / child["algorithmic_bytes_per_launch"],
                 "traffic_source": "live: rocprofv3 --pmc FETCH_SIZE child run of this bench (same workload, vote kernel, "
-                                  f"mean of {len(vals)} dispatches) x1024 (KiB) x2 (gfx950 wide streaming reads)"}
+                                  f"mean of {len(vals)} dispatches) x1024 (KiB) x2 (gfx950 wide streaming reads; the factor is "
+                                  "checked against the request-size counters in profiles/r03/fetch_size_crosscheck.txt)"}
     except (OSError, ValueError, KeyError, subprocess.SubprocessError) as e:
         log(f"pmc child failed: {e}")
         return None
@@ -118,43 +360,20 @@ def live_pmc_traffic(args, log):
 def pmc_child(args):
     """The profiled child of live_pmc_traffic: same synthetic workload, three launches of the hot path, nothing else
     (no torch, no CPU leg).  Prints the algorithmic bytes of one vote launch."""
-    import numpy as np
-    import bucket_map_amd as bma
     from bucket_map_amd import host
     total_bp, bucket_len, read_len, n_reads = WORKLOADS[args.workload]
-    n_reads = args.reads or n_reads
-    total_bp = args.total_bp or total_bp
-    bucket_len = args.bucket_len or bucket_len
     threads = args.host_threads or usable_cores()
-    cli = (dict(index_seed=9, query_seed=14, read_len=read_len, mapper_samples=20, max_error_rate=0.6, distinguishability=0.5,
-                average_base_quality=10) if args.params == "bench" else
-           dict(index_seed=9, query_seed=12, read_len=read_len, mapper_samples=15, max_error_rate=0.4, distinguishability=0.5,
-                average_base_quality=25))
-    genome = host.Genome.synth(20240001, workload_record_lengths(args.workload, total_bp), threads, profile=args.genome_profile)
-    nb = genome.awk_bucket_num(bucket_len)
-    reads = host.Reads(genome, bucket_len, read_len, read_len, n_reads, sub=0.002, ins=0.00025, dele=0.00025, seed=20240003,
-                       threads=threads)
-    flt = bma.Filter(bma.Params.from_cli(nb, device=0, **cli))
-    flat, _ = genome.flat()
-    bstart, blen = genome.bucket_views(bucket_len, read_len)
-    flt.build_index(flat, bstart, blen, host.select_qgrams(cli["index_seed"], args.kmer_frac))
-    del flat
-    ws, wl, _, _ = bma.windows_for_reads(reads.offsets, read_len)
-    batch = flt.batch(reads.bases, reads.quals, ws, wl)
+    cli = cli_params(args.params, read_len)
+    inp = Inputs(args.workload, args.total_bp or total_bp, args.bucket_len or bucket_len, read_len, args.reads or n_reads,
+                 args.genome_profile, threads)
+    flt = inp.new_filter(cli, 0, 0, host.select_qgrams(cli["index_seed"], args.kmer_frac))
+    batch = inp.batch(flt)
     for _ in range(3):
         batch.run()
     flt.sync()
-    print(json.dumps({"algorithmic_bytes_per_launch": int(batch.rows_anded()) * ((nb + 7) >> 3)}), flush=True)
+    print(json.dumps({"algorithmic_bytes_per_launch": int(batch.rows_anded()) * inp.row_bytes}), flush=True)
     batch.close()
     flt.close()
-
-
-def workload_record_lengths(workload, total_bp):
-    if workload == "ecoli":
-        return [total_bp]
-    if workload == "grch38":
-        return [int(total_bp * m / sum(GRCH38_MBP)) for m in GRCH38_MBP]
-    return egu_like_record_lengths(total_bp)
 
 
 def main():
@@ -174,13 +393,16 @@ def main():
                          "reference's default, a 217 MB index that fits the 256 MiB Infinity Cache (secondary data point)")
     ap.add_argument("--host-threads", type=int, default=0)
     ap.add_argument("--genome-profile", default="uniform", choices=["uniform", "genome"],
-                    help="uniform = i.i.d. bases (SURVEY 8d, the headline); genome = bm_synth.h's skewed, repetitive generator")
+                    help="the HEADLINE's genome: uniform = i.i.d. bases (SURVEY 8d); genome = bm_synth.h's skewed, repetitive generator")
     ap.add_argument("--index-build", default="gpu", choices=["gpu", "host"],
                     help="where the synthetic index is built (setup only, outside the timed region)")
     ap.add_argument("--early-exit", action="store_true",
                     help="BMF_FLAG_EARLY_EXIT: identical outputs, fewer rows actually read (off by default so "
                          "that the roofline line prices exactly the reference's row reads)")
     ap.add_argument("--no-pruned-leg", action="store_true", help="skip the extra BMF_FLAG_EARLY_EXIT measurement")
+    ap.add_argument("--no-extra-legs", action="store_true", help="skip the `skewed` and `roofline_large_index` legs (N = 1 only anyway)")
+    ap.add_argument("--skewed-parity-reads", type=int, default=50000, help="reads of the skewed leg checked against the oracle")
+    ap.add_argument("--large-index-reads", type=int, default=500000, help="reads per step of the large-index leg")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for the barrier / max-over-ranks (nccl = RCCL)")
     ap.add_argument("--device-override", type=int, default=-1,
@@ -195,6 +417,7 @@ def main():
     if args.pmc_child:
         return pmc_child(args)
 
+    t_process = time.perf_counter()
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -217,86 +440,69 @@ def main():
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", device))
         else:
             dist.init_process_group(backend="gloo")
+    comm_dev = "cuda" if (world > 1 and args.backend == "nccl") else "cpu"
 
     import bucket_map_amd as bma
     from bucket_map_amd import host
 
     total_bp, bucket_len, read_len, n_reads = WORKLOADS[args.workload]
-    if args.reads:
-        n_reads = args.reads
-    if args.total_bp:
-        total_bp = args.total_bp
-    if args.bucket_len:
-        bucket_len = args.bucket_len
+    n_reads = args.reads or n_reads
     threads = args.host_threads or max(1, usable_cores() // world)
-    if args.params == "bench":
-        cli = dict(index_seed=9, query_seed=14, read_len=read_len, mapper_samples=20, max_error_rate=0.6,
-                   distinguishability=0.5, average_base_quality=10)
-    else:
-        cli = dict(index_seed=9, query_seed=12, read_len=read_len, mapper_samples=15, max_error_rate=0.4,
-                   distinguishability=0.5, average_base_quality=25)
+    cli = cli_params(args.params, read_len)
 
     def log(msg):
         if rank == 0:
             print(f"[bench] {msg}", file=sys.stderr, flush=True)
 
-    # ---------------- synthetic inputs (SURVEY.md 8d), identical on every rank except the reads
-    t0 = time.perf_counter()
-    lens = workload_record_lengths(args.workload, total_bp)
-    genome = host.Genome.synth(20240001, lens, threads, profile=args.genome_profile)
-    nb = genome.awk_bucket_num(bucket_len)
-    log(f"genome ({args.genome_profile}): {len(lens)} records, {genome.total_length()} bp, NB={nb} ({time.perf_counter() - t0:.1f}s)")
-    row_bytes = (nb + 7) >> 3
-    index = None
-    if args.index_build == "host":
-        t0 = time.perf_counter()
-        index = host.Index(genome, nb, bucket_len, read_len, q=cli["index_seed"], kmer_frac=args.kmer_frac, threads=threads)
-        log(f"index (host indexer): {index.num_rows} rows x {row_bytes} B ({time.perf_counter() - t0:.1f}s)")
-    t0 = time.perf_counter()
-    scaling = args.scaling if args.scaling != "auto" else ("strong" if world > 1 else "weak")
-    if world == 1:
-        scaling = "weak"          # one GPU: the two coincide; the contract's default label
-    # strong: every rank simulates the same batch (same seed) and keeps the windows of its contiguous shard
-    reads = host.Reads(genome, bucket_len, read_len, read_len, n_reads, sub=0.002, ins=0.00025, dele=0.00025,
-                       seed=20240003 + (7919 * rank if scaling == "weak" else 0), threads=threads)
-    log(f"reads: {reads.n} x {read_len} bp ({time.perf_counter() - t0:.1f}s), scaling {scaling}")
-
-    # ---------------- GPU side
-    params = bma.Params.from_cli(nb, device=device, flags=bma.BMF_FLAG_EARLY_EXIT if args.early_exit else 0, **cli)
-    flt = bma.Filter(params)
-    t0 = time.perf_counter()
-    k2i = host.select_qgrams(cli["index_seed"], args.kmer_frac)
-    n_rows = int((k2i >= 0).sum())
-    if index is not None:
-        flt.load_index_ptr(index.rows_ptr, index.num_rows, index.k2i_ptr, index.num_kmers)
-    else:
-        # GPU index build (bmf_build_index): byte-identical to the host indexer (tests/test_index_build_gpu.py)
-        flat, _ = genome.flat()
-        bstart, blen = genome.bucket_views(bucket_len, read_len)
-        flt.build_index(flat, bstart, blen, k2i)
-        del flat
-    log(f"index in HBM via {args.index_build} build: {n_rows} rows x {row_bytes} B = {n_rows * row_bytes / 1e6:.1f} MB "
-        f"({time.perf_counter() - t0:.1f}s), kernel variant {flt.info()}")
-    # mapper::map's windowing: one window [0, min(read_len, len)) per short read
-    win_start, win_len, _, _ = bma.windows_for_reads(reads.offsets, read_len)
-    shard = slice(0, reads.n)
-    if scaling == "strong" and world > 1:
-        shard = slice(reads.n * rank // world, reads.n * (rank + 1) // world)
-        lo, hi = int(reads.offsets[shard.start]), int(reads.offsets[shard.stop])
-        batch = flt.batch(reads.bases[lo:hi], reads.quals[lo:hi], win_start[shard] - np.uint64(lo), win_len[shard])
-    else:
-        batch = flt.batch(reads.bases, reads.quals, win_start, win_len)
-    n_mine = shard.stop - shard.start
-    reads_per_step = reads.n if scaling == "strong" else world * reads.n
-
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
-        flt.sync()
+
+    def all_reduce_max(x):
+        if world == 1:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device=comm_dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    # ---------------- synthetic inputs (SURVEY.md 8d), identical on every rank except the reads
+    scaling = args.scaling if args.scaling != "auto" else ("strong" if world > 1 else "weak")
+    if world == 1:
+        scaling = "weak"          # one GPU: the two coincide; the contract's default label
+    # strong: every rank simulates the same batch (same seed) and keeps the windows of its contiguous shard
+    inp = Inputs(args.workload, args.total_bp or total_bp, args.bucket_len or bucket_len, read_len, n_reads, args.genome_profile,
+                 threads, read_seed=20240003 + (7919 * rank if scaling == "weak" else 0))
+    genome, reads, nb, row_bytes = inp.genome, inp.reads, inp.nb, inp.row_bytes
+    log(f"genome ({args.genome_profile}): {len(inp.lens)} records, {genome.total_length()} bp, NB={nb} ({inp.genome_s:.1f}s); "
+        f"reads: {reads.n} x {read_len} bp ({inp.reads_s:.1f}s), scaling {scaling}")
+
+    # ---------------- GPU side
+    t0 = time.perf_counter()
+    k2i = host.select_qgrams(cli["index_seed"], args.kmer_frac)
+    n_rows = int((k2i >= 0).sum())
+    index = None
+    flags = bma.BMF_FLAG_EARLY_EXIT if args.early_exit else 0
+    if args.index_build == "host":
+        index = host.Index(genome, nb, inp.bucket_len, read_len, q=cli["index_seed"], kmer_frac=args.kmer_frac, threads=threads)
+        flt = bma.Filter(bma.Params.from_cli(nb, device=device, flags=flags, **cli))
+        flt.load_index_ptr(index.rows_ptr, index.num_rows, index.k2i_ptr, index.num_kmers)
+    else:
+        flt = inp.new_filter(cli, device, flags, k2i)
+    params = flt.params
+    log(f"index in HBM via {args.index_build} build: {n_rows} rows x {row_bytes} B = {n_rows * row_bytes / 1e6:.1f} MB "
+        f"({time.perf_counter() - t0:.1f}s), kernel variant {flt.info()}")
+    shard = slice(0, reads.n)
+    if scaling == "strong" and world > 1:
+        shard = slice(reads.n * rank // world, reads.n * (rank + 1) // world)
+    batch = inp.batch(flt, shard)
+    n_mine = shard.stop - shard.start
+    reads_per_step = reads.n if scaling == "strong" else world * reads.n
+    setup_s = time.perf_counter() - t_process
 
     for _ in range(args.warmup):
         batch.run()
+    flt.sync()
     barrier()
     flt.profile_begin(args.steps)
     t_start = time.perf_counter()
@@ -304,128 +510,92 @@ def main():
         batch.run()
     flt.sync()
     torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t_start
+    my_elapsed = time.perf_counter() - t_start
     ms_sample, ms_vote = flt.profile_end(args.steps)
+    elapsed = all_reduce_max(my_elapsed)
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
         dist.barrier()
 
     rows_anded = batch.rows_anded()
     counts, buckets = batch.download()
 
+    # per-rank view of the timed region (N > 1): the slowest rank sets `value`; whether the others were waiting for it
+    # (jitter) or every rank lost the same time (a serial part, launch gaps) is read off these.
+    per_rank = None
+    if world > 1:
+        kern = ms_sample + ms_vote                                        # per step, HIP events
+        mine = torch.tensor([my_elapsed / args.steps * 1e3, float(kern.mean()), float(kern.min()), float(kern.max()),
+                             setup_s, resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1024.0, float(n_mine)],
+                            dtype=torch.float64, device=comm_dev)
+        got = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(got, mine)
+        rows = np.array([g.cpu().numpy() for g in got])
+        per_rank = {"step_ms": [round(float(x), 3) for x in rows[:, 0]],
+                    "kernel_ms_mean": [round(float(x), 3) for x in rows[:, 1]],
+                    "kernel_ms_min": [round(float(x), 3) for x in rows[:, 2]], "kernel_ms_max": [round(float(x), 3) for x in rows[:, 3]],
+                    "launch_gap_ms": [round(float(a - b), 3) for a, b in zip(rows[:, 0], rows[:, 1])],
+                    "setup_wall_s": [round(float(x), 1) for x in rows[:, 4]], "max_rss_MB": [round(float(x)) for x in rows[:, 5]],
+                    "reads": [int(x) for x in rows[:, 6]],
+                    "what": "step_ms = wall per step on that rank; kernel_ms_* = sample + vote kernels per step (HIP events); "
+                            "launch_gap_ms = step_ms - kernel_ms_mean; setup = process start to first warm-up step"}
+
     # the other scaling mode, beside the headline (strong runs only): every rank maps the whole batch
     weak_leg = None
     if scaling == "strong" and world > 1:
-        wb = flt.batch(reads.bases, reads.quals, win_start, win_len)
-        wb.run()
-        barrier()
-        t_w = time.perf_counter()
-        for _ in range(args.steps):
-            wb.run()
-        flt.sync()
-        weak_s = time.perf_counter() - t_w
-        tw = torch.tensor([weak_s], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
-        dist.all_reduce(tw, op=dist.ReduceOp.MAX)
-        weak_s = float(tw.item())
+        wb = inp.batch(flt)
+        w_elapsed, _, _ = timed_steps(flt, wb, args.steps, 1, barrier)
+        weak_s = all_reduce_max(w_elapsed)
         wb.close()
         weak_leg = {"value": world * reads.n * args.steps / weak_s, "unit": "reads/s", "ms_per_step": weak_s / args.steps * 1e3,
                     "what": f"every rank maps its own copy of the {reads.n}-read batch (per-GPU work fixed)"}
 
     # PCIe-inclusive rate of the host-buffer entry point (bmf_map_windows: H2D of the reads, both kernels,
     # compacted D2H of the results; the batch goes through in pieces so that the copies of one piece run under
-    # the kernels of its neighbours).  From page-locked buffers, as the `bucketmap` tool stages its reads, and
-    # from ordinary pageable memory.  Reported for DESIGN.md only; it is never `value`.
-    out_arrays = (np.zeros((len(win_start), 2), np.uint32), np.empty(2 * len(win_start) * params.max_candidates, np.uint32))
+    # the kernels of its neighbours).  From page-locked buffers and from ordinary pageable memory.  Reported for
+    # DESIGN.md only; it is never `value`.
+    out_arrays = (np.zeros((len(inp.win_start), 2), np.uint32), np.empty(2 * len(inp.win_start) * params.max_candidates, np.uint32))
 
     def time_map_windows(f, b, q):
-        f.map_windows_compact(b, q, win_start, win_len, out=out_arrays)          # first call allocates
+        f.map_windows_compact(b, q, inp.win_start, inp.win_len, out=out_arrays)          # first call allocates
         best = 1e9
         for _ in range(3):
             t_h = time.perf_counter()
-            f.map_windows_compact(b, q, win_start, win_len, out=out_arrays)
+            f.map_windows_compact(b, q, inp.win_start, inp.win_len, out=out_arrays)
             best = min(best, time.perf_counter() - t_h)
         return best
-    pinned_b, pinned_q = bma.pinned_copy(reads.bases), bma.pinned_copy(reads.quals)
-    host_pinned_s = time_map_windows(flt, pinned_b.array, pinned_q.array)
-    host_buffer_s = time_map_windows(flt, reads.bases, reads.quals)
+    host_pinned_s = host_buffer_s = None
+    pinned_b = pinned_q = None
+    if world == 1:
+        pinned_b, pinned_q = bma.pinned_copy(reads.bases), bma.pinned_copy(reads.quals)
+        host_pinned_s = time_map_windows(flt, pinned_b.array, pinned_q.array)
+        host_buffer_s = time_map_windows(flt, reads.bases, reads.quals)
 
-    # Second leg, reported beside the headline, never instead of it: the same batch with BMF_FLAG_EARLY_EXIT
-    # (identical outputs from fewer row bytes: waves stop, and lanes stop loading, once no bucket they hold can
-    # still be a candidate).  Its "algorithmic bytes / time" would exceed the HBM peak because bytes are skipped,
-    # not moved faster, so the roofline line above stays on the kernel that performs the reference's row reads.
+    # Second leg, reported beside the headline, never instead of it: the same batch with BMF_FLAG_EARLY_EXIT.
     pruned = None
     if not args.early_exit and not args.no_pruned_leg:
-        fp = bma.Filter(bma.Params.from_cli(nb, device=device, flags=bma.BMF_FLAG_EARLY_EXIT, **cli))
-        if index is not None:
-            fp.load_index_ptr(index.rows_ptr, index.num_rows, index.k2i_ptr, index.num_kmers)
-        else:
-            flat, _ = genome.flat()
-            bstart, blen = genome.bucket_views(bucket_len, read_len)
-            fp.build_index(flat, bstart, blen, k2i)
-            del flat
-        if shard.stop - shard.start != reads.n:
-            lo, hi = int(reads.offsets[shard.start]), int(reads.offsets[shard.stop])
-            bp = fp.batch(reads.bases[lo:hi], reads.quals[lo:hi], win_start[shard] - np.uint64(lo), win_len[shard])
-        else:
-            bp = fp.batch(reads.bases, reads.quals, win_start, win_len)
-        bp.run()
-        fp.sync()
-        if world > 1:
-            dist.barrier()
-        t_p = time.perf_counter()
-        for _ in range(args.steps):
-            bp.run()
-        fp.sync()
-        pruned_s = time.perf_counter() - t_p
-        if world > 1:
-            tp = torch.tensor([pruned_s], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
-            dist.all_reduce(tp, op=dist.ReduceOp.MAX)
-            pruned_s = float(tp.item())
-        cp, bkp = bp.download()
-        same = bool(np.array_equal(cp, counts))
-        maskp = np.arange(bkp.shape[-1])[None, None, :] < counts[:, :, None]
-        same = same and bool(np.array_equal(bkp[maskp], buckets[maskp]))
-        pruned = {"value": reads_per_step * args.steps / pruned_s, "unit": "reads/s", "ms_per_step": pruned_s / args.steps * 1e3,
-                  "outputs_identical_to_headline_run": same, "flag": "BMF_FLAG_EARLY_EXIT",
-                  "pass1_rows": fp.info()["pass1_rows"], "pass1_fold": fp.info()["pass1_fold"],
-                  "pass1_fold_rows": fp.info()["pass1_fold_rows"]}
-        if pruned["pass1_rows"]:
-            pruned["items_recounted"], pruned["items_slow_path"] = bp.pass2_counts()
-            pruned["recount_column_loads"] = bp.recount_loads()
+        pruned, fp, bp = pruned_leg(inp, cli, device, k2i, args.steps, (counts, buckets), shard, all_reduce_max,
+                                    (dist.barrier if world > 1 else None))
+        pruned["value"] = reads_per_step / (pruned["ms_per_step"] * 1e-3)
         bp.close()
         if world == 1:
             pruned["pcie_inclusive_ms_pinned"] = time_map_windows(fp, pinned_b.array, pinned_q.array) * 1e3
         fp.close()
-
-    # ---------------- correctness properties at full size (size-independent)
-    strand = reads.truth_rc.astype(np.int64)[shard]
-    idx = np.arange(n_mine)
-    own = buckets[idx, strand]                                   # candidate list on the true strand
-    valid = np.arange(own.shape[1])[None, :] < counts[idx, strand][:, None]
-    recovered = float(((own == reads.truth_bucket[shard][:, None]) & valid).any(axis=1).mean())
-    mapped = float((counts.sum(axis=1) > 0).mean())
+    pinned_b = pinned_q = None
 
     result = None
     if rank == 0:
         reads_per_s = reads_per_step * args.steps / elapsed
         vote_ms = float(np.mean(ms_vote))
-        algo_bytes_vote = rows_anded * row_bytes                 # rows ANDed x ceil(NB/8)
-        algo_bytes_read = algo_bytes_vote + 2 * int(win_len[shard].sum())
-        achieved = algo_bytes_vote / (vote_ms * 1e-3) / 1e9
-        # What the HBM devices themselves see: FETCH_SIZE (and the algorithmic count) include reads the 256 MiB
-        # Infinity Cache serves.  A uniformly gathered table of T bytes keeps about 256 MiB / T of itself there
-        # (MI355X_MICROARCH.md, Infinity Cache), so the HBM side moves roughly (1 - share) of the bytes.
-        index_bytes = (n_rows + 1) * flt.info()["row_pitch_bytes"]
-        ic_share = min(1.0, (256 << 20) / index_bytes)
+        roof = roofline_of(flt, inp, rows_anded, n_rows, vote_ms)
+        roof["bytes_per_read"] = (roof["algorithmic_bytes_per_launch"] + 2 * int(inp.win_len[shard].sum())) / n_mine
+        roof["sample_kernel_ms"] = float(np.mean(ms_sample))
         result = {
-            "metric": "mapped reads/sec (1M\u00d7300bp, 65536-bucket index)",   # BASELINE.json's metric, its first clause
+            "metric": "mapped reads/sec (1M×300bp, 65536-bucket index)",   # BASELINE.json's metric, its first clause
             "value": reads_per_s, "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": scaling,
             "vs_baseline": None, "dtype": "u32", "data": "synthetic",
             "config": {
-                "workload": f"{args.workload}-like synthetic genome ({args.genome_profile} profile) {genome.total_length()} bp, bucket_len {bucket_len}, "
+                "workload": f"{args.workload}-like synthetic genome ({args.genome_profile} profile) {genome.total_length()} bp, bucket_len {inp.bucket_len}, "
                             f"NB={nb}, -f {args.kmer_frac:g} index ({n_rows} rows x {row_bytes} B), {reads_per_step} x {read_len} bp "
                             f"simulated reads per step (sub 0.002, ins=del 0.00025), params {args.params} "
                             f"(k={params.k} q={params.q} S={params.num_samples} F={params.num_fault})",
@@ -433,47 +603,20 @@ def main():
                 "parallelism": f"reads sharded over {world} GPU(s) in contiguous ranges, index replicated, no collective",
                 "early_exit": bool(args.early_exit),
             },
-            "roofline": {
-                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBPS, "traffic": None, "traffic_source": None,
-                "kernel": "bmf_vote_kernel", "kernel_ms": vote_ms, "algorithmic_bytes_per_launch": int(algo_bytes_vote),
-                "bytes_per_read": algo_bytes_read / n_mine, "sample_kernel_ms": float(np.mean(ms_sample)),
-                "index_bytes_in_hbm": int(index_bytes), "infinity_cache_share": ic_share,
-                "hbm_side_estimate_GBps": achieved * (1.0 - ic_share),
-                "note": "achieved = algorithmic row bytes / kernel time: it counts reads the 256 MiB Infinity Cache serves; "
-                        "hbm_side_estimate_GBps = achieved x (1 - infinity_cache_share) is what the HBM stacks move",
-            },
-            "checks": {"reads_with_candidates": mapped, "source_bucket_recovered": recovered},
+            "roofline": roof,
+            "checks": candidate_checks(inp, counts, buckets, shard),
             "pruned": pruned,
             "weak_scaling": weak_leg,
-            "pcie_inclusive": {"reads_per_s_per_gpu": reads.n / host_pinned_s, "ms": host_pinned_s * 1e3,
-                               "ms_pageable": host_buffer_s * 1e3, "reads": int(reads.n),
-                               "what": "bmf_map_windows_compact (the entry point the bucketmap tool calls), host buffers in and out: "
-                                       "H2D of the reads, kernels and packed D2H pipelined in pieces; page-locked source (ms) "
-                                       "and pageable source (ms_pageable)"},
+            "per_rank": per_rank,
+            "setup": {"wall_s": setup_s, "genome_s": inp.genome_s, "reads_s": inp.reads_s, "host_threads": threads,
+                      "max_rss_MB": resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1024.0},
         }
-
-        # HBM-side traffic of the vote kernel, measured NOW: PMC counters cannot be read in-process, so a child
-        # runs the same workload's vote kernel under `rocprofv3 --pmc FETCH_SIZE` (its own pass, no tracing) and the
-        # per-dispatch values are corrected as MI355X_MICROARCH.md prescribes (KiB -> bytes, x2 on gfx950 for wide
-        # streaming reads).  If the profiler cannot run here the committed pass of the same workload is quoted,
-        # and traffic_source says so.
-        if world == 1 and not args.no_pmc and not args.early_exit:
-            live = live_pmc_traffic(args, log)
-            if live:
-                result["roofline"].update(live)
-        if result["roofline"]["traffic"] is None:
-            try:
-                with open(os.path.join(ROOT, "profiles", "pmc_latest.json")) as f:
-                    pmc = json.load(f)
-                for e in pmc.get("entries", [pmc]):
-                    if (e.get("workload") == args.workload and e.get("params") == args.params
-                            and e.get("reads") == int(n_mine) and not args.early_exit and args.kmer_frac == 1.0
-                            and not args.total_bp and not args.bucket_len):
-                        result["roofline"]["traffic"] = e["vote_kernel_traffic_bytes"]
-                        result["roofline"]["traffic_source"] = "NOT measured in this run; committed pass " + e["source"]
-            except (OSError, ValueError, KeyError):
-                pass
+        if host_pinned_s is not None:
+            result["pcie_inclusive"] = {"reads_per_s_per_gpu": reads.n / host_pinned_s, "ms": host_pinned_s * 1e3,
+                                        "ms_pageable": host_buffer_s * 1e3, "reads": int(reads.n),
+                                        "what": "bmf_map_windows_compact (the entry point the bucketmap tool calls), host buffers in and "
+                                                "out: H2D of the reads, kernels and packed D2H pipelined in pieces; page-locked source "
+                                                "(ms) and pageable source (ms_pageable)"}
 
         # ---------------- CPU baseline (oracle = port of the reference algorithm, 1 thread) + parity sample
         if args.cpu_sample > 0 and world == 1:               # the CPU baseline is an N=1 leg only
@@ -482,7 +625,7 @@ def main():
             rows_host = index.rows() if index is not None else flt.index_download()
             ora = oracle_c.Index(oracle_c.params_from_cli(nb, **cli), rows_host, k2i)
             t0 = time.perf_counter()
-            c_ref, b_ref, rows_ref = ora.map_windows(reads.bases, reads.quals, win_start[:n_cpu], win_len[:n_cpu])
+            c_ref, b_ref, rows_ref = ora.map_windows(reads.bases, reads.quals, inp.win_start[:n_cpu], inp.win_len[:n_cpu])
             cpu_s = time.perf_counter() - t0
             same = bool(np.array_equal(c_ref, counts[:n_cpu]))
             mask = np.arange(b_ref.shape[-1])[None, None, :] < c_ref[:, :, None]
@@ -500,18 +643,51 @@ def main():
             shards = [(i * per, (i + 1) * per) for i in range(n_thr)]
             t0 = time.perf_counter()
             with ThreadPoolExecutor(n_thr) as pool:
-                list(pool.map(lambda s: ora.map_windows(reads.bases, reads.quals, win_start[s[0]:s[1]], win_len[s[0]:s[1]]),
+                list(pool.map(lambda s: ora.map_windows(reads.bases, reads.quals, inp.win_start[s[0]:s[1]], inp.win_len[s[0]:s[1]]),
                               shards))
             mt_s = time.perf_counter() - t0
             result["cpu_baseline_all_cores"] = {"value": n_thr * per / mt_s, "unit": "reads/s", "cores": n_thr,
                                                 "kind": "port", "sample": f"{n_thr} threads x {per} reads, {mt_s:.1f} s"}
+            del ora, rows_host
         else:
             result["cpu_baseline"] = None
-        print(json.dumps(result), flush=True)
 
+    # every GPU resource of the headline is released before the other legs and the profiler child start
     batch.close()
     flt.close()
+    del inp, reads, genome, index
+
+    if rank == 0:
+        extra = world == 1 and not args.no_extra_legs and not args.early_exit and args.kmer_frac == 1.0
+        # HBM-side traffic of the vote kernel, measured NOW: PMC counters cannot be read in-process, so a child
+        # runs the same workload's vote kernel under `rocprofv3 --pmc FETCH_SIZE` (its own pass, no tracing) and the
+        # per-dispatch values are corrected as MI355X_MICROARCH.md prescribes (KiB -> bytes, x2 on gfx950 for wide
+        # streaming reads).  If the profiler cannot run here the committed pass of the same workload is quoted,
+        # and traffic_source says so.
+        if world == 1 and not args.no_pmc and not args.early_exit:
+            live = live_pmc_traffic(args, log)
+            if live:
+                result["roofline"].update(live)
+        if result["roofline"]["traffic"] is None:
+            try:
+                with open(os.path.join(ROOT, "profiles", "pmc_latest.json")) as f:
+                    pmc = json.load(f)
+                for e in pmc.get("entries", [pmc]):
+                    if (e.get("workload") == args.workload and e.get("params") == args.params
+                            and e.get("reads") == int(n_mine) and not args.early_exit and args.kmer_frac == 1.0
+                            and not args.total_bp and not args.bucket_len and args.genome_profile == "uniform"):
+                        result["roofline"]["traffic"] = e["vote_kernel_traffic_bytes"]
+                        result["roofline"]["traffic_source"] = "NOT measured in this run; committed pass " + e["source"]
+            except (OSError, ValueError, KeyError):
+                pass
+        if extra and args.genome_profile == "uniform":
+            result["skewed"] = skewed_leg(args, device, cli, k2i, threads, log)
+        if extra and args.workload == "egu" and not args.total_bp and not args.bucket_len:
+            result["roofline_large_index"] = large_index_leg(args, device, k2i, threads, log)
+        print(json.dumps(result), flush=True)
+
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -15,7 +15,7 @@ ROOT=${GRAFT_REPO_ROOT:?GRAFT_REPO_ROOT is not set: run this through gpurun (or 
 OUT=$ROOT/gpurun_out/prof_${TAG}_${NAME}
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp && cd "$ROOT"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt" -- python3 bench.py --steps 5 --warmup 2 --workload "$WORKLOAD" --params "$PARAMS" --cpu-sample 0 --no-pmc "$@" > "$OUT/bench_kt.json" 2> "$OUT/bench_kt.err"
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- python3 bench.py --steps 2 --warmup 1 --workload "$WORKLOAD" --params "$PARAMS" --cpu-sample 0 --no-pmc "$@" > "$OUT/bench_pmc.json" 2> "$OUT/bench_pmc.err"
-rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d "$OUT/pmc_l2" -- python3 bench.py --steps 2 --warmup 1 --workload "$WORKLOAD" --params "$PARAMS" --cpu-sample 0 --no-pmc "$@" > "$OUT/bench_pmc2.json" 2> "$OUT/bench_pmc2.err"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt" -- python3 bench.py --steps 5 --warmup 2 --workload "$WORKLOAD" --params "$PARAMS" --cpu-sample 0 --no-pmc --no-extra-legs "$@" > "$OUT/bench_kt.json" 2> "$OUT/bench_kt.err"
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- python3 bench.py --steps 2 --warmup 1 --workload "$WORKLOAD" --params "$PARAMS" --cpu-sample 0 --no-pmc --no-extra-legs "$@" > "$OUT/bench_pmc.json" 2> "$OUT/bench_pmc.err"
+rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d "$OUT/pmc_l2" -- python3 bench.py --steps 2 --warmup 1 --workload "$WORKLOAD" --params "$PARAMS" --cpu-sample 0 --no-pmc --no-extra-legs "$@" > "$OUT/bench_pmc2.json" 2> "$OUT/bench_pmc2.err"
 echo "profiles written under $OUT"

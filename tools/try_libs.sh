@@ -9,7 +9,7 @@ mkdir -p gpurun_out
 cp bucket-map_amd/libbmf.so /tmp/libbmf_main.so
 for lib in /tmp/libbmf_main.so bucket-map_amd/alt/*.so /tmp/libbmf_main.so; do
     cp "$lib" bucket-map_amd/libbmf.so
-    python bench.py --no-pmc --steps 10 --warmup 3 > gpurun_out/try_$(basename $lib .so).json
+    python bench.py --no-pmc --no-extra-legs --steps 10 --warmup 3 > gpurun_out/try_$(basename $lib .so).json
     python - "$lib" <<'PY'
 import json, sys, os
 d = json.load(open("gpurun_out/try_" + os.path.basename(sys.argv[1])[:-3] + ".json"))
