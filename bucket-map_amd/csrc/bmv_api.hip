@@ -205,13 +205,14 @@ int bmv_create(const bmv_params *params, bmv_ctx **out) {
     HIP_TRY(hipSetDevice(params->device));
     bmv_ctx *c = new bmv_ctx();
     c->p = *params;
-    // traceback bits of the alignments in flight: a quarter of the free HBM, 1..48 GiB (a 10-kbp alignment
-    // keeps 28 MB of trace and is one wave: long reads want thousands in flight); BMV_SCRATCH_MB overrides
-    // (tests use it to force chunking)
+    // checkpoints of the alignments in flight: a third of the free HBM, 1..96 GiB (a 30-kbp alignment keeps 19 MB and
+    // is one wave: long reads want thousands in flight, and a mixed batch wants several length classes in flight
+    // together -- 40 000 alignments of 1 .. 30 kbp: 26.8 / 31.2 / 32.8 / 35.0 T cell updates/s with 48 / 72 / 96 / 140 GB);
+    // BMV_SCRATCH_MB overrides (tests use it to force chunking)
     size_t free_b = 0, total_b = 0;
     c->scratch_bytes = (size_t)8 << 30;
     if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
-        c->scratch_bytes = std::min<size_t>(std::max<size_t>(free_b / 4, (size_t)1 << 30), (size_t)48 << 30);
+        c->scratch_bytes = std::min<size_t>(std::max<size_t>(free_b / 3, (size_t)1 << 30), (size_t)96 << 30);
     if (const char *env = getenv("BMV_SCRATCH_MB")) {
         const long v = strtol(env, nullptr, 10);
         if (v > 0) c->scratch_bytes = (size_t)v << 20;
@@ -468,64 +469,83 @@ int bmv_align(bmv_ctx *c, const uint8_t *reads, uint64_t n_read_bytes, const uin
         return BMV_OK;
     };
 
-    // Several classes that each fit the scratch budget in one piece, and together too: their kernels run side by side on a
-    // few streams -- a class of long reads is few waves that each run for tens of milliseconds, and the card is theirs
-    // alone otherwise.
-    size_t sum_trace = 0, sum_ops = 0;
-    bool whole = plans.size() > 1;
-    for (const Plan &pl : plans) {
-        whole = whole && pl.chunk == pl.members;
-        sum_trace += (size_t)((pl.members + pl.gpw - 1u) / pl.gpw * pl.trace_stride);
-        sum_ops += (size_t)pl.members * pl.ops_stride;
+    // Rounds.  A launch's scratch (checkpoints + reversed CIGAR entries) is what bounds how many alignments are in flight:
+    // 19 MB per 30-kbp alignment.  A class of long reads is few waves that each run for tens of milliseconds, so one class
+    // at a time leaves most of the card idle (measured on 40 000 alignments of 1 .. 30 kbp: 19.8 T cell updates/s against
+    // 37-41 T for uniform batches).  Every class is therefore cut into pieces of at most a THIRD of the scratch budget (when
+    // there is more than one class), the pieces -- longest reads first -- are packed into rounds that fit the budget
+    // together, and the pieces of a round run side by side on a few streams; their CIGARs are collected once per round.
+    // BMV_SERIAL_CLASSES=1: one piece per round (the old behaviour), for comparison.
+    struct Todo {
+        const Plan *pl;
+        uint64_t first;
+        uint32_t count;
+        size_t trace_words, ops_words;
+    };
+    std::vector<Todo> todo;
+    const bool serial = getenv("BMV_SERIAL_CLASSES") != nullptr;
+    for (size_t i = plans.size(); i-- > 0;) {                   // the longest first: they take the longest
+        const Plan &pl = plans[i];
+        const uint64_t per_slot = pl.trace_stride / pl.gpw * 8u + (uint64_t)pl.ops_stride * 4u;
+        uint64_t chunk = pl.chunk;
+        if (plans.size() > 1 && !serial) {
+            const uint64_t third = std::max<uint64_t>(pl.gpw, c->scratch_bytes / 3u / per_slot) / pl.gpw * pl.gpw;
+            chunk = std::min<uint64_t>(chunk, std::max<uint64_t>(third, pl.gpw));
+            const uint64_t n_pieces = (pl.members + chunk - 1u) / chunk;
+            chunk = std::min<uint64_t>(chunk, ((pl.members + n_pieces - 1u) / n_pieces + pl.gpw - 1u) / pl.gpw * pl.gpw);
+        }
+        for (uint64_t first = 0; first < pl.members; first += chunk) {
+            const uint32_t count = (uint32_t)std::min<uint64_t>(chunk, pl.members - first);
+            todo.push_back({&pl, first, count, (size_t)((count + pl.gpw - 1u) / pl.gpw * pl.trace_stride), (size_t)count * pl.ops_stride});
+        }
     }
-    whole = whole && sum_trace * 8u + sum_ops * 4u <= c->scratch_bytes && !getenv("BMV_SERIAL_CLASSES");
-    if (whole) {
+    for (size_t at = 0; at < todo.size();) {
+        // the pieces of this round: as many as fit the budget (at least one)
+        size_t end = at, sum_trace = 0, sum_ops = 0, slots = 0;
+        while (end < todo.size() && (end == at || (!serial && (sum_trace + todo[end].trace_words) * 8u + (sum_ops + todo[end].ops_words) * 4u <=
+                                                                   c->scratch_bytes))) {
+            sum_trace += todo[end].trace_words;
+            sum_ops += todo[end].ops_words;
+            slots += todo[end].count;
+            end++;
+        }
         HIP_TRY(c->trace.need(with_headroom(sum_trace, c->trace.cap)));
         HIP_TRY(c->ops_rev.need(with_headroom(sum_ops, c->ops_rev.cap)));
-        HIP_TRY(c->nops.need(with_headroom(n, c->nops.cap)));
-        HIP_TRY(c->offsets.need(with_headroom((size_t)n + 1, c->offsets.cap)));
-        HIP_TRY(hipEventRecord(c->ev0, c->stream));             // the uploads above
+        HIP_TRY(c->nops.need(with_headroom(slots, c->nops.cap)));
+        HIP_TRY(c->offsets.need(with_headroom(slots + 1, c->offsets.cap)));
+        HIP_TRY(hipEventRecord(c->ev0, c->stream));             // the uploads above / the round before
         std::vector<Piece> pieces;
         size_t trace_at = 0, ops_at = 0;
-        for (size_t i = plans.size(); i-- > 0;) {               // the longest first: they take the longest
-            const Plan &pl = plans[i];
-            hipStream_t side = c->side[i % kSideStreams];
-            HIP_TRY(hipStreamWaitEvent(side, c->ev0, 0));
-            HIP_TRY(launch(pl, 0, pl.members, side, c->trace.p + trace_at, c->ops_rev.p + ops_at, c->nops.p + pl.lo));
-            pieces.push_back({&pl, 0, pl.members, pl.lo, c->ops_rev.p + ops_at});
-            trace_at += (size_t)((pl.members + pl.gpw - 1u) / pl.gpw * pl.trace_stride);
-            ops_at += (size_t)pl.members * pl.ops_stride;
+        uint32_t slot_at = 0;
+        const bool alone = end - at == 1;
+        for (size_t i = at; i < end; i++) {
+            const Todo &t = todo[i];
+            hipStream_t st = alone ? c->stream : c->side[(i - at) % kSideStreams];
+            if (!alone) HIP_TRY(hipStreamWaitEvent(st, c->ev0, 0));
+            HIP_TRY(launch(*t.pl, t.first, t.count, st, c->trace.p + trace_at, c->ops_rev.p + ops_at, c->nops.p + slot_at));
+            pieces.push_back({t.pl, t.first, t.count, slot_at, c->ops_rev.p + ops_at});
+            trace_at += t.trace_words;
+            ops_at += t.ops_words;
+            slot_at += t.count;
         }
-        for (uint32_t k = 0; k < kSideStreams; k++) {           // and the main stream goes on when all of them are done
-            HIP_TRY(hipEventRecord(c->side_done[k], c->side[k]));
-            HIP_TRY(hipStreamWaitEvent(c->stream, c->side_done[k], 0));
-        }
+        if (!alone)
+            for (uint32_t k = 0; k < kSideStreams; k++) {       // the main stream goes on when all of them are done
+                HIP_TRY(hipEventRecord(c->side_done[k], c->side[k]));
+                HIP_TRY(hipStreamWaitEvent(c->stream, c->side_done[k], 0));
+            }
         HIP_TRY(hipEventRecord(c->ev1, c->stream));
-        std::sort(pieces.begin(), pieces.end(), [](const Piece &x, const Piece &y) { return x.slot0 < y.slot0; });
-        if (int rc = collect(pieces, n)) return rc;
+        if (int rc = collect(pieces, slot_at)) return rc;
         float ms = 0.f;
         HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
         c->ms_kernels += ms;
-    } else {
-        HIP_TRY(c->trace.need(with_headroom(need_trace, c->trace.cap)));
-        HIP_TRY(c->ops_rev.need(with_headroom(need_ops, c->ops_rev.cap)));
-        HIP_TRY(c->nops.need(with_headroom(need_slots, c->nops.cap)));
-        HIP_TRY(c->offsets.need(with_headroom((size_t)need_slots + 1, c->offsets.cap)));
-        for (const Plan &pl : plans) {
-            for (uint64_t first = 0; first < pl.members; first += pl.chunk) {
-                const uint32_t count = (uint32_t)std::min<uint64_t>(pl.chunk, pl.members - first);
-                HIP_TRY(hipEventRecord(c->ev0, c->stream));
-                HIP_TRY(launch(pl, first, count, c->stream, c->trace.p, c->ops_rev.p, c->nops.p));
-                HIP_TRY(hipEventRecord(c->ev1, c->stream));
-                if (int rc = collect({Piece{&pl, first, count, 0u, c->ops_rev.p}}, count)) return rc;
-                float ms = 0.f;
-                HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
-                c->ms_kernels += ms;
-                if (getenv("BMV_LOG_CLASSES"))
-                    fprintf(stderr, "[bmv] class up to %u bases: %u of %u alignments, %u lanes x %d words, %.2f ms\n",
-                            pl.max_m, count, pl.members, pl.sh.group, pl.sh.cw, ms);
-            }
+        if (getenv("BMV_LOG_CLASSES")) {
+            fprintf(stderr, "[bmv] round of %zu piece(s), %.2f ms:", end - at, ms);
+            for (size_t i = at; i < end; i++)
+                fprintf(stderr, " [up to %u bases: %u of %u alignments, %u lanes x %d words]", todo[i].pl->max_m, todo[i].count,
+                        todo[i].pl->members, todo[i].pl->sh.group, todo[i].pl->sh.cw);
+            fprintf(stderr, "\n");
         }
+        at = end;
     }
     if (!one_class) {
         uint64_t at = 0;

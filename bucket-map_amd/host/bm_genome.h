@@ -226,6 +226,7 @@ inline void for_each_fastq_stream(const std::string &path, const std::function<v
                 size_t end;
                 if (nl) end = static_cast<size_t>(nl - buf.data());
                 else if (eof && p < have) end = have;
+                else if (eof && got_lines == 3 && len[1] == 0) end = have;   // an empty last record may end at its '+' line
                 else break;
                 line[got_lines] = buf.data() + p;
                 len[got_lines] = end - p;
@@ -242,6 +243,7 @@ inline void for_each_fastq_stream(const std::string &path, const std::function<v
                 break;
             }
             if (line[0][0] != '@') fail("FASTQ record does not start with '@'");
+            if (len[2] == 0 || line[2][0] != '+') fail("FASTQ record lacks its '+' line");
             if (len[1] != len[3]) fail("sequence and quality lengths differ");
             FastqRecord rec{std::string_view(line[0] + 1, len[0] - 1), std::string_view(line[1], len[1]),
                             std::string_view(line[3], len[3])};
@@ -317,12 +319,17 @@ inline void parse_chunk(const char *begin, const char *limit, const char *end, b
             out.error = "truncated FASTQ record";
             return;
         }
+        if (*n1 != '+') {                                            // (find_record asks the same of every later chunk)
+            out.error = "FASTQ record lacks its '+' line";
+            return;
+        }
         line_end(n1, end, n2);
-        if (n2 >= end) {                                             // no quality line
+        if (n2 >= end && e1 != n0) {                                 // no quality line although there is a sequence
             out.error = "truncated FASTQ record";
             return;
         }
-        const char *e3 = line_end(n2, end, n3);
+        n3 = end;                                                    // an empty last record may end at its '+' line
+        const char *e3 = n2 < end ? line_end(n2, end, n3) : n2;
         if (static_cast<size_t>(e1 - n0) != static_cast<size_t>(e3 - n2)) {
             out.error = "sequence and quality lengths differ";
             return;

@@ -89,11 +89,36 @@ public:
         const std::vector<uint32_t> cut = cut_evenly(n_pairs, D);
         std::vector<float> ms(3 * D, 0.f);
         std::vector<uint64_t> occ(D, 0);
+        const size_t p = num_samples_;
         for_each_device(D, [&](size_t d) {
             const uint32_t i0 = cut[d], n = cut[d + 1] - cut[d];
             if (n == 0) return;
-            check(bml_locate(ctx_[d], sample_hash, sample_pos, seg_len, n_windows, pair_bucket + i0, pair_window + i0, pair_rc + i0,
-                             n, out_offset + i0, out_votes + i0), "the GPU locator scan failed: ");
+            if (D == 1) {
+                check(bml_locate(ctx_[d], sample_hash, sample_pos, seg_len, n_windows, pair_bucket, pair_window, pair_rc, n,
+                                 out_offset, out_votes), "the GPU locator scan failed: ");
+            } else {
+                // a device is handed the samples of the windows ITS candidates name, renumbered in order of first use
+                // (candidates are grouped by bucket, so a range of them names windows from all over the batch)
+                std::vector<uint32_t> local(n_windows, 0xFFFFFFFFu), used, pw(n);
+                for (uint32_t i = 0; i < n; i++) {
+                    const uint32_t w = pair_window[i0 + i];
+                    if (w >= n_windows) throw std::runtime_error("the GPU locator scan failed: a candidate names window " + std::to_string(w));
+                    if (local[w] == 0xFFFFFFFFu) {
+                        local[w] = static_cast<uint32_t>(used.size());
+                        used.push_back(w);
+                    }
+                    pw[i] = local[w];
+                }
+                std::vector<uint32_t> hash(used.size() * p), len(used.size());
+                std::vector<uint16_t> pos(used.size() * p);
+                for (size_t u = 0; u < used.size(); u++) {
+                    std::copy(sample_hash + used[u] * p, sample_hash + (used[u] + 1) * p, hash.begin() + u * p);
+                    std::copy(sample_pos + used[u] * p, sample_pos + (used[u] + 1) * p, pos.begin() + u * p);
+                    len[u] = seg_len[used[u]];
+                }
+                check(bml_locate(ctx_[d], hash.data(), pos.data(), len.data(), static_cast<uint32_t>(used.size()), pair_bucket + i0,
+                                 pw.data(), pair_rc + i0, n, out_offset + i0, out_votes + i0), "the GPU locator scan failed: ");
+            }
             bml_last_stats(ctx_[d], &ms[3 * d], &ms[3 * d + 1], &ms[3 * d + 2], &occ[d]);
         });
         float a = 0, b = 0, c = 0;

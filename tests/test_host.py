@@ -401,6 +401,35 @@ def test_fastq_reader_finds_record_starts_anywhere(tmp_path, monkeypatch):
     for block in (16, 17, 23, 64, 100, 333, 1024, 1 << 20):
         monkeypatch.setenv("BM_IO_BLOCK", str(block))
         assert stats(path) == want, block
+    # a last record with an empty sequence and no trailing newline ends at its '+' line: accepted by every path
+    (tmp_path / "tail.fastq").write_text(text + "@last\n\n+\n")
+    for block in (16, 64, 1 << 20):
+        monkeypatch.setenv("BM_IO_BLOCK", str(block))
+        assert stats(tmp_path / "tail.fastq")[:2] == (want[0] + 1, want[1]), block
+    # a third line that does not begin with '+' is refused wherever the record lies: in the first chunk, in a later one
+    # (found by find_record) and by the block reader that serves pipes
+    noplus = text.replace("\n+\n", "\n-\n", 1)
+    (tmp_path / "noplus.fastq").write_text(noplus)
+    (tmp_path / "noplus_late.fastq").write_text(text + "@x\nACGT\n-\nIIII\n")
+    for name in ("noplus.fastq", "noplus_late.fastq"):
+        for block in (16, 64, 1 << 20):
+            monkeypatch.setenv("BM_IO_BLOCK", str(block))
+            with pytest.raises(RuntimeError):
+                stats(tmp_path / name)
+    fifo = tmp_path / "pipe.fastq"
+    os.mkfifo(fifo)
+    import threading
+    for body, ok in ((text + "@last\n\n+\n", True), (noplus, False)):
+        t = threading.Thread(target=lambda b=body: open(fifo, "w").write(b))
+        t.start()
+        try:
+            if ok:
+                assert stats(fifo)[:2] == (want[0] + 1, want[1])
+            else:
+                with pytest.raises(RuntimeError):
+                    stats(fifo)
+        finally:
+            t.join()
     # damage: a missing quality line in the middle, junk between two records, unequal lengths
     lines = text.split("\n")
     for what, bad in (("missing line", lines[:403] + lines[404:]), ("junk", lines[:400] + ["junk"] + lines[400:]),
