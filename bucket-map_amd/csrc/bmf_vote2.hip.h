@@ -38,6 +38,7 @@ constexpr int kMaxLive = 32;    // most live chunks (= lanes) an item can bring 
 constexpr int kDepthCol = 16;   // rows in flight in a 16-byte-column stream
 
 constexpr uint32_t kSlowItem = 0xFFFFFFFFu;   // live_n of an item that went to the slow queue
+constexpr uint32_t kSlowBound = 0xFFFFFF00u;  // ... from the recount kernel, which found an upper bound U of the best count: | U
 
 struct Pass2Queue {
     uint32_t *counters;         // [0] items bmf_recount_kernel has work for (statistics), [1] length of slow_items,
@@ -574,7 +575,7 @@ __global__ __launch_bounds__(kWave, BMF_RECOUNT_OCC) void bmf_recount_kernel(Dev
     for (uint32_t base = P.item_base + blockIdx.x * kPerWave; base < item_end; base += gridDim.x * kPerWave) {
         const uint32_t item = base + grp;
         uint32_t n_live = item < item_end ? Q.live_n[item] : 0u;
-        if (n_live == kSlowItem) n_live = 0;
+        if (n_live >= kSlowBound) n_live = 0;
         const bool have = n_live != 0;
         if (__ballot(have) == 0) continue;       // all results are final already
         recounted += (have && gl == 0) ? 1u : 0u;
@@ -601,6 +602,10 @@ __global__ __launch_bounds__(kWave, BMF_RECOUNT_OCC) void bmf_recount_kernel(Dev
         };
         const uint32_t bias_f = kSat - P.F;          // saturated = F misses or more (start_word's bias)
         // Round A: the chunks at the item's lowest level, exactly.  Their best count bounds m* from above.
+        // (Tried: no round A for an item whose lowest lower bound is already 3 misses or more -- the wrong strand of a
+        // read, whose level-L chunk is an arbitrary one -- sending all its chunks through round B instead.  A quarter fewer
+        // column loads and a slower kernel, 2.99 -> 5.54 ms on the uniform batch: the groups of a wave move in lockstep, a
+        // wave pays for every stream any of its groups runs, and this made most waves run both.  Reverted.)
         const bool in_a = mine && level == lv_lo;
         reset(in_a, bias_f);
         loads += stream_column<PLANES>(P, rows, list, 0u, P.G, chunk * 16u, in_a, cnt, 0u, P.S);
@@ -618,7 +623,10 @@ __global__ __launch_bounds__(kWave, BMF_RECOUNT_OCC) void bmf_recount_kernel(Dev
         const uint32_t U = min(best, kSat - 1u);      // every bucket with a lower bound above U is dead
         // a chunk the result may need was not kept by pass 1: the slow kernel takes the item
         const bool to_slow = have && U > lv_T;
-        if (to_slow && gl == 0) Q.slow_items[atomicAdd(&Q.counters[1], 1u)] = item;
+        if (to_slow && gl == 0) {
+            Q.slow_items[atomicAdd(&Q.counters[1], 1u)] = item;
+            Q.live_n[item] = kSlowBound | U;          // the slow kernel need not look above U either
+        }
         // Round B: the other chunks with a level <= U.  First one row per sample that pass 1 has NOT seen, on its own:
         // its miss count is an independent lower bound, so a chunk that survived pass 1 by chance dies here for at most
         // S sectors instead of G*S -- judged against U, on the buckets pass 1 left at or below T (its mask), in two
@@ -661,9 +669,11 @@ __global__ __launch_bounds__(kWave, BMF_RECOUNT_OCC) void bmf_recount_kernel(Dev
 
 // One item the slow way: pass 1, then the exact recount of the live chunks -- one lane per chunk up to 64,
 // else at full width with loads predicated per chunk.
+// `bound`: buckets whose pass-1 counter (biased) exceeds it are dead -- 2^PLANES - 2 ("below F") unless the recount kernel
+// has already found a bucket with a better exact count.
 template <int CPL, int PLANES, int DEPTH>
 __device__ __forceinline__ void vote2_item(const DevParams &P, const uint8_t *__restrict__ rows,
-                                           const uint32_t *__restrict__ list, uint32_t item, uint32_t lane,
+                                           const uint32_t *__restrict__ list, uint32_t item, uint32_t lane, uint32_t bound,
                                            uint32_t *live_chunk, uint32_t *__restrict__ out_counts,
                                            uint32_t *__restrict__ out_buckets) {
     uint32_t cidx[CPL], coff[CPL];
@@ -680,7 +690,12 @@ __device__ __forceinline__ void vote2_item(const DevParams &P, const uint8_t *__
     for (int j = 0; j < CPL; j++) {
         uint32_t a = 0;
 #pragma unroll
-        for (int x = 0; x < 4; x++) a |= alive_word<CPL, PLANES>(cnt, j, x);
+        for (int x = 0; x < 4; x++) {
+            uint32_t c[PLANES];
+#pragma unroll
+            for (int p = 0; p < PLANES; p++) c[p] = cnt[p][j].v[x];
+            a |= count_le<PLANES>(c, bound);
+        }
         live[j] = a != 0;
         const uint64_t m = __ballot(live[j]);
         const uint32_t at = n_live + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
@@ -734,7 +749,9 @@ __global__ __launch_bounds__(kWave) void bmf_vote2_slow_kernel(DevParams P, cons
     const uint32_t n_slow = Q.counters[1];
     for (uint32_t i = blockIdx.x; i < n_slow; i += gridDim.x) {
         const uint32_t item = Q.slow_items[i];
-        vote2_item<CPL, PLANES, DEPTH>(P, rows, row_lists + (size_t)item * P.list_len, item, threadIdx.x, live_chunk,
+        const uint32_t tag = Q.live_n[item];
+        const uint32_t bound = tag != kSlowItem && tag >= kSlowBound ? (tag & 0xFFu) : (1u << PLANES) - 2u;
+        vote2_item<CPL, PLANES, DEPTH>(P, rows, row_lists + (size_t)item * P.list_len, item, threadIdx.x, bound, live_chunk,
                                        out_counts, out_buckets);
     }
 }
