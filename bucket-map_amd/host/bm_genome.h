@@ -345,16 +345,22 @@ inline void parse_chunk(const char *begin, const char *limit, const char *end, b
 }  // namespace fastq_detail
 
 inline void for_each_fastq(const std::string &path, const std::function<void(const FastqRecord &)> &op) {
+    // A pipe (or anything else that is not a regular file) goes to the block reader, and is opened ONCE: opening a FIFO
+    // to look at it and closing it again takes the read end away from the writer.
+    struct stat st {};
+    if (::stat(path.c_str(), &st) != 0) throw std::runtime_error("cannot open FASTQ file " + path);
+    if (!S_ISREG(st.st_mode)) {
+        for_each_fastq_stream(path, op);
+        return;
+    }
     const int fd = ::open(path.c_str(), O_RDONLY);
     if (fd < 0) throw std::runtime_error("cannot open FASTQ file " + path);
-    struct stat st {};
-    const bool ok = ::fstat(fd, &st) == 0 && S_ISREG(st.st_mode);
-    const size_t size = ok ? static_cast<size_t>(st.st_size) : 0;
-    void *map = ok && size ? ::mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0) : MAP_FAILED;
+    const size_t size = static_cast<size_t>(st.st_size);
+    void *map = size ? ::mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0) : MAP_FAILED;
     ::close(fd);
     if (map == MAP_FAILED) {
-        if (ok && size == 0) return;
-        for_each_fastq_stream(path, op);                             // a pipe, or no address space: the block reader
+        if (size == 0) return;
+        for_each_fastq_stream(path, op);                             // no address space: the block reader
         return;
     }
     struct Unmap {

@@ -367,6 +367,7 @@ def test_fasta_reader_edge_cases(tmp_path):
     assert host.Genome.read_fasta(str(tmp_path / "empty.fa")).n_records == 0
 
 
+@pytest.mark.timeout(180)
 def test_fastq_reader_finds_record_starts_anywhere(tmp_path, monkeypatch):
     """The mapped FASTQ reader resynchronises at every chunk boundary on "a line that begins with '@' whose line after
     next begins with '+'".  Qualities that begin with '@' or '+', headers that look like anything, reads of every
