@@ -359,6 +359,19 @@ int bmv_align(bmv_ctx *c, const uint8_t *reads, uint64_t n_read_bytes, const uin
     };
     std::vector<Plan> plans;
     size_t need_trace = 0, need_ops = 0, need_slots = 0;
+    // A batch of one length class (or of a few neighbouring ones: 10-kbp reads with indels straddle a class boundary) gains
+    // nothing from more alignments in flight than fill the card, and fresh device memory is not free (the first call that
+    // grew the scratch to 90 GB spent 2 s in hipMalloc): only a batch that really mixes lengths -- three classes or more,
+    // the longest query at least twice the shortest class's -- may use more than 48 GiB.
+    size_t budget = std::min<size_t>(c->scratch_bytes, (size_t)48 << 30);
+    {
+        uint32_t lo_m = 0xFFFFFFFFu, hi_m = 0;
+        for (uint32_t a = 0; a < n; a++) {
+            lo_m = std::min(lo_m, std::max(query_len[a], 1024u));
+            hi_m = std::max(hi_m, query_len[a]);
+        }
+        if (n_classes >= 3 && hi_m >= 2u * lo_m) budget = c->scratch_bytes;
+    }
     for (uint32_t k = 0; k < kClasses; k++) {
         Plan pl{};
         pl.lo = class_lo[k];
@@ -385,7 +398,7 @@ int bmv_align(bmv_ctx *c, const uint8_t *reads, uint64_t n_read_bytes, const uin
         if (pl.lds > 160 * 1024) return fail(BMV_ERR_UNSUPPORTED, "text windows of %u bases need %zu B of LDS", max_n, pl.lds);
         if (pl.lds > 48 * 1024) HIP_TRY(bmhip::raise_dynamic_lds(reinterpret_cast<const void *>(pl.sh.fn), pl.lds));
         const uint64_t per_slot = pl.trace_stride / pl.gpw * 8u + (uint64_t)pl.ops_stride * 4u;
-        uint64_t chunk = std::max<uint64_t>(pl.gpw, c->scratch_bytes / per_slot);
+        uint64_t chunk = std::max<uint64_t>(pl.gpw, budget / per_slot);
         chunk = std::min<uint64_t>(chunk, (uint64_t)pl.gpw << 25);   // one wave per gpw alignments: waves * 64 threads < 2^32
         chunk = std::min<uint64_t>(chunk / pl.gpw * pl.gpw, (uint64_t)pl.members);
         if (chunk == 0) chunk = pl.members;
@@ -489,7 +502,7 @@ int bmv_align(bmv_ctx *c, const uint8_t *reads, uint64_t n_read_bytes, const uin
         const uint64_t per_slot = pl.trace_stride / pl.gpw * 8u + (uint64_t)pl.ops_stride * 4u;
         uint64_t chunk = pl.chunk;
         if (plans.size() > 1 && !serial) {
-            const uint64_t third = std::max<uint64_t>(pl.gpw, c->scratch_bytes / 3u / per_slot) / pl.gpw * pl.gpw;
+            const uint64_t third = std::max<uint64_t>(pl.gpw, budget / 3u / per_slot) / pl.gpw * pl.gpw;
             chunk = std::min<uint64_t>(chunk, std::max<uint64_t>(third, pl.gpw));
             const uint64_t n_pieces = (pl.members + chunk - 1u) / chunk;
             chunk = std::min<uint64_t>(chunk, ((pl.members + n_pieces - 1u) / n_pieces + pl.gpw - 1u) / pl.gpw * pl.gpw);
@@ -503,7 +516,7 @@ int bmv_align(bmv_ctx *c, const uint8_t *reads, uint64_t n_read_bytes, const uin
         // the pieces of this round: as many as fit the budget (at least one)
         size_t end = at, sum_trace = 0, sum_ops = 0, slots = 0;
         while (end < todo.size() && (end == at || (!serial && (sum_trace + todo[end].trace_words) * 8u + (sum_ops + todo[end].ops_words) * 4u <=
-                                                                   c->scratch_bytes))) {
+                                                                   budget))) {
             sum_trace += todo[end].trace_words;
             sum_ops += todo[end].ops_words;
             slots += todo[end].count;
