@@ -10,6 +10,7 @@
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -91,7 +92,7 @@ struct bml_ctx {
     DevBuf<uint16_t> s_pos, s_table;
     uint32_t s_table_len = 0;        // windows up to this length are tabulated
     DevBuf<unsigned long long> occ_count;
-    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // scan | (gap) | light replay | heavy replay
     float ms[3] = {0, 0, 0};
     uint64_t last_occ = 0;
 };
@@ -127,7 +128,7 @@ int bml_create(const bml_params *params, bml_ctx **out) {
     c->scan_lds = lds;
     c->max_pairs_per_chunk = max_pairs;
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
-    for (int i = 0; i < 4 && e == hipSuccess; i++) e = hipEventCreate(&c->ev[i]);
+    for (int i = 0; i < 6 && e == hipSuccess; i++) e = hipEventCreate(&c->ev[i]);
     if (e == hipSuccess && lds > 48 * 1024)
         e = bmhip::raise_dynamic_lds(reinterpret_cast<const void *>(bml::bml_scan_kernel), lds);
     uint8_t lut[256];
@@ -135,7 +136,7 @@ int bml_create(const bml_params *params, bml_ctx **out) {
     if (e == hipSuccess) e = c->lut.need(256);
     if (e == hipSuccess) e = hipMemcpy(c->lut.p, lut, 256, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = c->occ_count.need(1);
-    if (e == hipSuccess) e = c->n_heavy.need(1);
+    if (e == hipSuccess) e = c->n_heavy.need(3);
     if (e == hipSuccess) (void)hipDeviceGetAttribute(&c->n_cu, hipDeviceAttributeMultiprocessorCount, p.device);
     if (c->n_cu <= 0) c->n_cu = 256;
     if (e != hipSuccess) {
@@ -320,7 +321,7 @@ int bml_locate(bml_ctx *c, const uint32_t *sample_hash, const uint16_t *sample_p
     }
     c->last_occ = n_occ;
     HIP_TRY(c->heavy.need(n_pairs));
-    HIP_TRY(hipMemsetAsync(c->n_heavy.p, 0, sizeof(uint32_t), c->stream));
+    HIP_TRY(hipMemsetAsync(c->n_heavy.p, 0, 3 * sizeof(uint32_t), c->stream));   // count, largest, queue head
     HIP_TRY(hipEventRecord(c->ev[2], c->stream));
     {
         auto light = [&](auto kernel, unsigned threads) {
@@ -333,25 +334,35 @@ int bml_locate(bml_ctx *c, const uint32_t *sample_hash, const uint16_t *sample_p
         else light(bml::bml_replay_light_kernel<64, 128>, 128);
     }
     HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(c->ev[4], c->stream));
     // candidates with more occurrences than the light kernel takes (repeats): one workgroup each, dense bitmaps of the start positions
-    uint32_t n_heavy = 0;
-    HIP_TRY(hipMemcpyAsync(&n_heavy, c->n_heavy.p, sizeof n_heavy, hipMemcpyDeviceToHost, c->stream));
+    uint32_t heavy_info[2] = {0, 0};                          // their number, and the most occurrences one of them has
+    HIP_TRY(hipMemcpyAsync(heavy_info, c->n_heavy.p, sizeof heavy_info, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    const uint32_t n_heavy = heavy_info[0];
+    if (getenv("BML_LOG"))
+        fprintf(stderr, "[bml] %u candidates, %llu occurrences; %u heavy candidates, the largest with %u occurrences\n", n_pairs,
+                (unsigned long long)n_occ, n_heavy, heavy_info[1]);
     c->last_heavy = n_heavy;
     if (n_heavy) {
         uint32_t max_seg = 0;
         for (uint32_t w = 0; w < n_windows; w++) max_seg = std::max(max_seg, seg_len[w]);
         const uint32_t range = c->p.max_bucket_bases + max_seg, words = (range + 31u) / 32u;
-        const unsigned grid = (unsigned)std::min<uint32_t>(n_heavy, 2u * (uint32_t)c->n_cu);
-        const size_t lds = (size_t)3 * words * sizeof(uint32_t);
-        const bool in_lds = lds <= 150 * 1024;
-        if (in_lds && lds > 48 * 1024)
+        const size_t lds_occ = (size_t)bml::kHeavyLdsOcc * sizeof(uint32_t);
+        const bool in_lds = lds_occ + (size_t)3 * words * sizeof(uint32_t) <= 150 * 1024;
+        const size_t lds = lds_occ + (in_lds ? (size_t)3 * words * sizeof(uint32_t) : 0);
+        if (lds > 48 * 1024)
             HIP_TRY(bmhip::raise_dynamic_lds(reinterpret_cast<const void *>(bml::bml_replay_heavy_kernel), lds));
+        // as many workgroups as the CUs hold at once (LDS decides: 1 per CU at 262 144-base buckets, 3 at 65 536)
+        const uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(8, (size_t)(156 * 1024) / (lds + 1024)));
+        const unsigned grid = (unsigned)std::min<uint32_t>(n_heavy, per_cu * (uint32_t)c->n_cu);
         HIP_TRY(c->heavy_votes.need((size_t)grid * range));
         if (!in_lds) HIP_TRY(c->heavy_bitmaps.need((size_t)grid * 3 * words));
-        HIP_TRY(c->occ_b.need((size_t)n_occ));
-        const bml::HeavyScratch hs{c->heavy_votes.p, c->heavy_bitmaps.p, c->occ_b.p};
-        hipLaunchKernelGGL(bml::bml_replay_heavy_kernel, dim3(grid), dim3(bml::kThreads), in_lds ? lds : 0, c->stream, c->lp,
+        // candidates whose occurrences do not fit the kernel's LDS copy group them by sample in a second buffer
+        if (heavy_info[1] > bml::kHeavyLdsOcc) HIP_TRY(c->occ_b.need((size_t)n_occ));
+        const bml::HeavyScratch hs{c->heavy_votes.p, c->heavy_bitmaps.p, heavy_info[1] > bml::kHeavyLdsOcc ? c->occ_b.p : nullptr};
+        HIP_TRY(hipEventRecord(c->ev[5], c->stream));            // (the allocations above are not replay time)
+        hipLaunchKernelGGL(bml::bml_replay_heavy_kernel, dim3(grid), dim3(bml::kThreads), lds, c->stream, c->lp,
                            c->occ_a.p, c->cand_start.p, c->cand_count.p, c->sample_pos.p, c->seg_len.p, c->pair_window.p, c->pair_rc.p, c->heavy.p,
                            c->n_heavy.p, range, max_seg, in_lds ? 1u : 0u, hs, c->out_offset.p, c->out_votes.p);
     }
@@ -360,7 +371,13 @@ int bml_locate(bml_ctx *c, const uint32_t *sample_hash, const uint16_t *sample_p
     HIP_TRY(hipMemcpyAsync(out_offset, c->out_offset.p, (size_t)n_pairs * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipMemcpyAsync(out_votes, c->out_votes.p, (size_t)n_pairs * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    for (int i = 0; i < 3; i++) HIP_TRY(hipEventElapsedTime(&c->ms[i], c->ev[i], c->ev[i + 1]));
+    for (int i = 0; i < 2; i++) HIP_TRY(hipEventElapsedTime(&c->ms[i], c->ev[i], c->ev[i + 1]));
+    HIP_TRY(hipEventElapsedTime(&c->ms[2], c->ev[2], c->ev[4]));          // light replay ...
+    if (n_heavy) {                                                        // ... + heavy replay, without the host gap between them
+        float heavy_ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&heavy_ms, c->ev[5], c->ev[3]));
+        c->ms[2] += heavy_ms;
+    }
     return BML_OK;
 }
 

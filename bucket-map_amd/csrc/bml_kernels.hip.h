@@ -225,6 +225,7 @@ __global__ __launch_bounds__(kLightThreads) void bml_replay_light_kernel(
     const uint32_t n = cand_count[pair];
     if (n > kLightMax) {
         heavy[atomicAdd(n_heavy, 1u)] = pair;
+        atomicMax(n_heavy + 1, n);
         return;
     }
     // (sample in processing order) ascending, offset descending: insertion sort while loading
@@ -315,10 +316,13 @@ __global__ __launch_bounds__(kLightThreads) void bml_replay_light_kernel(
 //   4. the new proposals join `exists`.
 // Winner: most votes, ties -> smallest start (:281-283), accepted as in the light kernel.
 // Bitmaps live in LDS when 3 of them fit (`lds_bitmaps`), else in the workgroup's global scratch.
+constexpr uint32_t kHeavyLdsOcc = 6144;          // occurrences of one candidate kept in LDS (24 KB)
+
 struct HeavyScratch {
     uint32_t *votes;        // per workgroup: range entries
     uint32_t *bitmaps;      // per workgroup: 3 x words (used when the bitmaps do not fit LDS)
-    uint64_t *by_sample;    // the candidate's occurrences grouped by sample: same layout as the grouped buffer
+    uint64_t *by_sample;    // candidates with more than kHeavyLdsOcc occurrences: theirs grouped by sample, same layout as
+                            // the occurrence buffer (null when no candidate is that large)
 };
 
 __global__ __launch_bounds__(kThreads) void bml_replay_heavy_kernel(
@@ -329,14 +333,19 @@ __global__ __launch_bounds__(kThreads) void bml_replay_heavy_kernel(
     uint32_t range, uint32_t bias, uint32_t lds_bitmaps, HeavyScratch S, int32_t *__restrict__ out_offset,
     uint32_t *__restrict__ out_votes) {
     extern __shared__ uint32_t heavy_lds[];
-    __shared__ uint32_t s_hist[65], s_cursor[64], s_fresh, s_new, s_np;
+    __shared__ uint32_t s_hist[65], s_cursor[64], s_fresh, s_new, s_np, s_fmax, s_fmin, s_next;
     __shared__ unsigned long long s_best;
     const uint32_t tid = threadIdx.x, words = (range + 31u) / 32u;
-    uint32_t *exists = lds_bitmaps ? heavy_lds : S.bitmaps + (size_t)blockIdx.x * 3u * words;
+    uint32_t *locc = heavy_lds;                  // a candidate's occurrences grouped by sample (kHeavyLdsOcc of them fit)
+    uint32_t *exists = lds_bitmaps ? heavy_lds + kHeavyLdsOcc : S.bitmaps + (size_t)blockIdx.x * 3u * words;
     uint32_t *fresh = exists + words, *fnew = fresh + words;
     uint32_t *votes = S.votes + (size_t)blockIdx.x * range;
     const int32_t d = P.allowed_indel;
     const uint32_t total = *n_heavy;
+    // The bitmaps are all zero between candidates: a candidate only ever sets bits at the start positions of its own
+    // occurrences, and clears exactly those words when it is done -- per candidate the work is O(occurrences), not O(range).
+    for (uint32_t i = tid; i < 3u * words; i += kThreads) exists[i] = 0;
+    __syncthreads();
     // any bit of bm set in [lo, hi] (inclusive, clamped to the range)?  op(pos) for every set bit.
     auto for_bits = [&](const uint32_t *bm, int64_t lo, int64_t hi, auto op) {
         if (lo < 0) lo = 0;
@@ -355,7 +364,13 @@ __global__ __launch_bounds__(kThreads) void bml_replay_heavy_kernel(
         }
         return any;
     };
-    for (uint32_t h = blockIdx.x; h < total; h += gridDim.x) {
+    // candidates are handed out one at a time (their costs differ a hundredfold): n_heavy[2] is the queue's head
+    for (;;) {
+        __syncthreads();
+        if (tid == 0) s_next = atomicAdd(const_cast<uint32_t *>(n_heavy) + 2, 1u);
+        __syncthreads();
+        const uint32_t h = s_next;
+        if (h >= total) break;
         const uint32_t pair = heavy[h];
         const uint64_t first = cand_start[pair], n = cand_count[pair];
         const uint32_t w = pair_window[pair];
@@ -363,7 +378,6 @@ __global__ __launch_bounds__(kThreads) void bml_replay_heavy_kernel(
         const uint32_t length = seg_len[w];
         // 0. the occurrences grouped by sample (counting sort on the sample number)
         for (uint32_t i = tid; i < 65u; i += kThreads) s_hist[i] = 0;
-        for (uint32_t i = tid; i < words; i += kThreads) exists[i] = fresh[i] = fnew[i] = 0;
         if (tid == 0) s_np = 0;
         __syncthreads();
         for (uint64_t i = tid; i < n; i += kThreads) atomicAdd(&s_hist[(uint32_t)(keys[first + i] >> 32) - pair * P.p + 1u], 1u);
@@ -373,10 +387,14 @@ __global__ __launch_bounds__(kThreads) void bml_replay_heavy_kernel(
             for (uint32_t i = 0; i < P.p; i++) s_cursor[i] = s_hist[i];
         }
         __syncthreads();
-        uint64_t *mine = S.by_sample + first;
+        // ... into LDS (their bucket offsets, 4 bytes each) when they fit, else into the global scratch
+        const bool in_lds = n <= kHeavyLdsOcc;
+        uint64_t *mine = S.by_sample ? S.by_sample + first : nullptr;
         for (uint64_t i = tid; i < n; i += kThreads) {
             const uint64_t key = keys[first + i];
-            mine[atomicAdd(&s_cursor[(uint32_t)(key >> 32) - pair * P.p], 1u)] = key;
+            const uint32_t at = atomicAdd(&s_cursor[(uint32_t)(key >> 32) - pair * P.p], 1u);
+            if (in_lds) locc[at] = 0x7FFFFFFFu - (uint32_t)key;
+            else mine[at] = key;
         }
         __syncthreads();
         for (uint32_t i = 0; i < P.p; i++) {
@@ -385,36 +403,48 @@ __global__ __launch_bounds__(kThreads) void bml_replay_heavy_kernel(
             const uint32_t o0 = s_hist[i], o1 = s_hist[i + 1];
             if (o0 == o1) continue;                                  // (uniform: s_hist is shared)
             // start position of an occurrence, shifted by `bias` into [0, range)
-            auto start_of = [&](uint64_t key) { return (uint32_t)((int32_t)((0x7FFFFFFFu - (uint32_t)key) - idx) + (int32_t)bias); };
+            auto start_of = [&](uint32_t occ) { return (uint32_t)((int32_t)(occ - idx) + (int32_t)bias); };
+            // every step below walks the sample's occurrences again: from the LDS copy when the candidate's fit there
+            auto for_each_pos = [&](auto fn) {
+                if (in_lds)
+                    for (uint32_t o = o0 + tid; o < o1; o += kThreads) fn(start_of(locc[o]));
+                else
+                    for (uint32_t o = o0 + tid; o < o1; o += kThreads) fn(start_of(0x7FFFFFFFu - (uint32_t)mine[o]));
+            };
             if (s_np == 0) {                                         // :247-251 the map was empty: every start goes in
                 __syncthreads();
-                for (uint32_t o = o0 + tid; o < o1; o += kThreads) {
-                    const uint32_t pos = start_of(mine[o]);
+                for_each_pos([&](uint32_t pos) {
                     atomicOr(&exists[pos >> 5], 1u << (pos & 31u));
                     votes[pos] = 1;
-                }
+                });
                 if (tid == 0) s_np = o1 - o0;
                 __syncthreads();
                 continue;
             }
-            if (tid == 0) s_fresh = s_new = 0;
+            if (tid == 0) {
+                s_fresh = s_new = 0;
+                s_fmax = 0;
+                s_fmin = 0xFFFFFFFFu;
+            }
             __syncthreads();
             // 1. votes for the proposals that were there before this sample
-            for (uint32_t o = o0 + tid; o < o1; o += kThreads) {
-                const uint32_t pos = start_of(mine[o]);
+            for_each_pos([&](uint32_t pos) {
                 const bool hit = for_bits(exists, (int64_t)pos - d, (int64_t)pos + d, [&](uint32_t at) { atomicAdd(&votes[at], 1u); });
                 if (!hit) {
                     atomicOr(&fresh[pos >> 5], 1u << (pos & 31u));
                     atomicAdd(&s_fresh, 1u);
+                    atomicMax(&s_fmax, pos);
+                    atomicMin(&s_fmin, pos);
                 }
-            }
+            });
             __syncthreads();
             if (s_fresh == 0) continue;
             // 2. new proposals among the fresh starts, highest first (one wave)
             if (tid < 64) {
-                int64_t limit = (int64_t)range - 1;                  // the next proposal lies at or below `limit`
+                int64_t limit = (int64_t)s_fmax;                     // the next proposal lies at or below `limit`
+                const int64_t lowest = (int64_t)s_fmin;
                 uint32_t made = 0;
-                while (limit >= 0) {
+                while (limit >= lowest) {
                     // the 64 words at and below limit's word, lane l takes word (top - l)
                     const int64_t top = limit >> 5, wd = top - (int64_t)tid;
                     uint32_t bits = wd >= 0 ? fresh[wd] : 0u;
@@ -438,31 +468,37 @@ __global__ __launch_bounds__(kThreads) void bml_replay_heavy_kernel(
             }
             __syncthreads();
             // 3. votes for the new proposal within indel above an occurrence
-            for (uint32_t o = o0 + tid; o < o1; o += kThreads) {
-                const uint32_t pos = start_of(mine[o]);
+            for_each_pos([&](uint32_t pos) {
                 (void)for_bits(fnew, (int64_t)pos + 1, (int64_t)pos + d, [&](uint32_t at) { atomicAdd(&votes[at], 1u); });
-            }
+            });
             __syncthreads();
-            // 4. the new proposals join the map
-            for (uint32_t wd = tid; wd < words; wd += kThreads) {
-                exists[wd] |= fnew[wd];
-                fresh[wd] = 0;
-                fnew[wd] = 0;
-            }
+            // 4. the new proposals join the map (they sit at start positions of this sample's occurrences: those words only)
+            for_each_pos([&](uint32_t pos) {
+                const uint32_t nw = fnew[pos >> 5];
+                if (nw) atomicOr(&exists[pos >> 5], nw);
+            });
+            __syncthreads();
+            for_each_pos([&](uint32_t pos) {
+                fresh[pos >> 5] = 0;
+                fnew[pos >> 5] = 0;
+            });
             if (tid == 0) s_np += s_new;
             __syncthreads();
         }
-        // winner: most votes, ties -> smallest start
+        // winner: most votes, ties -> smallest start.  Every proposal sits at the start position of some occurrence.
         if (tid == 0) s_best = 0;
         __syncthreads();
         unsigned long long best = 0;
-        for (uint32_t wd = tid; wd < words; wd += kThreads) {
-            uint32_t bits = exists[wd];
-            while (bits) {
-                const uint32_t pos = wd * 32u + (uint32_t)__builtin_ctz(bits);
-                bits &= bits - 1u;
-                const unsigned long long cand = ((unsigned long long)votes[pos] << 32) | (0xFFFFFFFFu - pos);
-                best = cand > best ? cand : best;
+        for (uint32_t i = 0; i < P.p; i++) {
+            uint32_t idx = sample_pos[(size_t)w * P.p + (rc ? P.p - 1u - i : i)];
+            if (rc) idx = length - P.k - idx;
+            for (uint32_t o = s_hist[i] + tid; o < s_hist[i + 1]; o += kThreads) {
+                const uint32_t occ = in_lds ? locc[o] : 0x7FFFFFFFu - (uint32_t)mine[o];
+                const uint32_t pos = (uint32_t)((int32_t)(occ - idx) + (int32_t)bias);
+                if ((exists[pos >> 5] >> (pos & 31u)) & 1u) {
+                    const unsigned long long cand = ((unsigned long long)votes[pos] << 32) | (0xFFFFFFFFu - pos);
+                    best = cand > best ? cand : best;
+                }
             }
         }
         atomicMax(&s_best, best);
@@ -480,6 +516,15 @@ __global__ __launch_bounds__(kThreads) void bml_replay_heavy_kernel(
             }
             out_offset[pair] = off;
             out_votes[pair] = nv;
+        }
+        __syncthreads();
+        for (uint32_t i = 0; i < P.p; i++) {                       // leave the map empty for the next candidate
+            uint32_t idx = sample_pos[(size_t)w * P.p + (rc ? P.p - 1u - i : i)];
+            if (rc) idx = length - P.k - idx;
+            for (uint32_t o = s_hist[i] + tid; o < s_hist[i + 1]; o += kThreads) {
+                const uint32_t occ = in_lds ? locc[o] : 0x7FFFFFFFu - (uint32_t)mine[o];
+                exists[((uint32_t)((int32_t)(occ - idx) + (int32_t)bias)) >> 5] = 0;
+            }
         }
         __syncthreads();
     }
