@@ -99,13 +99,15 @@ vote_fn pick_vote(int cpl, int planes, bool prune) {
 
 // two-pass exact pruning (bmf_vote2.hip.h), unsliced geometries only
 using pass1_fn = void (*)(bmf::DevParams, const uint8_t *, const uint32_t *, const uint32_t *, uint32_t *, bmf::Pass2Queue);
-using recount_fn = void (*)(bmf::DevParams, const uint8_t *, const uint32_t *, uint32_t, uint32_t *, uint32_t *, bmf::Pass2Queue);
+using recount_fn = void (*)(bmf::DevParams, const uint8_t *, const uint32_t *, uint32_t, uint32_t *, uint32_t *, bmf::Pass2Queue, uint32_t);
+using finish_fn = void (*)(bmf::DevParams, const uint8_t *, const uint32_t *, uint32_t, uint32_t *, uint32_t *, bmf::Pass2Queue);
 using slow_fn = void (*)(bmf::DevParams, const uint8_t *, const uint32_t *, uint32_t *, uint32_t *, bmf::Pass2Queue);
 
 struct TwoPass {
     pass1_fn pass1 = nullptr;
     recount_fn recount = nullptr;
     slow_fn slow = nullptr;
+    finish_fn finish = nullptr;
 };
 
 template <int CPL, int PLANES>
@@ -117,7 +119,7 @@ TwoPass two_pass_of(int max_live) {
         if (env && env[0] == '1') p1 = bmf::bmf_pass1_kernel<CPL, PLANES, D - 1>;
     }
     recount_fn rc = max_live <= 16 ? bmf::bmf_recount_kernel<PLANES, 16> : bmf::bmf_recount_kernel<PLANES, 32>;
-    return {p1, rc, bmf::bmf_vote2_slow_kernel<CPL, PLANES, D>};
+    return {p1, rc, bmf::bmf_vote2_slow_kernel<CPL, PLANES, D>, bmf::bmf_finish_kernel<PLANES>};
 }
 
 template <int CPL>
@@ -214,7 +216,7 @@ struct bmf_batch {
     DevBuf<uint64_t> win_start;
     DevBuf<uint32_t> win_len, lists, list_n, rows_anded, counts, buckets, offsets, compact;
     DevBuf<uint32_t> slice_min, slice_cnt, slice_ids;   // NB > 65 536 only
-    DevBuf<uint32_t> q_counters, q_slow, q_live_n;   // two-pass pruning only (bmf::Pass2Queue)
+    DevBuf<uint32_t> q_counters, q_slow, q_live_n, q_left;   // two-pass pruning only (bmf::Pass2Queue)
     DevBuf<uint16_t> q_live_chunks;
     DevBuf<uint4> q_live_mask;
 };
@@ -258,6 +260,7 @@ struct bmf_ctx {
     uint32_t tune_windows = 32768;
     double guard_baseline = -1.0;    // share of slow-path items of the first run after tuning (< 0: not sampled yet)
     unsigned recount_waves = 4096;   // waves of the recount kernel the device holds at once (CUs x 4 SIMDs x BMF_RECOUNT_OCC)
+    bool no_finish = false;          // BMF_NO_FINISH=1: every item through the recount kernel (experiments)
     size_t sample_lds = 0;
     bmf::SampleGeom sample_geom{};
     bool sample_bitmap_lds = false;
@@ -373,6 +376,7 @@ int bmf_create(const bmf_params *params, bmf_ctx **out) {
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, p.device) == hipSuccess && cus > 0)
             c->recount_waves = (unsigned)cus * 4u * BMF_RECOUNT_OCC;
         if (const char *env = getenv("BMF_RECOUNT_WAVES")) c->recount_waves = (unsigned)std::max(64, atoi(env));   // experiments
+        c->no_finish = getenv("BMF_NO_FINISH") != nullptr;
     }
     const bool prune = (p.flags & BMF_FLAG_EARLY_EXIT) != 0;
     c->vote = n_slices > 1 ? pick_sliced(planes, prune) : pick_vote(cpl, planes, prune);
@@ -696,7 +700,7 @@ static void release_batch(bmf_batch *b) {
     b->lists.release(); b->list_n.release(); b->rows_anded.release(); b->counts.release(); b->buckets.release();
     b->offsets.release(); b->compact.release();
     b->slice_min.release(); b->slice_cnt.release(); b->slice_ids.release();
-    b->q_counters.release(); b->q_slow.release(); b->q_live_n.release(); b->q_live_chunks.release(); b->q_live_mask.release();
+    b->q_counters.release(); b->q_slow.release(); b->q_live_n.release(); b->q_left.release(); b->q_live_chunks.release(); b->q_live_mask.release();
 }
 
 static void free_map_slots(bmf_ctx *c) {
@@ -1157,11 +1161,12 @@ static int launch_vote_stage(bmf_ctx *c, bmf_batch *b, uint32_t n_windows) {
         }
         HIP_TRY(b->q_counters.need(4));
         HIP_TRY(b->q_slow.need(2 * (size_t)b->n_windows));
+        HIP_TRY(b->q_left.need(2 * (size_t)b->n_windows));
         HIP_TRY(b->q_live_n.need(2 * (size_t)b->n_windows));
         HIP_TRY(b->q_live_chunks.need(2 * (size_t)b->n_windows * bmf::kMaxLive));
         HIP_TRY(b->q_live_mask.need(2 * (size_t)b->n_windows * c->dp.max_live));
         HIP_TRY(hipMemsetAsync(b->q_counters.p, 0, 4 * sizeof(uint32_t), c->stream));
-        const bmf::Pass2Queue q{b->q_counters.p, b->q_slow.p, b->q_live_n.p, b->q_live_chunks.p, b->q_live_mask.p};
+        const bmf::Pass2Queue q{b->q_counters.p, b->q_slow.p, b->q_left.p, b->q_live_n.p, b->q_live_chunks.p, b->q_live_mask.p};
         const size_t per_wave = bmf::kWave / c->dp.max_live;   // items per wave of the recount kernel
         const size_t recount_lds = per_wave * (size_t)c->dp.S * c->dp.G * sizeof(uint32_t);
         // Fixed grids: the recount walks all items (most keep a few live chunks), the slow kernel strides over the
@@ -1204,9 +1209,19 @@ static int launch_vote_stage(bmf_ctx *c, bmf_batch *b, uint32_t n_windows) {
             // One resident round of waves, each walking its share of the items: the recount kernel spills a few
             // registers to scratch, and a wave that needs scratch takes ~75 us to start (measured: 32 768 one-item waves
             // took 0.87 ms for the work 4 096 waves do in 0.3 ms) -- so no more waves than the card holds at once.
+            // items with ONE stored chunk: a lane each (bmf_finish_kernel); the rest, queued by it, go through the recount
+            // kernel.  (Not with BMF_SLICES: the slices' kernels overlap and would share the queue.)
+            const size_t finish_lds = (size_t)bmf::kWave * ((size_t)(c->dp.S * c->dp.G) | 1u) * sizeof(uint32_t);
+            const bool finish = n_sl == 1 && finish_lds <= 150 * 1024 && !c->no_finish;
+            if (finish) {
+                if (finish_lds > 48 * 1024)
+                    HIP_TRY(bmhip::raise_dynamic_lds(reinterpret_cast<const void *>(c->two_pass.finish), finish_lds));
+                hipLaunchKernelGGL(c->two_pass.finish, dim3((unsigned)((count + bmf::kWave - 1) / bmf::kWave)), dim3(bmf::kWave),
+                                   finish_lds, rs, dp, c->d_rows, b->lists.p, (uint32_t)count, b->counts.p, b->buckets.p, q);
+            }
             const unsigned recount_blocks = (unsigned)std::min<size_t>((count + per_wave - 1) / per_wave, c->recount_waves);
             hipLaunchKernelGGL(c->two_pass.recount, dim3(recount_blocks), dim3(bmf::kWave), recount_lds, rs, dp, c->d_rows, b->lists.p,
-                               (uint32_t)count, b->counts.p, b->buckets.p, q);
+                               (uint32_t)count, b->counts.p, b->buckets.p, q, finish ? 1u : 0u);
         }
         if (n_sl > 1) {
             HIP_TRY(hipEventRecord(c->side_done, c->side));

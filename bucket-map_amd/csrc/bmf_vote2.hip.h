@@ -41,9 +41,10 @@ constexpr uint32_t kSlowItem = 0xFFFFFFFFu;   // live_n of an item that went to 
 constexpr uint32_t kSlowBound = 0xFFFFFF00u;  // ... from the recount kernel, which found an upper bound U of the best count: | U
 
 struct Pass2Queue {
-    uint32_t *counters;         // [0] items bmf_recount_kernel has work for (statistics), [1] length of slow_items,
-                                // [2] 16-byte column loads bmf_recount_kernel issued (statistics: one 64-byte sector each)
+    uint32_t *counters;         // [0] items the finish / recount kernels had work for (statistics), [1] length of slow_items,
+                                // [2] 16-byte column loads they issued (statistics: one 64-byte sector each), [3] length of left_items
     uint32_t *slow_items;
+    uint32_t *left_items;       // items bmf_finish_kernel left to bmf_recount_kernel (more than one stored chunk)
     uint32_t *live_n;           // per item: 0 (result already final), kSlowItem, or n | L << 8 | T << 16 -- n chunks are
                                 // stored, every chunk whose LEVEL (lowest pass-1 counter among its buckets) is <= T; L is
                                 // the item's lowest level (counters biased as below, so 2^PLANES - 1 is "F misses or more")
@@ -77,6 +78,25 @@ __device__ __forceinline__ uint32_t min_level(const uint32_t (&c)[PLANES][NW]) {
         const bool some = any != 0;
 #pragma unroll
         for (int w = 0; w < NW; w++) cand[w] = some ? cand[w] & ~c[p][w] : cand[w];
+        level |= some ? 0u : 1u << p;
+    }
+    return level;
+}
+
+// ... and which buckets hold it (cand), for the four words of one chunk
+template <int PLANES>
+__device__ __forceinline__ uint32_t min_candidates(const u128 (&cnt)[PLANES], uint32_t (&cand)[4]) {
+    uint32_t level = 0;
+#pragma unroll
+    for (int x = 0; x < 4; x++) cand[x] = 0xFFFFFFFFu;
+#pragma unroll
+    for (int p = PLANES - 1; p >= 0; p--) {
+        uint32_t any = 0;
+#pragma unroll
+        for (int x = 0; x < 4; x++) any |= cand[x] & ~cnt[p].v[x];
+        const bool some = any != 0;
+#pragma unroll
+        for (int x = 0; x < 4; x++) cand[x] = some ? cand[x] & ~cnt[p].v[x] : cand[x];
         level |= some ? 0u : 1u << p;
     }
     return level;
@@ -553,6 +573,83 @@ __device__ __forceinline__ uint32_t stream_column(const DevParams &P, const uint
     return act ? n_rows : 0u;
 }
 
+// One LANE per item.  Most items leave pass 1 with exactly ONE stored chunk -- the read's own -- and in the recount kernel
+// its exact count is a stream that one lane in 16 or 32 takes part in.  Here 64 such items share a wave: every lane
+// streams its own item's chunk through all S*G rows (its row-id list in LDS, odd stride: the lanes of a wave hit
+// different banks), finds the buckets at the minimum and writes the item's result (best_results over one chunk; the
+// > max_candidates rule).  Items with more stored chunks are queued, one atomic per wave, for bmf_recount_kernel.
+template <int PLANES>
+__global__ __launch_bounds__(kWave) void bmf_finish_kernel(DevParams P, const uint8_t *__restrict__ rows,
+                                                          const uint32_t *__restrict__ row_lists, uint32_t n_items,
+                                                          uint32_t *__restrict__ out_counts, uint32_t *__restrict__ out_buckets,
+                                                          Pass2Queue Q) {
+    extern __shared__ uint32_t lds_lists[];
+    const uint32_t lane = threadIdx.x, n_ids = P.S * P.G, stride = n_ids | 1u;
+    const uint32_t item0 = P.item_base + blockIdx.x * kWave, item_end = P.item_base + n_items, item = item0 + lane;
+    const uint32_t tag = item < item_end ? Q.live_n[item] : 0u;
+    const uint32_t n = tag >= kSlowBound ? 0u : (tag & 0xFFu);
+    const bool single = n == 1u;
+    const uint64_t singles = __ballot(single);
+    for (uint64_t todo = singles; todo; todo &= todo - 1ull) {       // their lists, one coalesced copy each
+        const uint32_t i = (uint32_t)__builtin_ctzll(todo);
+        for (uint32_t e = lane; e < n_ids; e += kWave) lds_lists[i * stride + e] = row_lists[(size_t)(item0 + i) * P.list_len + e];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    constexpr uint32_t kSat = (1u << PLANES) - 1u;
+    const uint32_t chunk = single ? (Q.live_chunks[(size_t)item * P.max_live] & ((1u << kChunkIdBits) - 1u)) : 0u;
+    u128 cnt[PLANES];
+#pragma unroll
+    for (int x = 0; x < 4; x++) {
+        const uint32_t bits = single ? bucket_mask(P, chunk, x) : 0u;
+#pragma unroll
+        for (int p = 0; p < PLANES; p++) cnt[p].v[x] = start_word<PLANES>(P, bits, p);
+    }
+    uint32_t loads = stream_column<PLANES>(P, rows, lds_lists + lane * stride, 0u, P.G, chunk * 16u, single, cnt, 0u, P.S);
+    if (single) {
+        uint32_t cand[4];
+        const uint32_t level = min_candidates<PLANES>(cnt, cand);
+        const uint32_t total = __popc(cand[0]) + __popc(cand[1]) + __popc(cand[2]) + __popc(cand[3]);
+        const uint32_t U = min(level, kSat - 1u), lv_T = (tag >> 16) & 0xFFu;
+        if (U > lv_T) {
+            // the one stored chunk was all that FIT, not all there was: chunks at levels up to U were left out and may
+            // hold the result -- the slow kernel takes the item, as from the recount kernel
+            Q.slow_items[atomicAdd(&Q.counters[1], 1u)] = item;
+            Q.live_n[item] = kSlowBound | U;
+        } else if (level == kSat || total > P.max_cand) {        // nothing below F misses / more than max_candidates tie
+            out_counts[item] = 0;
+            Q.live_n[item] = 0;
+        } else {
+            uint32_t *__restrict__ out = out_buckets + (size_t)item * P.max_cand;
+            uint32_t pos = 0;
+#pragma unroll
+            for (int x = 0; x < 4; x++) {
+                uint32_t bits = cand[x];
+                while (bits) {
+                    out[pos++] = chunk * 128u + x * 32u + (uint32_t)__builtin_ctz(bits);
+                    bits &= bits - 1u;
+                }
+            }
+            out_counts[item] = total;
+            Q.live_n[item] = 0;                                  // final
+        }
+    }
+    const bool left = n >= 2u;
+    const uint64_t lm = __ballot(left);
+    if (lm) {
+        uint32_t base = 0;
+        if (lane == (uint32_t)__builtin_ctzll(lm)) base = atomicAdd(&Q.counters[3], (uint32_t)__popcll(lm));
+        base = (uint32_t)__shfl((int)base, __builtin_ctzll(lm), kWave);
+        if (left) Q.left_items[base + (uint32_t)__popcll(lm & ((1ull << lane) - 1ull))] = item;
+    }
+    loads = wave_sum(loads);
+    if (lane == 0 && singles) {
+        atomicAdd(&Q.counters[0], (uint32_t)__popcll(singles));
+        atomicAdd(&Q.counters[2], loads);
+    }
+}
+
 // (4 waves per SIMD asked for: at most 128 VGPRs, the latency of the short dependent streams needs the waves.  The 16
 //  registers this spills cost less than the waves they buy: pruned Egu step 16.96 ms; 17.35 ms at 3 waves and no spill,
 //  21.3 ms at 5 waves -- tools/try_libs.sh over builds with -DBMF_RECOUNT_OCC=3 / 5.)
@@ -563,18 +660,19 @@ template <int PLANES, int LIVE>
 __global__ __launch_bounds__(kWave, BMF_RECOUNT_OCC) void bmf_recount_kernel(DevParams P, const uint8_t *__restrict__ rows,
                                                            const uint32_t *__restrict__ row_lists, uint32_t n_items,
                                                            uint32_t *__restrict__ out_counts,
-                                                           uint32_t *__restrict__ out_buckets, Pass2Queue Q) {
+                                                           uint32_t *__restrict__ out_buckets, Pass2Queue Q, uint32_t from_queue) {
     extern __shared__ uint32_t lds_lists[];      // the row-id lists of the wave's items: every lane of a
     constexpr uint32_t kPerWave = kWave / LIVE;   // group reads the same entry at every step
     const uint32_t lane = threadIdx.x, grp = lane / LIVE, gl = lane % LIVE;
     const uint32_t n_ids = P.S * P.G;
     uint32_t *list = lds_lists + grp * n_ids;
     uint32_t recounted = 0, loads = 0;
-    // items [item_base, item_base + n_items) of the batch
-    const uint32_t item_end = P.item_base + n_items;
-    for (uint32_t base = P.item_base + blockIdx.x * kPerWave; base < item_end; base += gridDim.x * kPerWave) {
-        const uint32_t item = base + grp;
-        uint32_t n_live = item < item_end ? Q.live_n[item] : 0u;
+    // items [item_base, item_base + n_items) of the batch, or -- from_queue -- the ones bmf_finish_kernel left over
+    const uint32_t first = from_queue ? 0u : P.item_base, item_end = from_queue ? Q.counters[3] : P.item_base + n_items;
+    for (uint32_t base = first + blockIdx.x * kPerWave; base < item_end; base += gridDim.x * kPerWave) {
+        const uint32_t at = base + grp;
+        const uint32_t item = from_queue ? (at < item_end ? Q.left_items[at] : 0u) : at;
+        uint32_t n_live = at < item_end ? Q.live_n[item] : 0u;
         if (n_live >= kSlowBound) n_live = 0;
         const bool have = n_live != 0;
         if (__ballot(have) == 0) continue;       // all results are final already
