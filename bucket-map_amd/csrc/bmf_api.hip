@@ -1312,9 +1312,11 @@ static int tune_pruned(bmf_ctx *c, bmf_batch *b) {
                 for (uint32_t r = 3; r <= d.G && r <= 5; r++) add(2, 4, r, live, sorted != 0);
         }
     }
-    hipEvent_t e0, e1;
-    HIP_TRY(hipEventCreate(&e0));
-    HIP_TRY(hipEventCreate(&e1));
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) {
+        if (e0) (void)hipEventDestroy(e0);
+        return fail(BMF_ERR_HIP, "tune_pruned: cannot create timing events");
+    }
     float best_ms = 1e30f;
     size_t best = 0;
     int rc = BMF_OK;
@@ -1349,7 +1351,12 @@ static int tune_pruned(bmf_ctx *c, bmf_batch *b) {
     if (log)
         fprintf(stderr, "[bmf] tune: chose kind %d fold %u rows %u lanes %u sorted %d\n", cands[best].kind, cands[best].fold,
                 cands[best].rows, cands[best].max_live, (int)cands[best].sort);
-    return apply_choice(c, cands[best]);
+    rc = apply_choice(c, cands[best]);
+    if (rc == BMF_OK && !c->pass1_fold && c->d_fold) {             // no folded pass in the end: its copy of the index goes
+        (void)hipFree(c->d_fold);
+        c->d_fold = nullptr;
+    }
+    return rc;
 }
 
 // The filter's kernels for the n_windows windows of `b`, reads at d_bases / d_quals, on the context's stream.
