@@ -381,7 +381,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="egu", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default="egu", choices=sorted(WORKLOADS) + [w + "-skewed" for w in sorted(WORKLOADS)],
+                    help="<name>-skewed: the same geometry on the genome-like genome as the headline (= --genome-profile genome)")
     ap.add_argument("--reads", type=int, default=0, help="reads per GPU (default: the workload's)")
     ap.add_argument("--total-bp", type=int, default=0, help="override the workload's genome size (other NB geometries)")
     ap.add_argument("--bucket-len", type=int, default=0, help="override the workload's bucket length (other NB geometries)")
@@ -414,6 +415,8 @@ def main():
                     help="do not spawn the rocprofv3 --pmc FETCH_SIZE child that measures roofline.traffic live")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.workload.endswith("-skewed"):        # `--workload egu-skewed` = `--workload egu --genome-profile genome`
+        args.workload, args.genome_profile = args.workload[: -len("-skewed")], "genome"
     if args.pmc_child:
         return pmc_child(args)
 
