@@ -18,6 +18,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
 #include <string>
 #include <vector>
 
@@ -1297,60 +1298,67 @@ static int tune_pruned(bmf_ctx *c, bmf_batch *b) {
         ch.kind = kind; ch.fold = fold; ch.rows = rows; ch.max_live = live; ch.sort = sort;
         cands.push_back(ch);
     };
-    // Unsorted forms first: the order kernel re-orders the lists in place (any order is valid for every kernel).
+    // Unsorted forms first (the order kernel re-orders the lists in place; any order is valid for every kernel): the plain
+    // kernel, the single-pass kernel and the MODEL's two-pass choice -- on rows of one density the model is right and
+    // the sort is pure overhead.  Then, rows sparsest first, the forms that have won somewhere: one or two rows of the
+    // index itself, two or three of its 2-fold copy, three or four of its 4-fold copy on large indexes; 16 or 32 lanes.
+    add(0, 1, 0, 32, false);
+    add(1, 1, 0, 32, false);
+    if (c->dp.pass1_rows)
+        add(2, c->pass1_fold ? c->fold : 1u, c->pass1_fold ? c->dpf.pass1_rows : c->dp.pass1_rows, c->dp.max_live, false);
     const uint32_t chunks2 = ((((d.nb + 1u) / 2u + 7u) >> 3) + 15u) / 16u, chunks4 = ((((d.nb + 3u) / 4u + 7u) >> 3) + 15u) / 16u;
-    for (int sorted = 0; sorted < 2; sorted++) {
-        if (!sorted) {
-            add(0, 1, 0, 32, false);
-            add(1, 1, 0, 32, false);
-        }
-        for (uint32_t live : {16u, 32u}) {
-            for (uint32_t r = 1; r < d.G && r <= 3; r++) add(2, 1, r, live, sorted != 0);
-            if (chunks2 <= 256u)
-                for (uint32_t r = 2; r <= d.G && r <= 4; r++) add(2, 2, r, live, sorted != 0);
-            if (chunks4 <= 128u)
-                for (uint32_t r = 3; r <= d.G && r <= 5; r++) add(2, 4, r, live, sorted != 0);
-        }
-    }
+    for (uint32_t r = 1; r < d.G && r <= 2; r++)
+        for (uint32_t live : {16u, 32u}) add(2, 1, r, live, true);
+    if (chunks2 <= 256u)
+        for (uint32_t r = 2; r <= d.G && r <= 3; r++)
+            for (uint32_t live : {16u, 32u}) add(2, 2, r, live, true);
+    if (chunks4 <= 128u && d.n_chunks >= 256u)
+        for (uint32_t r = 3; r <= d.G && r <= 4; r++)
+            for (uint32_t live : {16u, 32u}) add(2, 4, r, live, true);
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) {
         if (e0) (void)hipEventDestroy(e0);
         return fail(BMF_ERR_HIP, "tune_pruned: cannot create timing events");
     }
-    float best_ms = 1e30f;
-    size_t best = 0;
+    const auto wall0 = std::chrono::steady_clock::now();
+    // the queue buffers at their largest, so that no timed run reallocates
     int rc = BMF_OK;
-    for (size_t i = 0; i < cands.size() && rc == BMF_OK; i++) {
+    if (b->q_live_mask.need(2 * (size_t)b->n_windows * bmf::kMaxLive) != hipSuccess) rc = fail(BMF_ERR_HIP, "tune_pruned: out of device memory");
+    std::vector<float> ms(cands.size(), 1e30f);
+    auto time_one = [&](size_t i) {
         rc = apply_choice(c, cands[i]);
-        if (rc != BMF_OK) break;
-        if (cands[i].kind == 2 && (!c->dp.pass1_rows || (cands[i].fold > 1 && !c->pass1_fold))) continue;   // no such kernel
+        if (rc != BMF_OK) return;
+        if (cands[i].kind == 2 && (!c->dp.pass1_rows || (cands[i].fold > 1 && !c->pass1_fold))) return;   // no such kernel
         c->guard_pending = true;                                   // (no guard samples from the tuning runs)
-        float ms = 1e30f;
-        for (int rep = 0; rep < 2 && rc == BMF_OK; rep++) {        // the first run of a form also sizes its buffers
-            if (rep == 1 && ms > 1.5f * best_ms) break;            // far behind already: no second look
-            (void)hipEventRecord(e0, c->stream);
-            rc = launch_vote_stage(c, b, n_win);
-            (void)hipEventRecord(e1, c->stream);
-            if (hipEventSynchronize(e1) != hipSuccess || hipGetLastError() != hipSuccess) rc = fail(BMF_ERR_HIP, "tuning run failed");
-            float t = 0.f;
-            (void)hipEventElapsedTime(&t, e0, e1);
-            ms = std::min(ms, t);
-        }
+        (void)hipEventRecord(e0, c->stream);
+        rc = launch_vote_stage(c, b, n_win);
+        (void)hipEventRecord(e1, c->stream);
+        if (hipEventSynchronize(e1) != hipSuccess || hipGetLastError() != hipSuccess) rc = fail(BMF_ERR_HIP, "tuning run failed");
         c->guard_pending = false;
-        if (log)
-            fprintf(stderr, "[bmf] tune: kind %d fold %u rows %u lanes %u sorted %d: %.3f ms per %u windows\n", cands[i].kind,
-                    cands[i].fold, cands[i].rows, cands[i].max_live, (int)cands[i].sort, ms, n_win);
-        if (ms < best_ms) {
-            best_ms = ms;
-            best = i;
-        }
-    }
+        float t = 0.f;
+        (void)hipEventElapsedTime(&t, e0, e1);
+        ms[i] = std::min(ms[i], t);
+    };
+    for (size_t i = 0; i < cands.size() && rc == BMF_OK; i++) time_one(i);      // every form once ...
+    std::vector<size_t> order(cands.size());
+    for (size_t i = 0; i < order.size(); i++) order[i] = i;
+    std::sort(order.begin(), order.end(), [&](size_t x, size_t y) { return ms[x] < ms[y]; });
+    for (size_t k = 0; k < std::min<size_t>(3, order.size()) && rc == BMF_OK; k++)   // ... the three fastest twice more
+        for (int rep = 0; rep < 2 && rc == BMF_OK; rep++) time_one(order[k]);
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     if (rc != BMF_OK) return rc;
-    if (log)
-        fprintf(stderr, "[bmf] tune: chose kind %d fold %u rows %u lanes %u sorted %d\n", cands[best].kind, cands[best].fold,
-                cands[best].rows, cands[best].max_live, (int)cands[best].sort);
+    size_t best = 0;
+    for (size_t i = 1; i < cands.size(); i++)
+        if (ms[i] < ms[best]) best = i;
+    if (log) {
+        for (size_t i = 0; i < cands.size(); i++)
+            fprintf(stderr, "[bmf] tune: kind %d fold %u rows %u lanes %u sorted %d: %.3f ms per %u windows\n", cands[i].kind,
+                    cands[i].fold, cands[i].rows, cands[i].max_live, (int)cands[i].sort, ms[i], n_win);
+        fprintf(stderr, "[bmf] tune: chose kind %d fold %u rows %u lanes %u sorted %d (%.1f ms spent measuring)\n", cands[best].kind,
+                cands[best].fold, cands[best].rows, cands[best].max_live, (int)cands[best].sort,
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count());
+    }
     rc = apply_choice(c, cands[best]);
     if (rc == BMF_OK && !c->pass1_fold && c->d_fold) {             // no folded pass in the end: its copy of the index goes
         (void)hipFree(c->d_fold);
