@@ -1,7 +1,7 @@
 // bmv_api.hip -- C ABI (include/bmv.h) over the alignment-verification kernels in bmv_kernels.hip.h.
 // Host side only: validation, choice of the kernel shape for the longest query of the batch, chunking so
 // that the traceback bits of one chunk fit the scratch budget, offsets of the packed CIGAR output
-// (hipCUB exclusive sum, a library primitive).
+// (bm_scan.hip.h's exclusive sum).
 #include "bmv_kernels.hip.h"
 
 namespace bmv {
