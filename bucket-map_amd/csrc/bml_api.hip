@@ -299,85 +299,133 @@ int bml_locate(bml_ctx *c, const uint32_t *sample_hash, const uint16_t *sample_p
     HIP_TRY(hipMemcpyAsync(c->pair_rc.p, pair_rc, (size_t)n_pairs, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemcpyAsync(c->chunks.p, chunks.data(), chunks.size() * sizeof(bml::Chunk), hipMemcpyHostToDevice, c->stream));
 
-    // occurrence buffer: a true match per sample is the common case; grow and re-scan when it was too small
+    // Occurrence buffer.  A true match per sample is the common case, so the first scan runs with room for two per sample;
+    // it counts every candidate's occurrences whether they fit or not.  If they did not fit, the candidates are cut into
+    // GROUPS of whole chunks whose occurrences fit a budget (BML_MAX_OCC occurrences, default 2^31 = 16 GiB of keys: reads
+    // in repeats bring 1 000+ occurrences per candidate, 11 G for 10 M reads on the genome-like genome), and every group is
+    // scanned again and replayed on its own.
     HIP_TRY(c->cand_count.need(n_pairs));
     HIP_TRY(c->cand_start.need(n_pairs));
-    unsigned long long cap = std::max<unsigned long long>(1ull << 20, 2ull * n_pairs * p);
-    unsigned long long n_occ = 0;
-    for (int attempt = 0; attempt < 3; attempt++) {
+    HIP_TRY(c->heavy.need(n_pairs));
+    unsigned long long budget = 1ull << 31;
+    if (const char *env = getenv("BML_MAX_OCC")) budget = std::max<unsigned long long>(1024, strtoull(env, nullptr, 10));
+    uint32_t max_seg = 0;
+    for (uint32_t w = 0; w < n_windows; w++) max_seg = std::max(max_seg, seg_len[w]);
+    c->ms[0] = c->ms[1] = c->ms[2] = 0.f;
+    c->last_occ = 0;
+    c->last_heavy = 0;
+
+    auto scan = [&](size_t chunk_lo, size_t chunk_hi, unsigned long long cap, unsigned long long *n_occ) -> int {
         HIP_TRY(c->occ_a.need((size_t)cap));
         HIP_TRY(hipMemsetAsync(c->occ_count.p, 0, sizeof(unsigned long long), c->stream));
         HIP_TRY(hipEventRecord(c->ev[0], c->stream));
-        hipLaunchKernelGGL(bml::bml_scan_kernel, dim3((unsigned)chunks.size()), dim3(bml::kScanThreads), c->scan_lds, c->stream,
-                           c->lp, c->genome.p, c->bucket_start.p, c->bucket_len.p, c->lut.p, c->chunks.p, c->sample_hash.p,
+        hipLaunchKernelGGL(bml::bml_scan_kernel, dim3((unsigned)(chunk_hi - chunk_lo)), dim3(bml::kScanThreads), c->scan_lds, c->stream,
+                           c->lp, c->genome.p, c->bucket_start.p, c->bucket_len.p, c->lut.p, c->chunks.p + chunk_lo, c->sample_hash.p,
                            c->pair_window.p, c->pair_rc.p, c->occ_a.p, c->occ_count.p, cap, c->cand_start.p, c->cand_count.p);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(c->ev[1], c->stream));
-        HIP_TRY(hipMemcpyAsync(&n_occ, c->occ_count.p, sizeof n_occ, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemcpyAsync(n_occ, c->occ_count.p, sizeof *n_occ, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
-        if (n_occ <= cap) break;
-        cap = n_occ;
-        if (attempt == 2) return fail(BML_ERR_HIP, "occurrence buffer still too small after re-scan");
-    }
-    c->last_occ = n_occ;
-    HIP_TRY(c->heavy.need(n_pairs));
-    HIP_TRY(hipMemsetAsync(c->n_heavy.p, 0, 3 * sizeof(uint32_t), c->stream));   // count, largest, queue head
-    HIP_TRY(hipEventRecord(c->ev[2], c->stream));
-    {
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
+        c->ms[0] += ms;
+        return BML_OK;
+    };
+    // the vote of the candidates [pair_lo, pair_hi), whose occurrences (n_occ of them) are in occ_a
+    auto replay = [&](uint32_t pair_lo, uint32_t pair_hi, unsigned long long n_occ) -> int {
+        HIP_TRY(hipMemsetAsync(c->n_heavy.p, 0, 3 * sizeof(uint32_t), c->stream));   // count, largest, queue head
+        HIP_TRY(hipEventRecord(c->ev[2], c->stream));
+        const uint32_t count = pair_hi - pair_lo;
         auto light = [&](auto kernel, unsigned threads) {
-            hipLaunchKernelGGL(kernel, dim3((n_pairs + threads - 1) / threads), dim3(threads), 0, c->stream, c->lp, c->occ_a.p,
+            hipLaunchKernelGGL(kernel, dim3((count + threads - 1) / threads), dim3(threads), 0, c->stream, c->lp, c->occ_a.p,
                                c->cand_start.p, c->cand_count.p, c->sample_pos.p, c->seg_len.p, c->pair_window.p, c->pair_rc.p,
-                               n_pairs, c->out_offset.p, c->out_votes.p, c->heavy.p, c->n_heavy.p);
+                               pair_lo, pair_hi, c->out_offset.p, c->out_votes.p, c->heavy.p, c->n_heavy.p);
         };
         if (p <= 10) light(bml::bml_replay_light_kernel<16, 256>, 256);
         else if (p <= 24) light(bml::bml_replay_light_kernel<32, 256>, 256);
         else light(bml::bml_replay_light_kernel<64, 128>, 128);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(c->ev[4], c->stream));
+        // candidates with more occurrences than the light kernel takes (repeats): one workgroup each, dense bitmaps of the
+        // start positions
+        uint32_t heavy_info[2] = {0, 0};                      // their number, and the most occurrences one of them has
+        HIP_TRY(hipMemcpyAsync(heavy_info, c->n_heavy.p, sizeof heavy_info, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        const uint32_t n_heavy = heavy_info[0];
+        if (getenv("BML_LOG"))
+            fprintf(stderr, "[bml] candidates %u..%u, %llu occurrences; %u heavy candidates, the largest with %u occurrences\n", pair_lo,
+                    pair_hi, (unsigned long long)n_occ, n_heavy, heavy_info[1]);
+        c->last_heavy += n_heavy;
+        if (n_heavy) {
+            const uint32_t range = c->p.max_bucket_bases + max_seg, words = (range + 31u) / 32u;
+            const size_t lds_occ = (size_t)bml::kHeavyLdsOcc * sizeof(uint32_t);
+            const bool in_lds = lds_occ + (size_t)3 * words * sizeof(uint32_t) <= 150 * 1024;
+            const size_t lds = lds_occ + (in_lds ? (size_t)3 * words * sizeof(uint32_t) : 0);
+            if (lds > 48 * 1024)
+                HIP_TRY(bmhip::raise_dynamic_lds(reinterpret_cast<const void *>(bml::bml_replay_heavy_kernel), lds));
+            // as many workgroups as the CUs hold at once (LDS decides: 1 per CU at 262 144-base buckets, 3 at 65 536)
+            const uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(8, (size_t)(156 * 1024) / (lds + 1024)));
+            const unsigned grid = (unsigned)std::min<uint32_t>(n_heavy, per_cu * (uint32_t)c->n_cu);
+            HIP_TRY(c->heavy_votes.need((size_t)grid * range));
+            if (!in_lds) HIP_TRY(c->heavy_bitmaps.need((size_t)grid * 3 * words));
+            // candidates whose occurrences do not fit the kernel's LDS copy group them by sample in a second buffer
+            if (heavy_info[1] > bml::kHeavyLdsOcc) HIP_TRY(c->occ_b.need((size_t)n_occ));
+            const bml::HeavyScratch hs{c->heavy_votes.p, c->heavy_bitmaps.p, heavy_info[1] > bml::kHeavyLdsOcc ? c->occ_b.p : nullptr};
+            HIP_TRY(hipEventRecord(c->ev[5], c->stream));        // (the allocations above are not replay time)
+            hipLaunchKernelGGL(bml::bml_replay_heavy_kernel, dim3(grid), dim3(bml::kThreads), lds, c->stream, c->lp, c->occ_a.p,
+                               c->cand_start.p, c->cand_count.p, c->sample_pos.p, c->seg_len.p, c->pair_window.p, c->pair_rc.p, c->heavy.p,
+                               c->n_heavy.p, range, max_seg, in_lds ? 1u : 0u, hs, c->out_offset.p, c->out_votes.p);
+            HIP_TRY(hipGetLastError());
+        }
+        HIP_TRY(hipEventRecord(c->ev[3], c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, c->ev[2], c->ev[4]));            // light replay ...
+        c->ms[2] += ms;
+        if (n_heavy) {                                                    // ... + heavy replay, without the host gap between them
+            HIP_TRY(hipEventElapsedTime(&ms, c->ev[5], c->ev[3]));
+            c->ms[2] += ms;
+        }
+        return BML_OK;
+    };
+
+    unsigned long long cap = std::min<unsigned long long>(std::max<unsigned long long>(1ull << 20, 2ull * n_pairs * p), budget);
+    unsigned long long n_occ = 0;
+    if (int rc = scan(0, chunks.size(), cap, &n_occ)) return rc;
+    c->last_occ = n_occ;
+    if (n_occ > cap && n_occ <= budget) {                       // too small, but one buffer will do: grow it and scan again
+        cap = n_occ;
+        if (int rc = scan(0, chunks.size(), cap, &n_occ)) return rc;
+        if (n_occ > cap) return fail(BML_ERR_HIP, "occurrence buffer still too small after re-scan");
     }
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(c->ev[4], c->stream));
-    // candidates with more occurrences than the light kernel takes (repeats): one workgroup each, dense bitmaps of the start positions
-    uint32_t heavy_info[2] = {0, 0};                          // their number, and the most occurrences one of them has
-    HIP_TRY(hipMemcpyAsync(heavy_info, c->n_heavy.p, sizeof heavy_info, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    const uint32_t n_heavy = heavy_info[0];
-    if (getenv("BML_LOG"))
-        fprintf(stderr, "[bml] %u candidates, %llu occurrences; %u heavy candidates, the largest with %u occurrences\n", n_pairs,
-                (unsigned long long)n_occ, n_heavy, heavy_info[1]);
-    c->last_heavy = n_heavy;
-    if (n_heavy) {
-        uint32_t max_seg = 0;
-        for (uint32_t w = 0; w < n_windows; w++) max_seg = std::max(max_seg, seg_len[w]);
-        const uint32_t range = c->p.max_bucket_bases + max_seg, words = (range + 31u) / 32u;
-        const size_t lds_occ = (size_t)bml::kHeavyLdsOcc * sizeof(uint32_t);
-        const bool in_lds = lds_occ + (size_t)3 * words * sizeof(uint32_t) <= 150 * 1024;
-        const size_t lds = lds_occ + (in_lds ? (size_t)3 * words * sizeof(uint32_t) : 0);
-        if (lds > 48 * 1024)
-            HIP_TRY(bmhip::raise_dynamic_lds(reinterpret_cast<const void *>(bml::bml_replay_heavy_kernel), lds));
-        // as many workgroups as the CUs hold at once (LDS decides: 1 per CU at 262 144-base buckets, 3 at 65 536)
-        const uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(8, (size_t)(156 * 1024) / (lds + 1024)));
-        const unsigned grid = (unsigned)std::min<uint32_t>(n_heavy, per_cu * (uint32_t)c->n_cu);
-        HIP_TRY(c->heavy_votes.need((size_t)grid * range));
-        if (!in_lds) HIP_TRY(c->heavy_bitmaps.need((size_t)grid * 3 * words));
-        // candidates whose occurrences do not fit the kernel's LDS copy group them by sample in a second buffer
-        if (heavy_info[1] > bml::kHeavyLdsOcc) HIP_TRY(c->occ_b.need((size_t)n_occ));
-        const bml::HeavyScratch hs{c->heavy_votes.p, c->heavy_bitmaps.p, heavy_info[1] > bml::kHeavyLdsOcc ? c->occ_b.p : nullptr};
-        HIP_TRY(hipEventRecord(c->ev[5], c->stream));            // (the allocations above are not replay time)
-        hipLaunchKernelGGL(bml::bml_replay_heavy_kernel, dim3(grid), dim3(bml::kThreads), lds, c->stream, c->lp,
-                           c->occ_a.p, c->cand_start.p, c->cand_count.p, c->sample_pos.p, c->seg_len.p, c->pair_window.p, c->pair_rc.p, c->heavy.p,
-                           c->n_heavy.p, range, max_seg, in_lds ? 1u : 0u, hs, c->out_offset.p, c->out_votes.p);
+    if (n_occ <= cap) {
+        if (int rc = replay(0, n_pairs, n_occ)) return rc;
+    } else {
+        // groups of whole chunks within the budget (a single chunk beyond it is a group of its own)
+        std::vector<uint32_t> counts(n_pairs);
+        HIP_TRY(hipMemcpy(counts.data(), c->cand_count.p, (size_t)n_pairs * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        size_t lo = 0;
+        while (lo < chunks.size()) {
+            unsigned long long sum = 0;
+            size_t hi = lo;
+            while (hi < chunks.size()) {
+                unsigned long long cs = 0;
+                for (uint32_t i = 0; i < chunks[hi].pair_count; i++) cs += counts[chunks[hi].pair_begin + i];
+                if (hi > lo && sum + cs > budget) break;
+                sum += cs;
+                hi++;
+            }
+            unsigned long long got = 0;
+            if (int rc = scan(lo, hi, std::max<unsigned long long>(sum, 1), &got)) return rc;
+            if (got != sum) return fail(BML_ERR_HIP, "a group's occurrence count changed between scans (%llu, then %llu)", sum, got);
+            const uint32_t pair_lo = chunks[lo].pair_begin, pair_hi = chunks[hi - 1].pair_begin + chunks[hi - 1].pair_count;
+            if (int rc = replay(pair_lo, pair_hi, got)) return rc;
+            lo = hi;
+        }
     }
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(c->ev[3], c->stream));
     HIP_TRY(hipMemcpyAsync(out_offset, c->out_offset.p, (size_t)n_pairs * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipMemcpyAsync(out_votes, c->out_votes.p, (size_t)n_pairs * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    for (int i = 0; i < 2; i++) HIP_TRY(hipEventElapsedTime(&c->ms[i], c->ev[i], c->ev[i + 1]));
-    HIP_TRY(hipEventElapsedTime(&c->ms[2], c->ev[2], c->ev[4]));          // light replay ...
-    if (n_heavy) {                                                        // ... + heavy replay, without the host gap between them
-        float heavy_ms = 0.f;
-        HIP_TRY(hipEventElapsedTime(&heavy_ms, c->ev[5], c->ev[3]));
-        c->ms[2] += heavy_ms;
-    }
     return BML_OK;
 }
 

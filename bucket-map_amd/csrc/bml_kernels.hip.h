@@ -215,13 +215,13 @@ template <int kLightMax, int kLightThreads>
 __global__ __launch_bounds__(kLightThreads) void bml_replay_light_kernel(
     LocParams P, const uint64_t *__restrict__ keys, const uint64_t *__restrict__ cand_start, const uint32_t *__restrict__ cand_count,
     const uint16_t *__restrict__ sample_pos, const uint32_t *__restrict__ seg_len, const uint32_t *__restrict__ pair_window,
-    const uint8_t *__restrict__ pair_rc, uint32_t n_pairs, int32_t *__restrict__ out_offset, uint32_t *__restrict__ out_votes,
-    uint32_t *__restrict__ heavy, uint32_t *__restrict__ n_heavy) {
+    const uint8_t *__restrict__ pair_rc, uint32_t pair_lo, uint32_t pair_hi, int32_t *__restrict__ out_offset,
+    uint32_t *__restrict__ out_votes, uint32_t *__restrict__ heavy, uint32_t *__restrict__ n_heavy) {
     __shared__ uint32_t s_key[kLightMax][kLightThreads];
     __shared__ int32_t s_pk[kLightMax][kLightThreads];
     __shared__ uint8_t s_pv[kLightMax][kLightThreads];
-    const uint32_t tid = threadIdx.x, pair = blockIdx.x * kLightThreads + tid;
-    if (pair >= n_pairs) return;
+    const uint32_t tid = threadIdx.x, pair = pair_lo + blockIdx.x * kLightThreads + tid;   // candidates [pair_lo, pair_hi)
+    if (pair >= pair_hi) return;
     const uint32_t n = cand_count[pair];
     if (n > kLightMax) {
         heavy[atomicAdd(n_heavy, 1u)] = pair;

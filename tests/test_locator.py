@@ -162,6 +162,22 @@ def test_gpu_scan_equals_oracle(name, kw):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("budget", [500, 20_000, 400_000])
+def test_gpu_scan_in_groups_within_an_occurrence_budget(budget, monkeypatch):
+    """When the occurrences of a call do not fit the budget (BML_MAX_OCC; 2^31 by default -- 10 M reads on the genome-like
+    genome bring 11 G), the candidates are cut into groups of whole chunks that are scanned and replayed one after the other:
+    same offsets and votes, whatever the budget -- even one smaller than a single chunk's occurrences."""
+    rng = np.random.default_rng(4242)
+    case = make_case(rng, n_buckets=6, bucket_len=8192, read_len=150, n_reads=400, motif=97)
+    o_ref, v_ref = oracle(case)
+    monkeypatch.setenv("BML_MAX_OCC", str(budget))
+    o_got, v_got, st = gpu_scan(case)
+    assert np.array_equal(o_ref, o_got) and np.array_equal(v_ref, v_got)
+    assert st["occurrences"] > 4 * budget or budget > 100_000    # the small budgets really force groups
+    assert st["heavy_candidates"] > 0
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("bucket_len,read_len,indel", [(262144, 300, 30), (300000, 40000, 700)])
 def test_gpu_scan_heavy_candidates_at_long_read_geometry(bucket_len, read_len, indel):
     """BASELINE configs[4]'s bucket length with satellite-like content: a 171-base monomer fills the bucket, every sampled
