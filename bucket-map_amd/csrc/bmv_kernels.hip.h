@@ -401,6 +401,37 @@ __global__ __launch_bounds__(kWave) void bmv_align_kernel(Job J) {
                 i--;
             } else {
                 const uint32_t x = (j + lc - 1u) % kBlock, held = x / kHold;
+                // A read mostly runs down the diagonal: how far from this cell?  Every lane looks at the columns it holds,
+                // at the rows the diagonal through (i, j) meets them (same word only: the bit index must stay >= 0); one
+                // ballot per slot gathers the answers into a mask over the block's columns, and the run is the stretch of
+                // set bits from column x downwards.  The whole run is then ONE step of the walk instead of up to sixteen.
+                {
+                    uint32_t colmask = 0;
+#pragma unroll
+                    for (int q = 0; q < kSlots; q++) {
+                        const uint32_t xq = (uint32_t)q * kHold + gl;
+                        const int32_t bit = (int32_t)((i - 1u) & 63u) - (int32_t)(x - xq);
+                        // (columns before the text's first hold stale words: the refill only writes columns 1 .. n)
+                        const bool ok = gl < kHold && xq <= x && x - xq < j && bit >= 0 && ((db[q] >> (bit & 63)) & 1ull) != 0;
+                        const uint64_t b = __ballot(ok);
+                        colmask |= (uint32_t)((b >> lane0) & ((1ull << kHold) - 1ull)) << ((uint32_t)q * kHold);
+                    }
+                    const uint32_t upto = (2u << x) - 1u, gaps = ~colmask & upto;
+                    const uint32_t run = gaps ? x - (31u - (uint32_t)__builtin_clz(gaps)) : x + 1u;
+                    if (run) {
+                        i -= run;
+                        j -= run;
+                        if (cur_op == 0) {
+                            cur_len += run;
+                        } else {
+                            if (cur_len && gl == 0) ops[n_rev] = (cur_len << 4) | cur_op;
+                            n_rev += cur_len ? 1u : 0u;
+                            cur_op = 0;
+                            cur_len = run;
+                        }
+                        continue;
+                    }
+                }
                 uint64_t md = db[0], mu = ub[0];
 #pragma unroll
                 for (int q = 1; q < kSlots; q++) {
