@@ -101,6 +101,7 @@ struct Shape {
     uint32_t group;   // lanes per alignment
     int cw;           // 64-row words per lane
     align_fn fn;
+    bool per_lane;    // bmv_align_lane_kernel: one alignment per lane (group 1), its own trace and text layout
 };
 
 // A group is as many lanes as the longest query has words, over CW words per lane; the kernel variant fixes CW and how many
@@ -116,10 +117,24 @@ constexpr int kMaxCw = 8;
 constexpr double kStepCost[kMaxCw + 1] = {0, 0.206, 0.290, 0.356, 0.440, 0.545, 0.645, 0.700, 0.810};
 constexpr uint32_t kStripsBeyond = 64u * kMaxCw;                 // words: longer queries go through in strips
 
+// Queries of up to this many words go one per lane (bmv_align_lane_kernel): 64 alignments share every instruction of a
+// column step.  BMV_LANE_MAX=0 switches it off (experiments; tests run both ways).
+constexpr uint32_t kLaneWords = 8;
+
 Shape pick_shape(uint32_t words, uint32_t max_n) {
+    {
+        static const align_fn per_lane[kLaneWords + 1] = {nullptr,
+                                                          bmv::bmv_align_lane_kernel<1>, bmv::bmv_align_lane_kernel<2>,
+                                                          bmv::bmv_align_lane_kernel<3>, bmv::bmv_align_lane_kernel<4>,
+                                                          bmv::bmv_align_lane_kernel<5>, bmv::bmv_align_lane_kernel<6>,
+                                                          bmv::bmv_align_lane_kernel<7>, bmv::bmv_align_lane_kernel<8>};
+        const char *env = getenv("BMV_LANE_MAX");
+        const uint32_t lane_max = env ? std::min<uint32_t>((uint32_t)atoi(env), kLaneWords) : kLaneWords;
+        if (words <= lane_max) return Shape{1u, (int)words, per_lane[words], true};
+    }
     // strips of 64 * CW words, one after the other (max_query_len = 65 536 bases: two of them)
     if (words > kStripsBeyond)
-        return words <= 2u * 64u * 6u ? Shape{64u, 6, bmv::bmv_align_kernel<1, 6, true>} : Shape{64u, 8, bmv::bmv_align_kernel<1, 8, true>};
+        return words <= 2u * 64u * 6u ? Shape{64u, 6, bmv::bmv_align_kernel<1, 6, true>, false} : Shape{64u, 8, bmv::bmv_align_kernel<1, 8, true>, false};
     static const align_fn one_pass[kMaxCw + 1] = {nullptr,
                                                   bmv::bmv_align_kernel<1, 1, false>, bmv::bmv_align_kernel<1, 2, false>,
                                                   bmv::bmv_align_kernel<1, 3, false>, bmv::bmv_align_kernel<1, 4, false>,
@@ -151,14 +166,14 @@ Shape pick_shape(uint32_t words, uint32_t max_n) {
     static const align_fn four_pairs[5] = {nullptr, nullptr, bmv::bmv_align_kernel<4, 2, false>, bmv::bmv_align_kernel<4, 3, false>,
                                            bmv::bmv_align_kernel<4, 4, false>};
     static const align_fn eight_pairs[4] = {nullptr, nullptr, bmv::bmv_align_kernel<8, 2, false>, bmv::bmv_align_kernel<8, 3, false>};
-    if (cw > 1 && g < 4) return {g, cw, eight_pairs[cw]};
-    if (cw > 1 && g < 8) return {g, cw, four_pairs[cw]};
-    if (cw > 1 && g < 16) return {g, cw, two_pairs[cw]};
-    if (cw > 1 || g >= 16) return {g, cw, one_pass[cw]};
-    if (g >= 8) return {g, 1, bmv::bmv_align_kernel<2, 1, false>};
-    if (g >= 4) return {g, 1, bmv::bmv_align_kernel<4, 1, false>};
-    if (g >= 2) return {g, 1, bmv::bmv_align_kernel<8, 1, false>};
-    return {g, 1, bmv::bmv_align_kernel<16, 1, false>};
+    if (cw > 1 && g < 4) return {g, cw, eight_pairs[cw], false};
+    if (cw > 1 && g < 8) return {g, cw, four_pairs[cw], false};
+    if (cw > 1 && g < 16) return {g, cw, two_pairs[cw], false};
+    if (cw > 1 || g >= 16) return {g, cw, one_pass[cw], false};
+    if (g >= 8) return {g, 1, bmv::bmv_align_kernel<2, 1, false>, false};
+    if (g >= 4) return {g, 1, bmv::bmv_align_kernel<4, 1, false>, false};
+    if (g >= 2) return {g, 1, bmv::bmv_align_kernel<8, 1, false>, false};
+    return {g, 1, bmv::bmv_align_kernel<16, 1, false>, false};
 }
 
 }  // namespace
@@ -311,10 +326,10 @@ int bmv_align(bmv_ctx *c, const uint8_t *reads, uint64_t n_read_bytes, const uin
 
     // Length classes.  The kernel's shape -- lanes per alignment, words per lane -- is fixed per launch by the longest query
     // it holds, and a 5-kbp read run in the shape of a 30-kbp one costs six times what it should: the batch is cut into
-    // classes of similar query length (in 64-row words; everything up to 16 words -- 1 024 bases -- is one class, so a
-    // short-read batch stays one launch), each class is a launch series of its own over an index list, and the
+    // classes of similar query length (in 64-row words; everything up to 8 words -- 512 bases, one alignment per lane -- is
+    // one class, so a short-read batch stays one launch; then up to 16 words), each class is a launch series of its own over an index list, and the
     // results find their way back through that list.
-    static const uint32_t kClassUpTo[] = {16, 20, 24, 32, 40, 48, 64, 80, 96, 128, 160, 192, 256, 320, 384, 512, 640, 768, 1024};
+    static const uint32_t kClassUpTo[] = {kLaneWords, 16, 20, 24, 32, 40, 48, 64, 80, 96, 128, 160, 192, 256, 320, 384, 512, 640, 768, 1024};
     constexpr uint32_t kClasses = sizeof kClassUpTo / sizeof kClassUpTo[0];
     const bool classes_off = getenv("BMV_ONE_CLASS") != nullptr;    // experiment knob: the whole batch in the longest query's shape
     auto class_of = [&](uint32_t m) {
@@ -392,8 +407,10 @@ int bmv_align(bmv_ctx *c, const uint8_t *reads, uint64_t n_read_bytes, const uin
         pl.n_blocks = (max_n + pl.sh.group + 15u) / 16u + 1u;     // blocks of 16 STEPS: the group's last lane is group - 1 steps behind
         const uint64_t n_entries = (uint64_t)pl.n_blocks * pl.gpw * pl.trace_words;
         pl.trace_stride = n_entries * 2u + (n_entries + 1u) / 2u;               // 64-bit words per wave
+        if (pl.sh.per_lane) pl.trace_stride += 4u * pl.trace_words * 64u;       // ... and the match masks, for the traceback
         pl.ops_stride = max_m + max_n + 1u;
         pl.lds_stride = (max_n + 15u) / 16u * 4u + 4u;                          // the text as a 2-bit stream
+        if (pl.sh.per_lane) pl.lds_stride = (max_n + 63u) / 64u * 16u + 8u;     // ... as two bit planes, 64 columns at a time
         pl.lds = 256 + (size_t)pl.gpw * pl.lds_stride;
         if (pl.lds > 160 * 1024) return fail(BMV_ERR_UNSUPPORTED, "text windows of %u bases need %zu B of LDS", max_n, pl.lds);
         if (pl.lds > 48 * 1024) HIP_TRY(bmhip::raise_dynamic_lds(reinterpret_cast<const void *>(pl.sh.fn), pl.lds));

@@ -473,4 +473,271 @@ __global__ __launch_bounds__(kWave) void bmv_align_kernel(Job J) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// One alignment per LANE: queries of up to 64 * CW bases (short reads).  Sixty-four alignments share every instruction of
+// the column step, against 64 / GROUP above (32 for a 300-bp read as 2 lanes x 3 words, and those 6 words for 5): nothing is
+// skewed, no delta crosses lanes, the text's column is the same for the whole wave.  What the lanes do together is the
+// LOADING: alignment g's query and text are read 64 bases at a time by the whole wave (one cache line per instruction
+// instead of 64), and a ballot per base rank turns 64 bases into the match masks of one query word (left in lane g's
+// registers) or into the two bit planes of 64 text columns (left in LDS, 32 columns per 32-bit word, low plane then high).
+// Checkpoints as above, laid out [block][word][lane]; behind them the match masks, [rank][word][lane].  The traceback is each lane's own: the 16 columns of the current
+// (word, block) are kept ROTATED -- column x's trace words turned right by x bits -- so that the cells of one diagonal sit
+// at the same bit of all 16: a diagonal run is read off with one bit extraction per column, whatever lane asks for whatever
+// diagonal, and no register is indexed by a value the compiler cannot see.
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t readlane64(uint64_t v, uint32_t src) {
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, (int)src);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), (int)src);
+    return ((uint64_t)hi << 32) | lo;
+}
+
+__device__ __forceinline__ uint64_t rotr64(uint64_t v, uint32_t by) { return by ? (v >> by) | (v << (64u - by)) : v; }
+
+// bit `at` (0..63, any lane its own) of each of 16 words, gathered into bits 0..15
+__device__ __forceinline__ uint32_t gather_bit(const uint64_t (&words)[kBlock], uint32_t at) {
+    const bool upper = at >= 32u;
+    const uint32_t sh = at & 31u;
+    uint32_t out = 0;
+#pragma unroll
+    for (int q = 0; q < (int)kBlock; q++) {
+        const uint32_t half = upper ? (uint32_t)(words[q] >> 32) : (uint32_t)words[q];
+        out |= ((half >> sh) & 1u) << q;
+    }
+    return out;
+}
+
+template <int CW>
+__global__ __launch_bounds__(kWave) void bmv_align_lane_kernel(Job J) {
+    extern __shared__ uint8_t lds_text[];
+    const uint32_t lane = threadIdx.x, slot = blockIdx.x * kWave + lane;
+    const bool have = slot < J.count;
+    const uint32_t a = J.order[have ? slot : 0u];
+    const uint32_t n = have ? J.text_len[a] : 0u, m = have ? J.query_len[a] : 0u;
+    const uint32_t W = (m + 63u) >> 6;                          // <= CW (the host's promise)
+    uint8_t *lut = lds_text;
+    reinterpret_cast<uint32_t *>(lut)[lane] = reinterpret_cast<const uint32_t *>(J.lut)[lane];
+    __syncthreads();
+    // the text of alignment g: pairs (low plane, high plane) of 32 columns each
+    auto text_of = [&](uint32_t g) { return reinterpret_cast<uint32_t *>(lds_text + 256 + (size_t)g * J.text_lds_stride); };
+
+    uint64_t peq[4][CW];
+#pragma unroll
+    for (int c = 0; c < CW; c++) peq[0][c] = peq[1][c] = peq[2][c] = peq[3][c] = 0;
+    {
+        const uint64_t q_at = have ? J.query_start[a] : 0u, t_at = have ? J.text_start[a] : 0u;
+        const uint32_t rc = have ? J.text_rc[a] : 0u;
+        for (uint32_t g = 0; g < kWave; g++) {                  // (everything indexed by g is the same in every lane)
+            const uint32_t mg = (uint32_t)__builtin_amdgcn_readlane((int)m, (int)g);
+            const uint32_t ng = (uint32_t)__builtin_amdgcn_readlane((int)n, (int)g);
+            if (mg == 0u && ng == 0u) continue;
+            const uint8_t *q = J.reads + readlane64(q_at, g);
+            const uint8_t *src = J.genome + readlane64(t_at, g);
+            const bool rcg = __builtin_amdgcn_readlane((int)rc, (int)g) != 0;
+            // match masks: rows past the query match nothing
+#pragma unroll
+            for (int c = 0; c < CW; c++) {
+                if ((uint32_t)c * 64u < mg) {
+                    const uint32_t row = (uint32_t)c * 64u + lane;
+                    const uint32_t r = row < mg ? lut[q[row]] : 0xFFu;
+#pragma unroll
+                    for (int b = 0; b < 4; b++) {
+                        const uint64_t mask = __ballot(r == (uint32_t)b);
+                        peq[b][c] = lane == g ? mask : peq[b][c];
+                    }
+                }
+            }
+            // text window, reverse-complemented if asked (bucket_locator.h:562-567)
+            uint32_t *tg = text_of(g);
+            for (uint32_t k = 0; k * 64u < ng; k++) {
+                const uint32_t col = k * 64u + lane;
+                uint32_t r = 0;
+                if (col < ng) {
+                    r = lut[rcg ? src[ng - 1u - col] : src[col]];
+                    r = rcg ? 3u - r : r;
+                }
+                const uint64_t lo = __ballot((r & 1u) != 0), hi = __ballot((r & 2u) != 0);
+                if (lane == 0) {
+                    tg[4u * k + 0u] = (uint32_t)lo;
+                    tg[4u * k + 1u] = (uint32_t)hi;
+                    tg[4u * k + 2u] = (uint32_t)(lo >> 32);
+                    tg[4u * k + 3u] = (uint32_t)(hi >> 32);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    const uint32_t *text = text_of(lane);
+
+    // checkpoint entry of (block b, word w) of this lane's alignment
+    const uint32_t TW = J.trace_words;
+    uint64_t *ckpt = J.trace + (size_t)blockIdx.x * J.trace_stride;
+    uint32_t *hbuf = reinterpret_cast<uint32_t *>(ckpt + (size_t)J.trace_blocks * kWave * TW * 2u);
+    auto entry = [&](uint32_t b, uint32_t w) { return (b * TW + w) * kWave + lane; };
+
+    uint64_t pv[CW], mv[CW];
+    uint32_t hacc[CW];
+#pragma unroll
+    for (int c = 0; c < CW; c++) {
+        pv[c] = ~0ull;                                          // column 0: H[i][0] = i
+        mv[c] = 0;
+        hacc[c] = 0;
+    }
+    int32_t score = (int32_t)m, best = (int32_t)m;
+    uint32_t best_j = 0;
+    const uint32_t last_word = W ? W - 1u : 0u, last_bit = (m - 1u) & 63u;
+    uint32_t steps = W ? n : 0u;
+#pragma unroll
+    for (int o = 1; o < kWave; o <<= 1) {
+        const uint32_t other = (uint32_t)__shfl_xor((int)steps, o, kWave);
+        steps = other > steps ? other : steps;
+    }
+    uint32_t tlo = 0, thi = 0;                                  // the planes of the current 32 columns
+    for (uint32_t t = 1; t <= steps; t++) {                     // column t, the same for every lane
+        const uint32_t xt = (t - 1u) % kBlock, x32 = (t - 1u) & 31u;
+        if (W && t <= n) {
+            if (x32 == 0u) {
+                tlo = text[2u * ((t - 1u) >> 5)];
+                thi = text[2u * ((t - 1u) >> 5) + 1u];
+            }
+            const bool odd = ((tlo >> x32) & 1u) != 0, high = ((thi >> x32) & 1u) != 0;
+            uint32_t hin = 0;                                   // row 0 is all zeros: free leading text gaps
+#pragma unroll
+            for (int c = 0; c < CW; c++) {
+                if ((uint32_t)c < W) {
+                    const uint64_t el = odd ? peq[1][c] : peq[0][c], eh = odd ? peq[3][c] : peq[2][c];
+                    const uint64_t eq0 = high ? eh : el;
+                    uint64_t ph, mh, d0;
+                    const uint32_t hout = myers_step(eq0, hin, pv[c], mv[c], ph, mh, d0);
+                    if ((uint32_t)c == last_word) {
+                        if (CW > 1) asm volatile("" ::: "memory");   // keeps this a branch: not to be if-converted
+                        score += (int32_t)((ph >> last_bit) & 1ull) - (int32_t)((mh >> last_bit) & 1ull);
+                        if (score <= best) {                    // the LAST minimum of the bottom row
+                            best = score;
+                            best_j = t;
+                        }
+                    }
+                    hin = hout;
+                    hacc[c] |= hout << (2u * xt);
+                }
+            }
+        }
+        if (xt == kBlock - 1u || t == steps) {
+            const uint32_t bt = (t - 1u) / kBlock;
+#pragma unroll
+            for (int c = 0; c < CW; c++) {
+                if ((uint32_t)c < W && bt * kBlock < n) {
+                    hbuf[entry(bt, (uint32_t)c)] = hacc[c];
+                    uint64_t *ck = ckpt + (size_t)entry(bt + 1u, (uint32_t)c) * 2u;
+                    ck[0] = pv[c];
+                    ck[1] = mv[c];
+                }
+                hacc[c] = 0;
+            }
+        }
+    }
+    // The match masks leave the registers here: the traceback needs the four of ONE word per round, and 8 * CW registers
+    // kept for that would cost the kernel a wave per SIMD (its 16 + 16 trace words are the other half of the budget).
+    uint64_t *masks = reinterpret_cast<uint64_t *>(hbuf + (((size_t)J.trace_blocks * kWave * TW + 1u) & ~(size_t)1)) + lane;
+#pragma unroll
+    for (int c = 0; c < CW; c++) {
+        if ((uint32_t)c < W) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) masks[((uint32_t)r * TW + (uint32_t)c) * kWave] = peq[r][c];
+        }
+    }
+    __threadfence_block();                                      // (the traceback reads back this lane's own stores)
+    if (!have) return;
+    if (m == 0) {                                               // H[0][j] = 0 everywhere: last column
+        best = 0;
+        best_j = n;
+    }
+
+    // traceback: this lane's walk, in rounds of one (word, block) -- every lane recomputes the 16 columns it stands in,
+    // then walks until it leaves them
+    uint64_t D[kBlock], U[kBlock];                              // rotated: bit (r - x) & 63 of [x] is row r of column x
+#pragma unroll
+    for (int x = 0; x < (int)kBlock; x++) D[x] = U[x] = 0;
+    struct Checkpoint {
+        uint64_t pv, mv;
+        uint32_t hw;
+    };
+    auto load_checkpoint = [&](uint32_t w, uint32_t b) {
+        Checkpoint k{~0ull, 0ull, 0u};                          // block 0 starts from column 0; row 0: deltas 0
+        if (b) {
+            const uint64_t *ck = ckpt + (size_t)entry(b, w) * 2u;
+            k.pv = ck[0];
+            k.mv = ck[1];
+        }
+        if (w) k.hw = hbuf[entry(b, w - 1u)];                   // what left the word above at the same columns
+        return k;
+    };
+    uint32_t *ops = J.ops_rev + (size_t)slot * J.ops_stride;
+    uint32_t i = m, j = best_j, n_rev = 0, cur_op = 3, cur_len = 0;
+    auto emit = [&](uint32_t op, uint32_t len) {
+        if (op == cur_op) {
+            cur_len += len;
+        } else {
+            if (cur_len) ops[n_rev++] = (cur_len << 4) | cur_op;
+            cur_op = op;
+            cur_len = len;
+        }
+    };
+    while (__ballot(i > 0) != 0) {
+        uint32_t wc = 0, bc = 0;
+        if (i > 0 && j > 0) {
+            wc = (i - 1u) >> 6;
+            bc = (j - 1u) / kBlock;
+            Checkpoint k = load_checkpoint(wc, bc);
+            uint64_t pm[4];                                     // the word's match masks
+#pragma unroll
+            for (int r = 0; r < 4; r++) pm[r] = masks[((uint32_t)r * TW + wc) * kWave];
+            const uint32_t sh = 16u * (bc & 1u);
+            const uint32_t lo16 = text[2u * (bc >> 1)] >> sh, hi16 = text[2u * (bc >> 1) + 1u] >> sh;
+#pragma unroll
+            for (int x = 0; x < (int)kBlock; x++) {
+                if (bc * kBlock + 1u + (uint32_t)x <= n) {
+                    const bool odd = ((lo16 >> x) & 1u) != 0, high = ((hi16 >> x) & 1u) != 0;
+                    const uint64_t el = odd ? pm[1] : pm[0], eh = odd ? pm[3] : pm[2];
+                    const uint64_t eq0 = high ? eh : el;
+                    uint64_t ph, mh, d0;
+                    myers_step(eq0, (k.hw >> (2 * x)) & 3u, k.pv, k.mv, ph, mh, d0);
+                    D[x] = rotr64(~(eq0 ^ d0), (uint32_t)x);    // diagonal predecessor valid
+                    U[x] = rotr64(k.pv, (uint32_t)x);           // upper predecessor valid
+                }
+            }
+        }
+        while (i > 0 && (j == 0 || (((i - 1u) >> 6) == wc && (j - 1u) / kBlock == bc))) {
+            if (j == 0) {                                       // column 0: only upper predecessors, all the way
+                emit(1u, i);
+                i = 0;
+                break;
+            }
+            // diagonal first, as far as it goes: the cells (i - s, j - s) sit at bit `at` of columns x - s
+            const uint32_t x = (j - 1u) % kBlock, bit = (i - 1u) & 63u, at = (bit - x) & 63u;
+            const uint32_t room = (x < bit ? x : bit) + 1u;     // cells of this diagonal inside the word and the block
+            const uint32_t gaps = ~gather_bit(D, at) & ((2u << x) - 1u);
+            uint32_t run = gaps ? x - (31u - (uint32_t)__builtin_clz(gaps)) : x + 1u;
+            run = run < room ? run : room;
+            if (run) {
+                emit(0u, run);
+                i -= run;
+                j -= run;
+            }
+            if (run < room) {                                   // stopped by a cell whose diagonal predecessor is not valid
+                if ((gather_bit(U, at) >> (x - run)) & 1u) {
+                    emit(1u, 1u);
+                    i--;
+                } else {
+                    emit(2u, 1u);
+                    j--;
+                }
+            }
+        }
+    }
+    if (cur_len) ops[n_rev++] = (cur_len << 4) | cur_op;
+    J.out_score[a] = -best;
+    J.out_begin[a] = j;
+    J.out_nops[slot] = n_rev;
+}
+
 }  // namespace bmv

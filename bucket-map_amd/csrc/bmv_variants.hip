@@ -21,4 +21,13 @@ template __global__ void bmv_align_kernel<4, 4, false>(Job);
 template __global__ void bmv_align_kernel<8, 2, false>(Job);
 template __global__ void bmv_align_kernel<8, 3, false>(Job);
 template __global__ void bmv_align_kernel<1, 8, true>(Job);
+// one alignment per lane: queries of up to 64 * CW bases
+template __global__ void bmv_align_lane_kernel<1>(Job);
+template __global__ void bmv_align_lane_kernel<2>(Job);
+template __global__ void bmv_align_lane_kernel<3>(Job);
+template __global__ void bmv_align_lane_kernel<4>(Job);
+template __global__ void bmv_align_lane_kernel<5>(Job);
+template __global__ void bmv_align_lane_kernel<6>(Job);
+template __global__ void bmv_align_lane_kernel<7>(Job);
+template __global__ void bmv_align_lane_kernel<8>(Job);
 }  // namespace bmv

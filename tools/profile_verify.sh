@@ -3,10 +3,12 @@
 # counters (own runs, never combined with tracing).  gpurun -- 'bash tools/profile_verify.sh r02'
 set -e
 TAG=${1:-r02}
+NAME=${2:-verify}                     # 2nd argument: a name for the output directory; everything after it replaces ARGS
 ROOT=${GRAFT_REPO_ROOT:?GRAFT_REPO_ROOT is not set: run this through gpurun}
-OUT=$ROOT/gpurun_out/prof_${TAG}_verify
+OUT=$ROOT/gpurun_out/prof_${TAG}_${NAME}
 mkdir -p "$OUT"
 ARGS="--reads 40000 --len 10000 --indel-rate 0.1 --sub 0.03 --cpu-sample 1 --repeat 2"
+if [ $# -gt 2 ]; then shift 2; ARGS="$*"; fi
 cd /tmp && export TMPDIR=/tmp && cd "$ROOT"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt" -- python3 tools/bench_verify.py $ARGS > "$OUT/bench_kt.json" 2> "$OUT/bench_kt.err"
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --output-format csv -d "$OUT/a" -- python3 tools/bench_verify.py $ARGS > "$OUT/a.json" 2> "$OUT/a.err"
