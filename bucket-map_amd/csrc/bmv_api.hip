@@ -120,9 +120,11 @@ constexpr uint32_t kStripsBeyond = 64u * kMaxCw;                 // words: longe
 // Queries of up to this many words go one per lane (bmv_align_lane_kernel): 64 alignments share every instruction of a
 // column step.  BMV_LANE_MAX=0 switches it off (experiments; tests run both ways).
 constexpr uint32_t kLaneWords = 8;
+constexpr uint32_t kLaneMaxText = 2048;
 
 Shape pick_shape(uint32_t words, uint32_t max_n) {
-    {
+    // (64 text windows in LDS, 2 bits a base: 33 KB at 2 048 bases -- longer windows would leave a CU fewer than four waves)
+    if (max_n <= kLaneMaxText) {
         static const align_fn per_lane[kLaneWords + 1] = {nullptr,
                                                           bmv::bmv_align_lane_kernel<1>, bmv::bmv_align_lane_kernel<2>,
                                                           bmv::bmv_align_lane_kernel<3>, bmv::bmv_align_lane_kernel<4>,
@@ -407,7 +409,7 @@ int bmv_align(bmv_ctx *c, const uint8_t *reads, uint64_t n_read_bytes, const uin
         pl.n_blocks = (max_n + pl.sh.group + 15u) / 16u + 1u;     // blocks of 16 STEPS: the group's last lane is group - 1 steps behind
         const uint64_t n_entries = (uint64_t)pl.n_blocks * pl.gpw * pl.trace_words;
         pl.trace_stride = n_entries * 2u + (n_entries + 1u) / 2u;               // 64-bit words per wave
-        if (pl.sh.per_lane) pl.trace_stride += 4u * pl.trace_words * 64u;       // ... and the match masks, for the traceback
+        if (pl.sh.per_lane) pl.trace_stride += 2u * pl.trace_words * 64u;       // ... and the query's bit planes, for the traceback
         pl.ops_stride = max_m + max_n + 1u;
         pl.lds_stride = (max_n + 15u) / 16u * 4u + 4u;                          // the text as a 2-bit stream
         if (pl.sh.per_lane) pl.lds_stride = (max_n + 63u) / 64u * 16u + 8u;     // ... as two bit planes, 64 columns at a time
@@ -429,6 +431,7 @@ int bmv_align(bmv_ctx *c, const uint8_t *reads, uint64_t n_read_bytes, const uin
         need_slots = std::max(need_slots, (size_t)pl.chunk);
         plans.push_back(pl);
     }
+    const uint32_t stop_after = getenv("BMV_STOP_AFTER") ? (uint32_t)atoi(getenv("BMV_STOP_AFTER")) : 0u;   // phase timing
     auto launch = [&](const Plan &pl, uint64_t first, uint32_t count, hipStream_t stream, uint64_t *trace, uint32_t *ops_rev,
                       uint32_t *nops) {
         bmv::Job j{};
@@ -453,6 +456,7 @@ int bmv_align(bmv_ctx *c, const uint8_t *reads, uint64_t n_read_bytes, const uin
         j.out_score = c->out_score.p;
         j.out_begin = c->out_begin.p;
         j.out_nops = nops;
+        j.stop_after = stop_after;
         hipLaunchKernelGGL(pl.sh.fn, dim3((count + pl.gpw - 1u) / pl.gpw), dim3(bmv::kWave), pl.lds, stream, j);
         return hipGetLastError();
     };

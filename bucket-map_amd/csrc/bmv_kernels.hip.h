@@ -66,6 +66,7 @@ struct Job {
     int32_t *out_score;             // per alignment of the batch
     uint32_t *out_begin;
     uint32_t *out_nops;             // per slot
+    uint32_t stop_after;            // experiments (BMV_STOP_AFTER): 1 = return after the set-up, 2 = after the forward pass
 };
 
 __device__ __forceinline__ uint64_t shfl64(uint64_t v, int src_lane) {
@@ -478,9 +479,9 @@ __global__ __launch_bounds__(kWave) void bmv_align_kernel(Job J) {
 // the column step, against 64 / GROUP above (32 for a 300-bp read as 2 lanes x 3 words, and those 6 words for 5): nothing is
 // skewed, no delta crosses lanes, the text's column is the same for the whole wave.  What the lanes do together is the
 // LOADING: alignment g's query and text are read 64 bases at a time by the whole wave (one cache line per instruction
-// instead of 64), and a ballot per base rank turns 64 bases into the match masks of one query word (left in lane g's
-// registers) or into the two bit planes of 64 text columns (left in LDS, 32 columns per 32-bit word, low plane then high).
-// Checkpoints as above, laid out [block][word][lane]; behind them the match masks, [rank][word][lane].  The traceback is each lane's own: the 16 columns of the current
+// instead of 64), and two ballots turn 64 bases into the two bit planes of their ranks: of one query word (left in lane g's
+// registers) or of 64 text columns (left in LDS, 32 columns per 32-bit word, low plane then high).
+// Checkpoints as above, laid out [block][word][lane]; behind them the query's planes, [plane][word][lane].  The traceback is each lane's own: the 16 columns of the current
 // (word, block) are kept ROTATED -- column x's trace words turned right by x bits -- so that the cells of one diagonal sit
 // at the same bit of all 16: a diagonal run is read off with one bit extraction per column, whatever lane asks for whatever
 // diagonal, and no register is indexed by a value the compiler cannot see.
@@ -506,6 +507,38 @@ __device__ __forceinline__ uint32_t gather_bit(const uint64_t (&words)[kBlock], 
     return out;
 }
 
+// One column step of one word with the horizontal delta carried as two WORDS whose bit 31 counts (hpw: +1 enters, hmw: -1
+// enters; on return the ones that leave): they are simply the high halves of the Ph and Mh of the word above, and the
+// 64-bit shifts take them in through v_alignbit -- the packed 2-bit code of myers_step costs a shift and two masks per word
+// and step to put together and take apart.
+__device__ __forceinline__ uint64_t shl1_carry(uint64_t v, uint32_t carry_word) {
+    const uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+    return ((uint64_t)__builtin_amdgcn_alignbit(hi, lo, 31) << 32) | __builtin_amdgcn_alignbit(lo, carry_word, 31);
+}
+
+__device__ __forceinline__ void myers_step_carry(uint64_t eq0, uint32_t &hpw, uint32_t &hmw, uint64_t &pv, uint64_t &mv, uint64_t &ph,
+                                                 uint64_t &mh, uint64_t &d0) {
+    const uint64_t xv = eq0 | mv;
+    const uint64_t eq = eq0 | (hmw >> 31);
+    const uint64_t xh = (((eq & pv) + pv) ^ pv) | eq;
+    ph = mv | ~(xh | pv);
+    mh = pv & xh;
+    d0 = xh | mv;
+    const uint64_t phs = shl1_carry(ph, hpw), mhs = shl1_carry(mh, hmw);
+    hpw = (uint32_t)(ph >> 32);
+    hmw = (uint32_t)(mh >> 32);
+    pv = mhs | ~(xv | phs);
+    mv = phs & xv;
+}
+
+// The rows of a word that match a text base: the query is kept as the two bit planes of its ranks (q0: low bit, q1: high
+// bit -- 4 registers per word where four match masks are 8), the base as two all-or-nothing words.  Rows past the query's
+// end compare like any other: nothing below the last row flows back up (carries and shifts go towards higher rows).
+__device__ __forceinline__ uint64_t match_rows(uint64_t q0, uint64_t q1, bool odd, bool high) {
+    const uint64_t t0 = odd ? ~0ull : 0ull, t1 = high ? ~0ull : 0ull;
+    return ~(q0 ^ t0) & ~(q1 ^ t1);
+}
+
 template <int CW>
 __global__ __launch_bounds__(kWave) void bmv_align_lane_kernel(Job J) {
     extern __shared__ uint8_t lds_text[];
@@ -520,41 +553,53 @@ __global__ __launch_bounds__(kWave) void bmv_align_lane_kernel(Job J) {
     // the text of alignment g: pairs (low plane, high plane) of 32 columns each
     auto text_of = [&](uint32_t g) { return reinterpret_cast<uint32_t *>(lds_text + 256 + (size_t)g * J.text_lds_stride); };
 
-    uint64_t peq[4][CW];
+    uint64_t q0[CW], q1[CW];
 #pragma unroll
-    for (int c = 0; c < CW; c++) peq[0][c] = peq[1][c] = peq[2][c] = peq[3][c] = 0;
+    for (int c = 0; c < CW; c++) q0[c] = q1[c] = 0;
     {
+        // Alignment g + 1's bases are on their way while alignment g's are turned into planes: CW query chunks and the
+        // first CW + 1 text chunks of 64 (a text is a little longer than its query; a longer one fetches the rest in place).
+        constexpr int TK = CW + 1;
+        struct Raw {
+            uint32_t q[CW], t[TK];
+        };
         const uint64_t q_at = have ? J.query_start[a] : 0u, t_at = have ? J.text_start[a] : 0u;
         const uint32_t rc = have ? J.text_rc[a] : 0u;
-        for (uint32_t g = 0; g < kWave; g++) {                  // (everything indexed by g is the same in every lane)
+        auto fetch = [&](uint32_t g, Raw &raw) {                // (everything indexed by g is the same in every lane)
             const uint32_t mg = (uint32_t)__builtin_amdgcn_readlane((int)m, (int)g);
             const uint32_t ng = (uint32_t)__builtin_amdgcn_readlane((int)n, (int)g);
-            if (mg == 0u && ng == 0u) continue;
             const uint8_t *q = J.reads + readlane64(q_at, g);
             const uint8_t *src = J.genome + readlane64(t_at, g);
             const bool rcg = __builtin_amdgcn_readlane((int)rc, (int)g) != 0;
-            // match masks: rows past the query match nothing
+#pragma unroll
+            for (int c = 0; c < CW; c++) {
+                const uint32_t row = (uint32_t)c * 64u + lane;
+                raw.q[c] = row < mg ? q[row] : 0u;
+            }
+#pragma unroll
+            for (int k = 0; k < TK; k++) {
+                const uint32_t col = (uint32_t)k * 64u + lane;
+                raw.t[k] = col < ng ? (rcg ? src[ng - 1u - col] : src[col]) : 0u;
+            }
+        };
+        auto deposit = [&](uint32_t g, const Raw &raw) {
+            const uint32_t mg = (uint32_t)__builtin_amdgcn_readlane((int)m, (int)g);
+            const uint32_t ng = (uint32_t)__builtin_amdgcn_readlane((int)n, (int)g);
+            const bool rcg = __builtin_amdgcn_readlane((int)rc, (int)g) != 0;
 #pragma unroll
             for (int c = 0; c < CW; c++) {
                 if ((uint32_t)c * 64u < mg) {
-                    const uint32_t row = (uint32_t)c * 64u + lane;
-                    const uint32_t r = row < mg ? lut[q[row]] : 0xFFu;
-#pragma unroll
-                    for (int b = 0; b < 4; b++) {
-                        const uint64_t mask = __ballot(r == (uint32_t)b);
-                        peq[b][c] = lane == g ? mask : peq[b][c];
-                    }
+                    const uint32_t r = lut[raw.q[c]];
+                    const uint64_t b0 = __ballot((r & 1u) != 0), b1 = __ballot((r & 2u) != 0);
+                    q0[c] = lane == g ? b0 : q0[c];
+                    q1[c] = lane == g ? b1 : q1[c];
                 }
             }
             // text window, reverse-complemented if asked (bucket_locator.h:562-567)
             uint32_t *tg = text_of(g);
-            for (uint32_t k = 0; k * 64u < ng; k++) {
-                const uint32_t col = k * 64u + lane;
-                uint32_t r = 0;
-                if (col < ng) {
-                    r = lut[rcg ? src[ng - 1u - col] : src[col]];
-                    r = rcg ? 3u - r : r;
-                }
+            auto planes = [&](uint32_t k, uint32_t byte) {
+                uint32_t r = lut[byte];
+                r = rcg ? 3u - r : r;
                 const uint64_t lo = __ballot((r & 1u) != 0), hi = __ballot((r & 2u) != 0);
                 if (lane == 0) {
                     tg[4u * k + 0u] = (uint32_t)lo;
@@ -562,7 +607,26 @@ __global__ __launch_bounds__(kWave) void bmv_align_lane_kernel(Job J) {
                     tg[4u * k + 2u] = (uint32_t)(lo >> 32);
                     tg[4u * k + 3u] = (uint32_t)(hi >> 32);
                 }
+            };
+#pragma unroll
+            for (int k = 0; k < TK; k++) {
+                if ((uint32_t)k * 64u < ng) planes((uint32_t)k, raw.t[k]);
             }
+            if ((uint32_t)TK * 64u < ng) {
+                const uint8_t *src = J.genome + readlane64(t_at, g);
+                for (uint32_t k = TK; k * 64u < ng; k++) {
+                    const uint32_t col = k * 64u + lane;
+                    planes(k, col < ng ? (rcg ? src[ng - 1u - col] : src[col]) : 0u);
+                }
+            }
+        };
+        Raw even, odd;
+        fetch(0u, even);
+        for (uint32_t g = 0; g < kWave; g += 2u) {
+            fetch(g + 1u, odd);
+            deposit(g, even);
+            if (g + 2u < kWave) fetch(g + 2u, even);
+            deposit(g + 1u, odd);
         }
     }
     __syncthreads();
@@ -573,24 +637,33 @@ __global__ __launch_bounds__(kWave) void bmv_align_lane_kernel(Job J) {
     uint64_t *ckpt = J.trace + (size_t)blockIdx.x * J.trace_stride;
     uint32_t *hbuf = reinterpret_cast<uint32_t *>(ckpt + (size_t)J.trace_blocks * kWave * TW * 2u);
     auto entry = [&](uint32_t b, uint32_t w) { return (b * TW + w) * kWave + lane; };
+    if (J.stop_after == 1u) {                                   // (phase timing, tools/bench_verify.py: no results)
+        if (have) J.out_nops[slot] = 0;
+        return;
+    }
 
     uint64_t pv[CW], mv[CW];
-    uint32_t hacc[CW];
+    uint32_t hacc_p[CW], hacc_m[CW];                            // deltas leaving each word in this block, the latest in bit 0
 #pragma unroll
     for (int c = 0; c < CW; c++) {
         pv[c] = ~0ull;                                          // column 0: H[i][0] = i
         mv[c] = 0;
-        hacc[c] = 0;
+        hacc_p[c] = hacc_m[c] = 0;
     }
     int32_t score = (int32_t)m, best = (int32_t)m;
     uint32_t best_j = 0;
     const uint32_t last_word = W ? W - 1u : 0u, last_bit = (m - 1u) & 63u;
-    uint32_t steps = W ? n : 0u;
+    uint32_t steps = W ? n : 0u, wave_words = W;
 #pragma unroll
     for (int o = 1; o < kWave; o <<= 1) {
-        const uint32_t other = (uint32_t)__shfl_xor((int)steps, o, kWave);
+        const uint32_t other = (uint32_t)__shfl_xor((int)steps, o, kWave), other_w = (uint32_t)__shfl_xor((int)wave_words, o, kWave);
         steps = other > steps ? other : steps;
+        wave_words = other_w > wave_words ? other_w : wave_words;
     }
+    // A lane runs as many words as the wave's longest query has: the instructions are issued for the wave anyway, rows past
+    // a query's end harm nothing, and a test the whole wave agrees on is a scalar branch (a lane's own "c < W" is a saved and
+    // restored exec mask per word and step, and copies of everything carried from word to word).
+    wave_words = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_words);
     uint32_t tlo = 0, thi = 0;                                  // the planes of the current 32 columns
     for (uint32_t t = 1; t <= steps; t++) {                     // column t, the same for every lane
         const uint32_t xt = (t - 1u) % kBlock, x32 = (t - 1u) & 31u;
@@ -600,25 +673,23 @@ __global__ __launch_bounds__(kWave) void bmv_align_lane_kernel(Job J) {
                 thi = text[2u * ((t - 1u) >> 5) + 1u];
             }
             const bool odd = ((tlo >> x32) & 1u) != 0, high = ((thi >> x32) & 1u) != 0;
-            uint32_t hin = 0;                                   // row 0 is all zeros: free leading text gaps
+            uint32_t hpw = 0, hmw = 0;                          // row 0 is all zeros: free leading text gaps
 #pragma unroll
             for (int c = 0; c < CW; c++) {
-                if ((uint32_t)c < W) {
-                    const uint64_t el = odd ? peq[1][c] : peq[0][c], eh = odd ? peq[3][c] : peq[2][c];
-                    const uint64_t eq0 = high ? eh : el;
-                    uint64_t ph, mh, d0;
-                    const uint32_t hout = myers_step(eq0, hin, pv[c], mv[c], ph, mh, d0);
-                    if ((uint32_t)c == last_word) {
-                        if (CW > 1) asm volatile("" ::: "memory");   // keeps this a branch: not to be if-converted
-                        score += (int32_t)((ph >> last_bit) & 1ull) - (int32_t)((mh >> last_bit) & 1ull);
-                        if (score <= best) {                    // the LAST minimum of the bottom row
-                            best = score;
-                            best_j = t;
-                        }
+                if ((uint32_t)c >= wave_words) break;
+                const uint64_t eq0 = match_rows(q0[c], q1[c], odd, high);
+                uint64_t ph, mh, d0;
+                myers_step_carry(eq0, hpw, hmw, pv[c], mv[c], ph, mh, d0);
+                if ((uint32_t)c == last_word) {
+                    if (CW > 1) asm volatile("" ::: "memory");   // keeps this a branch: not to be if-converted
+                    score += (int32_t)((ph >> last_bit) & 1ull) - (int32_t)((mh >> last_bit) & 1ull);
+                    if (score <= best) {                        // the LAST minimum of the bottom row
+                        best = score;
+                        best_j = t;
                     }
-                    hin = hout;
-                    hacc[c] |= hout << (2u * xt);
                 }
+                hacc_p[c] = __builtin_amdgcn_alignbit(hacc_p[c], hpw, 31);     // (hacc << 1) | bit 31 of the delta word
+                hacc_m[c] = __builtin_amdgcn_alignbit(hacc_m[c], hmw, 31);
             }
         }
         if (xt == kBlock - 1u || t == steps) {
@@ -626,26 +697,32 @@ __global__ __launch_bounds__(kWave) void bmv_align_lane_kernel(Job J) {
 #pragma unroll
             for (int c = 0; c < CW; c++) {
                 if ((uint32_t)c < W && bt * kBlock < n) {
-                    hbuf[entry(bt, (uint32_t)c)] = hacc[c];
+                    // step x of the block to bit 15 - x (+1) and 31 - x (-1), however many steps this lane's text had here
+                    const uint32_t done = n - bt * kBlock < kBlock ? n - bt * kBlock : kBlock;
+                    hbuf[entry(bt, (uint32_t)c)] = ((hacc_p[c] << (kBlock - done)) & 0xFFFFu) | (hacc_m[c] << (2u * kBlock - done));
                     uint64_t *ck = ckpt + (size_t)entry(bt + 1u, (uint32_t)c) * 2u;
                     ck[0] = pv[c];
                     ck[1] = mv[c];
                 }
-                hacc[c] = 0;
+                hacc_p[c] = hacc_m[c] = 0;
             }
         }
     }
-    // The match masks leave the registers here: the traceback needs the four of ONE word per round, and 8 * CW registers
-    // kept for that would cost the kernel a wave per SIMD (its 16 + 16 trace words are the other half of the budget).
-    uint64_t *masks = reinterpret_cast<uint64_t *>(hbuf + (((size_t)J.trace_blocks * kWave * TW + 1u) & ~(size_t)1)) + lane;
+    // The query's planes leave the registers here: the traceback needs those of ONE word per round, and registers kept for
+    // that would cost the kernel a wave per SIMD (its 16 + 16 trace words are the budget).
+    uint64_t *planes_at = reinterpret_cast<uint64_t *>(hbuf + (((size_t)J.trace_blocks * kWave * TW + 1u) & ~(size_t)1)) + lane;
 #pragma unroll
     for (int c = 0; c < CW; c++) {
         if ((uint32_t)c < W) {
-#pragma unroll
-            for (int r = 0; r < 4; r++) masks[((uint32_t)r * TW + (uint32_t)c) * kWave] = peq[r][c];
+            planes_at[(uint32_t)c * kWave] = q0[c];
+            planes_at[(TW + (uint32_t)c) * kWave] = q1[c];
         }
     }
     __threadfence_block();                                      // (the traceback reads back this lane's own stores)
+    if (J.stop_after == 2u) {
+        if (have) J.out_nops[slot] = 0;
+        return;
+    }
     if (!have) return;
     if (m == 0) {                                               // H[0][j] = 0 everywhere: last column
         best = 0;
@@ -657,20 +734,6 @@ __global__ __launch_bounds__(kWave) void bmv_align_lane_kernel(Job J) {
     uint64_t D[kBlock], U[kBlock];                              // rotated: bit (r - x) & 63 of [x] is row r of column x
 #pragma unroll
     for (int x = 0; x < (int)kBlock; x++) D[x] = U[x] = 0;
-    struct Checkpoint {
-        uint64_t pv, mv;
-        uint32_t hw;
-    };
-    auto load_checkpoint = [&](uint32_t w, uint32_t b) {
-        Checkpoint k{~0ull, 0ull, 0u};                          // block 0 starts from column 0; row 0: deltas 0
-        if (b) {
-            const uint64_t *ck = ckpt + (size_t)entry(b, w) * 2u;
-            k.pv = ck[0];
-            k.mv = ck[1];
-        }
-        if (w) k.hw = hbuf[entry(b, w - 1u)];                   // what left the word above at the same columns
-        return k;
-    };
     uint32_t *ops = J.ops_rev + (size_t)slot * J.ops_stride;
     uint32_t i = m, j = best_j, n_rev = 0, cur_op = 3, cur_len = 0;
     auto emit = [&](uint32_t op, uint32_t len) {
@@ -687,22 +750,28 @@ __global__ __launch_bounds__(kWave) void bmv_align_lane_kernel(Job J) {
         if (i > 0 && j > 0) {
             wc = (i - 1u) >> 6;
             bc = (j - 1u) / kBlock;
-            Checkpoint k = load_checkpoint(wc, bc);
-            uint64_t pm[4];                                     // the word's match masks
-#pragma unroll
-            for (int r = 0; r < 4; r++) pm[r] = masks[((uint32_t)r * TW + wc) * kWave];
+            // checkpoint of (word, block): the vertical state the block starts from (block 0: column 0, H[i][0] = i) and the
+            // deltas that left the word above at the same columns (row 0 above the first word: all zero)
+            uint64_t kpv = ~0ull, kmv = 0ull;
+            uint32_t hw = 0;
+            if (bc) {
+                const uint64_t *ck = ckpt + (size_t)entry(bc, wc) * 2u;
+                kpv = ck[0];
+                kmv = ck[1];
+            }
+            if (wc) hw = hbuf[entry(bc, wc - 1u)];
+            const uint64_t w0 = planes_at[wc * kWave], w1 = planes_at[(TW + wc) * kWave];
             const uint32_t sh = 16u * (bc & 1u);
             const uint32_t lo16 = text[2u * (bc >> 1)] >> sh, hi16 = text[2u * (bc >> 1) + 1u] >> sh;
 #pragma unroll
             for (int x = 0; x < (int)kBlock; x++) {
                 if (bc * kBlock + 1u + (uint32_t)x <= n) {
-                    const bool odd = ((lo16 >> x) & 1u) != 0, high = ((hi16 >> x) & 1u) != 0;
-                    const uint64_t el = odd ? pm[1] : pm[0], eh = odd ? pm[3] : pm[2];
-                    const uint64_t eq0 = high ? eh : el;
+                    const uint64_t eq0 = match_rows(w0, w1, ((lo16 >> x) & 1u) != 0, ((hi16 >> x) & 1u) != 0);
+                    uint32_t hpw = hw << (x + (int)kBlock), hmw = hw << x;    // the step's bits to bit 31
                     uint64_t ph, mh, d0;
-                    myers_step(eq0, (k.hw >> (2 * x)) & 3u, k.pv, k.mv, ph, mh, d0);
+                    myers_step_carry(eq0, hpw, hmw, kpv, kmv, ph, mh, d0);
                     D[x] = rotr64(~(eq0 ^ d0), (uint32_t)x);    // diagonal predecessor valid
-                    U[x] = rotr64(k.pv, (uint32_t)x);           // upper predecessor valid
+                    U[x] = rotr64(kpv, (uint32_t)x);            // upper predecessor valid
                 }
             }
         }

@@ -165,23 +165,64 @@ def _compare(v, genome, batch, what):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("lane_max", [None, "0", "3"])      # BMV_LANE_MAX: queries of up to that many words go one per lane
 @pytest.mark.parametrize("max_m,n,err", [
-    (150, 600, (0.02, 0.005, 0.005)),       # 4 lanes per alignment
-    (300, 600, (0.02, 0.005, 0.005)),       # 8
-    (500, 300, (0.05, 0.02, 0.02)),         # 8, noisier
-    (1000, 120, (0.03, 0.025, 0.025)),      # 16
-    (3000, 40, (0.03, 0.025, 0.025)),       # 64
+    (150, 600, (0.02, 0.005, 0.005)),       # one alignment per lane, 3 words (groups of 2 lanes with BMV_LANE_MAX=0)
+    (300, 600, (0.02, 0.005, 0.005)),       # ... 5 words (2 lanes x 3 words)
+    (500, 300, (0.05, 0.02, 0.02)),         # ... 8 words, noisier (3 lanes x 3)
+    (1000, 120, (0.03, 0.025, 0.025)),      # groups of lanes from here on
+    (3000, 40, (0.03, 0.025, 0.025)),
 ])
-def test_gpu_verifier_matches_oracle(max_m, n, err):
+def test_gpu_verifier_matches_oracle(max_m, n, err, lane_max, monkeypatch):
     from bucket_map_amd import verify
+    if lane_max is not None:
+        if max_m > 512:
+            pytest.skip("no query short enough for a lane of its own")
+        monkeypatch.setenv("BMV_LANE_MAX", lane_max)
     rng = np.random.default_rng(max_m)
     genome = rng.choice(list(b"ACGT"), 200_000).astype(np.uint8)
     genome[rng.integers(0, len(genome), 200)] = ord("N")
     v = verify.Verifier()
     v.load_genome(genome)
-    s = _compare(v, genome, _random_batch(rng, genome, n, max_m, err), f"max_m={max_m}")
+    s = _compare(v, genome, _random_batch(rng, genome, n, max_m, err), f"max_m={max_m} BMV_LANE_MAX={lane_max}")
     assert (s > -0.2 * max_m).mean() > 0.5          # most queries really align to their window
     assert v.stats()["cells"] > 0 and v.stats()["ms_kernels"] > 0
+    v.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("max_m,width", [(64, 700), (200, 2048), (200, 2049), (320, 5000)])
+def test_gpu_verifier_short_queries_in_long_windows(max_m, width):
+    """A text window much longer than its query: the lane-per-alignment kernel fetches the window's later chunks in place
+    (its look-ahead covers a query's length plus 64), and windows of more than 2 048 bases go to the kernels that spread an
+    alignment over a group of lanes (64 windows of that size do not fit a wave's LDS)."""
+    from bucket_map_amd import verify
+    rng = np.random.default_rng(width)
+    genome = rng.choice(list(b"ACGT"), 100_000).astype(np.uint8)
+    n = 130
+    reads, ts, tl, trc, qs, ql = [], [], [], [], [], []
+    at = 0
+    for a in range(n):
+        m = int(rng.integers(1, max_m + 1))
+        w = int(rng.integers(max(m, width // 2), width + 1)) if a else width
+        start = int(rng.integers(0, len(genome) - w))
+        rc = int(rng.integers(0, 2))
+        inner = start + int(rng.integers(0, w - m + 1))
+        src = genome[inner: inner + m]
+        if rc:
+            src = np.frombuffer(bytes(src).translate(COMP)[::-1], np.uint8)
+        q = _mutate(rng, src, 0.03, 0.01, 0.01)
+        if len(q) == 0:
+            q = np.frombuffer(b"C", np.uint8)
+        reads.append(q)
+        ts.append(start); tl.append(w); trc.append(rc); qs.append(at); ql.append(len(q))
+        at += len(q)
+    batch = (np.concatenate(reads), np.array(ts, np.uint64), np.array(tl, np.uint32), np.array(trc, np.uint8),
+             np.array(qs, np.uint64), np.array(ql, np.uint32))
+    v = verify.Verifier()
+    v.load_genome(genome)
+    s = _compare(v, genome, batch, f"max_m={max_m} width={width}")
+    assert (s > -0.2 * max_m).mean() > 0.8
     v.close()
 
 
@@ -408,11 +449,15 @@ def test_gpu_verifier_random_sweep(seed):
     genome = rng.choice(list(b"ACGT"), max(4 * max_m, 2000)).astype(np.uint8)
     n = int(np.clip(60000 // max_m, 3, 150))
     cw = int(rng.integers(0, 9))                       # 0: the library's own choice
+    lane_max = int(rng.choice([8, 8, 0, 2, 5]))        # queries of up to that many words go one per lane (8: the default)
     v = verify.Verifier()
     v.load_genome(genome)
     os.environ["BMV_CW"] = str(cw)
+    os.environ["BMV_LANE_MAX"] = str(lane_max)
     try:
-        _compare(v, genome, _random_batch(rng, genome, n, max_m, err), f"seed={seed} max_m={max_m} err={err} BMV_CW={cw}")
+        _compare(v, genome, _random_batch(rng, genome, n, max_m, err),
+                 f"seed={seed} max_m={max_m} err={err} BMV_CW={cw} BMV_LANE_MAX={lane_max}")
     finally:
         del os.environ["BMV_CW"]
+        del os.environ["BMV_LANE_MAX"]
     v.close()
