@@ -274,7 +274,7 @@ void bmv_destroy(bmv_ctx *c) {
 int bmv_load_genome(bmv_ctx *c, const uint8_t *bases, uint64_t n_bases) {
     if (!c || (n_bases && !bases)) return fail(BMV_ERR_ARG, "bmv_load_genome: null argument");
     HIP_TRY(hipSetDevice(c->p.device));
-    HIP_TRY(c->genome.need((size_t)n_bases));
+    HIP_TRY(c->genome.need((size_t)n_bases + 64u));             // (slack: an empty text window at the very end is still fetched from)
     if (n_bases) HIP_TRY(hipMemcpy(c->genome.p, bases, (size_t)n_bases, hipMemcpyHostToDevice));
     c->n_genome = n_bases;
     c->loaded = true;
@@ -311,7 +311,7 @@ int bmv_align(bmv_ctx *c, const uint8_t *reads, uint64_t n_read_bytes, const uin
     if (n == 0) return BMV_OK;
 
     HIP_TRY(hipSetDevice(c->p.device));
-    HIP_TRY(c->reads.need((size_t)n_read_bytes));
+    HIP_TRY(c->reads.need((size_t)n_read_bytes + 64u));         // (slack: so is an empty query)
     HIP_TRY(c->text_start.need(n));
     HIP_TRY(c->text_len.need(n));
     HIP_TRY(c->text_rc.need(n));

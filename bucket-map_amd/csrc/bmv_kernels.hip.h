@@ -492,6 +492,18 @@ __device__ __forceinline__ uint64_t readlane64(uint64_t v, uint32_t src) {
     return ((uint64_t)hi << 32) | lo;
 }
 
+// `old` with lane `dst`'s value replaced by v (v and dst the same in every lane)
+// (v_writelane_b32 has no builtin in this compiler.  The s_nop: v is a ballot, an SGPR pair a VALU compare has just written,
+// and gfx950 wants two wait states before another VALU instruction reads it -- the compiler's hazard pass does not look
+// inside an asm block; nor does it see that M0, written by the SALU, is read as a lane select -- one wait state, covered.)
+__device__ __forceinline__ uint64_t writelane64(uint64_t old, uint64_t v, uint32_t dst) {
+    uint32_t lo = (uint32_t)old, hi = (uint32_t)(old >> 32);
+    asm("s_mov_b32 m0, %4\n\ts_nop 0\n\tv_writelane_b32 %0, %2, m0\n\tv_writelane_b32 %1, %3, m0"   // (one SGPR operand each: the lane in M0)
+        : "+v"(lo), "+v"(hi)
+        : "s"((uint32_t)v), "s"((uint32_t)(v >> 32)), "s"(dst));   // (M0 cannot be named as clobbered; nothing else here uses it)
+    return ((uint64_t)hi << 32) | lo;
+}
+
 __device__ __forceinline__ uint64_t rotr64(uint64_t v, uint32_t by) { return by ? (v >> by) | (v << (64u - by)) : v; }
 
 // bit `at` (0..63, any lane its own) of each of 16 words, gathered into bits 0..15
@@ -565,41 +577,50 @@ __global__ __launch_bounds__(kWave) void bmv_align_lane_kernel(Job J) {
         };
         const uint64_t q_at = have ? J.query_start[a] : 0u, t_at = have ? J.text_start[a] : 0u;
         const uint32_t rc = have ? J.text_rc[a] : 0u;
+        // (Loads without a condition around them -- a lane past the end reads the last base again, or the byte an empty query
+        // or window begins at: the buffers have slack for that -- so that the compiler knows how many loads are in flight and
+        // waiting for alignment g's bases does not wait for alignment g + 1's too.  A base in SGPRs plus a 32-bit lane offset.)
         auto fetch = [&](uint32_t g, Raw &raw) {                // (everything indexed by g is the same in every lane)
             const uint32_t mg = (uint32_t)__builtin_amdgcn_readlane((int)m, (int)g);
             const uint32_t ng = (uint32_t)__builtin_amdgcn_readlane((int)n, (int)g);
             const uint8_t *q = J.reads + readlane64(q_at, g);
             const uint8_t *src = J.genome + readlane64(t_at, g);
             const bool rcg = __builtin_amdgcn_readlane((int)rc, (int)g) != 0;
+            const uint32_t q_last = mg ? mg - 1u : 0u, t_last = ng ? ng - 1u : 0u;
+            const uint32_t flip = rcg ? ~0u : 0u, from = rcg ? t_last + 1u : 0u;   // (col ^ flip) + from: col, or t_last - col
 #pragma unroll
             for (int c = 0; c < CW; c++) {
                 const uint32_t row = (uint32_t)c * 64u + lane;
-                raw.q[c] = row < mg ? q[row] : 0u;
+                raw.q[c] = q[row < q_last ? row : q_last];
             }
 #pragma unroll
             for (int k = 0; k < TK; k++) {
                 const uint32_t col = (uint32_t)k * 64u + lane;
-                raw.t[k] = col < ng ? (rcg ? src[ng - 1u - col] : src[col]) : 0u;
+                raw.t[k] = src[((col < t_last ? col : t_last) ^ flip) + from];
             }
         };
         auto deposit = [&](uint32_t g, const Raw &raw) {
             const uint32_t mg = (uint32_t)__builtin_amdgcn_readlane((int)m, (int)g);
             const uint32_t ng = (uint32_t)__builtin_amdgcn_readlane((int)n, (int)g);
             const bool rcg = __builtin_amdgcn_readlane((int)rc, (int)g) != 0;
+            // ranks first, all of them at once (rows past a query's end and columns past a text's get whatever the table holds
+            // for the stand-in byte: never looked at)
+            uint32_t rq[CW], rt[TK];
+#pragma unroll
+            for (int c = 0; c < CW; c++) rq[c] = lut[raw.q[c]];
+#pragma unroll
+            for (int k = 0; k < TK; k++) rt[k] = lut[raw.t[k]] ^ (rcg ? 3u : 0u);   // (3 - r: the complement)
 #pragma unroll
             for (int c = 0; c < CW; c++) {
                 if ((uint32_t)c * 64u < mg) {
-                    const uint32_t r = lut[raw.q[c]];
-                    const uint64_t b0 = __ballot((r & 1u) != 0), b1 = __ballot((r & 2u) != 0);
-                    q0[c] = lane == g ? b0 : q0[c];
-                    q1[c] = lane == g ? b1 : q1[c];
+                    const uint64_t b0 = __ballot((rq[c] & 1u) != 0), b1 = __ballot((rq[c] & 2u) != 0);
+                    q0[c] = writelane64(q0[c], b0, g);          // into lane g's registers
+                    q1[c] = writelane64(q1[c], b1, g);
                 }
             }
             // text window, reverse-complemented if asked (bucket_locator.h:562-567)
             uint32_t *tg = text_of(g);
-            auto planes = [&](uint32_t k, uint32_t byte) {
-                uint32_t r = lut[byte];
-                r = rcg ? 3u - r : r;
+            auto planes = [&](uint32_t k, uint32_t r) {
                 const uint64_t lo = __ballot((r & 1u) != 0), hi = __ballot((r & 2u) != 0);
                 if (lane == 0) {
                     tg[4u * k + 0u] = (uint32_t)lo;
@@ -610,13 +631,14 @@ __global__ __launch_bounds__(kWave) void bmv_align_lane_kernel(Job J) {
             };
 #pragma unroll
             for (int k = 0; k < TK; k++) {
-                if ((uint32_t)k * 64u < ng) planes((uint32_t)k, raw.t[k]);
+                if ((uint32_t)k * 64u < ng) planes((uint32_t)k, rt[k]);
             }
             if ((uint32_t)TK * 64u < ng) {
                 const uint8_t *src = J.genome + readlane64(t_at, g);
                 for (uint32_t k = TK; k * 64u < ng; k++) {
                     const uint32_t col = k * 64u + lane;
-                    planes(k, col < ng ? (rcg ? src[ng - 1u - col] : src[col]) : 0u);
+                    const uint32_t r = col < ng ? lut[rcg ? src[ng - 1u - col] : src[col]] : 0u;
+                    planes(k, rcg ? 3u - r : r);
                 }
             }
         };
@@ -625,7 +647,7 @@ __global__ __launch_bounds__(kWave) void bmv_align_lane_kernel(Job J) {
         for (uint32_t g = 0; g < kWave; g += 2u) {
             fetch(g + 1u, odd);
             deposit(g, even);
-            if (g + 2u < kWave) fetch(g + 2u, even);
+            fetch((g + 2u) % kWave, even);                      // (the last round fetches alignment 0 again, for nothing: no branch)
             deposit(g + 1u, odd);
         }
     }
