@@ -18,8 +18,9 @@
  * MAPQ = 60 + score rule and its threshold (:570-573), SAM output.
  *
  * Semi-global edit distance (the whole query against the best substring of the text, unit costs) by
- * Myers' bit-vector recurrence, 64 query rows per lane, lanes skewed along the text (queries beyond 16 384
- * bases in strips of that many rows); the traceback runs on the device too.  The score is unique; between equally good alignments SeqAn3's own choice is not
+ * Myers' bit-vector recurrence in words of 64 query rows: a query of up to 512 bases is one lane's work (64 alignments per
+ * wave), a longer one is spread over a group of lanes skewed along the text (beyond 32 768 bases in strips of that many
+ * rows); the traceback runs on the device too.  The score is unique; between equally good alignments SeqAn3's own choice is not
  * pinned by anything in the reference (no test, no fixture, SeqAn3 itself absent), so the rules are stated
  * here and a maintainer with SeqAn3 at hand can correct them in one place:
  *   (1) the alignment ends at the LAST text column whose bottom-row score is the minimum;
