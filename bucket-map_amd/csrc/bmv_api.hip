@@ -6,21 +6,20 @@
 
 namespace bmv {
 // instantiated in bmv_variants.hip
-extern template __global__ void bmv_align_kernel<1, 5, false>(Job);
-extern template __global__ void bmv_align_kernel<1, 6, false>(Job);
-extern template __global__ void bmv_align_kernel<1, 7, false>(Job);
-extern template __global__ void bmv_align_kernel<1, 8, false>(Job);
-extern template __global__ void bmv_align_kernel<1, 6, true>(Job);
-extern template __global__ void bmv_align_kernel<2, 2, false>(Job);
-extern template __global__ void bmv_align_kernel<2, 3, false>(Job);
-extern template __global__ void bmv_align_kernel<2, 4, false>(Job);
-extern template __global__ void bmv_align_kernel<2, 5, false>(Job);
-extern template __global__ void bmv_align_kernel<4, 2, false>(Job);
-extern template __global__ void bmv_align_kernel<4, 3, false>(Job);
-extern template __global__ void bmv_align_kernel<4, 4, false>(Job);
-extern template __global__ void bmv_align_kernel<8, 2, false>(Job);
-extern template __global__ void bmv_align_kernel<8, 3, false>(Job);
-extern template __global__ void bmv_align_kernel<1, 8, true>(Job);
+extern template __global__ void bmv_align_kernel<4, 5, false>(Job);
+extern template __global__ void bmv_align_kernel<4, 6, false>(Job);
+extern template __global__ void bmv_align_kernel<4, 7, false>(Job);
+extern template __global__ void bmv_align_kernel<4, 8, false>(Job);
+extern template __global__ void bmv_align_kernel<4, 6, true>(Job);
+extern template __global__ void bmv_align_kernel<4, 8, true>(Job);
+extern template __global__ void bmv_align_lane_kernel<1>(Job);
+extern template __global__ void bmv_align_lane_kernel<2>(Job);
+extern template __global__ void bmv_align_lane_kernel<3>(Job);
+extern template __global__ void bmv_align_lane_kernel<4>(Job);
+extern template __global__ void bmv_align_lane_kernel<5>(Job);
+extern template __global__ void bmv_align_lane_kernel<6>(Job);
+extern template __global__ void bmv_align_lane_kernel<7>(Job);
+extern template __global__ void bmv_align_lane_kernel<8>(Job);
 
 // CIGAR entries of one chunk, reversed into reading order at their final offsets.
 __global__ void bmv_gather_kernel(const uint32_t *__restrict__ ops_rev, uint32_t ops_stride,
@@ -136,21 +135,25 @@ Shape pick_shape(uint32_t words, uint32_t max_n) {
     }
     // strips of 64 * CW words, one after the other (max_query_len = 65 536 bases: two of them)
     if (words > kStripsBeyond)
-        return words <= 2u * 64u * 6u ? Shape{64u, 6, bmv::bmv_align_kernel<1, 6, true>, false} : Shape{64u, 8, bmv::bmv_align_kernel<1, 8, true>, false};
-    static const align_fn one_pass[kMaxCw + 1] = {nullptr,
-                                                  bmv::bmv_align_kernel<1, 1, false>, bmv::bmv_align_kernel<1, 2, false>,
-                                                  bmv::bmv_align_kernel<1, 3, false>, bmv::bmv_align_kernel<1, 4, false>,
-                                                  bmv::bmv_align_kernel<1, 5, false>, bmv::bmv_align_kernel<1, 6, false>,
-                                                  bmv::bmv_align_kernel<1, 7, false>, bmv::bmv_align_kernel<1, 8, false>};
+        return words <= 2u * 64u * 6u ? Shape{64u, 6, bmv::bmv_align_kernel<4, 6, true>, false} : Shape{64u, 8, bmv::bmv_align_kernel<4, 8, true>, false};
+    // A group's lanes share the traceback's trace words, 16 / SLOTS lanes to a (word, block) cell and SLOTS columns each:
+    // groups of 4 lanes and more use the SLOTS = 4 kernels (a round of the traceback then recomputes GROUP / 4 cells at
+    // once), groups of 2..3 lanes the SLOTS = 8 ones (CW <= 3), a lone lane SLOTS = 16 (CW = 1; only with BMV_LANE_MAX=0 or
+    // a text window too long for the lane kernel).
+    static const align_fn four_cols[kMaxCw + 1] = {nullptr,
+                                                   bmv::bmv_align_kernel<4, 1, false>, bmv::bmv_align_kernel<4, 2, false>,
+                                                   bmv::bmv_align_kernel<4, 3, false>, bmv::bmv_align_kernel<4, 4, false>,
+                                                   bmv::bmv_align_kernel<4, 5, false>, bmv::bmv_align_kernel<4, 6, false>,
+                                                   bmv::bmv_align_kernel<4, 7, false>, bmv::bmv_align_kernel<4, 8, false>};
+    static const align_fn eight_cols[4] = {nullptr, bmv::bmv_align_kernel<8, 1, false>, bmv::bmv_align_kernel<8, 2, false>,
+                                           bmv::bmv_align_kernel<8, 3, false>};
     int cw = 0;
     double best = 0;
     const char *env = getenv("BMV_CW");                          // experiment / test knob: force CW where it is possible
     const int forced = env ? atoi(env) : 0;
     for (int c = 1; c <= kMaxCw; c++) {
         const uint32_t g = (words + (uint32_t)c - 1u) / (uint32_t)c;
-        // (a group's lanes share the traceback's 16 trace-word pairs: the CW > 1 variants exist for 1 pair per lane, for 2
-        // -- groups of 8..15 lanes, CW <= 5 --, for 4 -- 4..7 lanes, CW <= 4 -- and for 8 -- 2..3 lanes, CW <= 3)
-        const int max_cw = g >= 16u ? kMaxCw : (g >= 8u ? 5 : (g >= 4u ? 4 : (g >= 2u ? 3 : 1)));
+        const int max_cw = g >= 4u ? kMaxCw : (g >= 2u ? 3 : 1);
         if (g > 64u || c > max_cw) continue;
         if (forced == c) {
             cw = c;
@@ -163,18 +166,8 @@ Shape pick_shape(uint32_t words, uint32_t max_n) {
         }
     }
     const uint32_t g = std::max(1u, (words + (uint32_t)cw - 1u) / (uint32_t)cw);
-    static const align_fn two_pairs[6] = {nullptr, nullptr, bmv::bmv_align_kernel<2, 2, false>, bmv::bmv_align_kernel<2, 3, false>,
-                                          bmv::bmv_align_kernel<2, 4, false>, bmv::bmv_align_kernel<2, 5, false>};
-    static const align_fn four_pairs[5] = {nullptr, nullptr, bmv::bmv_align_kernel<4, 2, false>, bmv::bmv_align_kernel<4, 3, false>,
-                                           bmv::bmv_align_kernel<4, 4, false>};
-    static const align_fn eight_pairs[4] = {nullptr, nullptr, bmv::bmv_align_kernel<8, 2, false>, bmv::bmv_align_kernel<8, 3, false>};
-    if (cw > 1 && g < 4) return {g, cw, eight_pairs[cw], false};
-    if (cw > 1 && g < 8) return {g, cw, four_pairs[cw], false};
-    if (cw > 1 && g < 16) return {g, cw, two_pairs[cw], false};
-    if (cw > 1 || g >= 16) return {g, cw, one_pass[cw], false};
-    if (g >= 8) return {g, 1, bmv::bmv_align_kernel<2, 1, false>, false};
-    if (g >= 4) return {g, 1, bmv::bmv_align_kernel<4, 1, false>, false};
-    if (g >= 2) return {g, 1, bmv::bmv_align_kernel<8, 1, false>, false};
+    if (g >= 4) return {g, cw, four_cols[cw], false};
+    if (g >= 2) return {g, cw, eight_cols[cw], false};
     return {g, 1, bmv::bmv_align_kernel<16, 1, false>, false};
 }
 
@@ -409,7 +402,7 @@ int bmv_align(bmv_ctx *c, const uint8_t *reads, uint64_t n_read_bytes, const uin
         pl.n_blocks = (max_n + pl.sh.group + 15u) / 16u + 1u;     // blocks of 16 STEPS: the group's last lane is group - 1 steps behind
         const uint64_t n_entries = (uint64_t)pl.n_blocks * pl.gpw * pl.trace_words;
         pl.trace_stride = n_entries * 2u + (n_entries + 1u) / 2u;               // 64-bit words per wave
-        if (pl.sh.per_lane) pl.trace_stride += 2u * pl.trace_words * 64u;       // ... and the query's bit planes, for the traceback
+        pl.trace_stride += 2u * pl.trace_words * pl.gpw;                        // ... and the query's bit planes, for the traceback
         pl.ops_stride = max_m + max_n + 1u;
         pl.lds_stride = (max_n + 15u) / 16u * 4u + 4u;                          // the text as a 2-bit stream
         if (pl.sh.per_lane) pl.lds_stride = (max_n + 63u) / 64u * 16u + 8u;     // ... as two bit planes, 64 columns at a time

@@ -24,7 +24,7 @@
 // +1: Pv); when neither holds the left one must be.  Writing them for every cell is 16 B per word and column
 // -- 25 KB per 300x307 alignment, 28 MB per 10-kbp alignment -- and the stores, not the arithmetic, set the
 // kernel's time.  So the forward pass keeps only CHECKPOINTS: every kBlock = 16 STEPS the vertical state
-// (Pv, Mv) of each word, and for every step the horizontal delta that leaves each word (2 bits, 16 steps
+// (Pv, Mv) of each word, and for every step the horizontal delta that leaves each word (a +1 bit and a -1 bit, 16 steps
 // per 32-bit word): 1.25 B per word and column.  The traceback walks from the LAST minimum of the bottom row,
 // trying diagonal, up, left in that order (include/bmv.h, tie rules 1-2); when it enters a (word, block)
 // it recomputes that block's 16 steps from the checkpoint -- the horizontal deltas entering
@@ -77,37 +77,39 @@ __device__ __forceinline__ uint64_t shfl64(uint64_t v, int src_lane) {
 
 constexpr uint32_t kBlock = 16;   // columns between checkpoints = horizontal deltas per 32-bit word
 
-// One column step of one 64-row word (Myers 1999 in Hyyro's block form).  eq0: rows that match the text
-// base; hd: the horizontal delta entering the word from above as a 2-bit code (0: 0, 1: +1, 2: -1 -- bit 0 "plus", bit 1
-// "minus": the form the recurrence wants, and the form the trace stores).  Updates (pv, mv) to this column,
-// returns the code of the delta leaving the word; ph / mh are the horizontal deltas of the rows BEFORE the shift (bit r =
-// row r of the word), d0 the rows whose diagonal delta is 0.
-__device__ __forceinline__ uint32_t myers_step(uint64_t eq0, uint32_t hd, uint64_t &pv, uint64_t &mv, uint64_t &ph, uint64_t &mh,
-                                               uint64_t &d0) {
-    const uint64_t h_plus = hd & 1u, h_minus = hd >> 1;
+// One column step of one 64-row word (Myers 1999 in Hyyro's block form).  eq0: rows that match the text base.  The
+// horizontal delta enters and leaves as two WORDS whose bit 31 counts (hpw: +1, hmw: -1): they are simply the high halves of
+// the Ph and Mh of the word above, and the 64-bit shifts take them in through v_alignbit -- a packed 2-bit code cost a shift
+// and two masks per word and step to put together and take apart.  Updates (pv, mv) to this column; ph / mh are the
+// horizontal deltas of the rows BEFORE the shift (bit r = row r of the word), d0 the rows whose diagonal delta is 0.
+__device__ __forceinline__ uint64_t shl1_carry(uint64_t v, uint32_t carry_word) {
+    const uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+    return ((uint64_t)__builtin_amdgcn_alignbit(hi, lo, 31) << 32) | __builtin_amdgcn_alignbit(lo, carry_word, 31);
+}
+
+__device__ __forceinline__ void myers_step_carry(uint64_t eq0, uint32_t &hpw, uint32_t &hmw, uint64_t &pv, uint64_t &mv, uint64_t &ph,
+                                                 uint64_t &mh, uint64_t &d0) {
     const uint64_t xv = eq0 | mv;
-    const uint64_t eq = eq0 | h_minus;
+    const uint64_t eq = eq0 | (hmw >> 31);
     const uint64_t xh = (((eq & pv) + pv) ^ pv) | eq;
     ph = mv | ~(xh | pv);
     mh = pv & xh;
     d0 = xh | mv;
-    const uint32_t hout = (uint32_t)(ph >> 63) | ((uint32_t)(mh >> 63) << 1);
-    const uint64_t phs = (ph << 1) | h_plus;
-    const uint64_t mhs = (mh << 1) | h_minus;
+    const uint64_t phs = shl1_carry(ph, hpw), mhs = shl1_carry(mh, hmw);
+    hpw = (uint32_t)(ph >> 32);
+    hmw = (uint32_t)(mh >> 32);
     pv = mhs | ~(xv | phs);
     mv = phs & xv;
-    return hout;
 }
 
-// The match mask of text base ch (a rank, 0..3) out of the four of a word.  Bit arithmetic on values already in
-// registers: written as a chain of ?: over array elements the compiler merged the loads into one load through a selected
-// POINTER, which kept the masks of the CW >= 2 kernels in scratch memory and put a scratch load, waited for, into every
-// column step of every word.
-__device__ __forceinline__ uint64_t pick_mask(uint64_t p0, uint64_t p1, uint64_t p2, uint64_t p3, uint32_t ch) {
-    const bool odd = (ch & 1u) != 0, high = (ch & 2u) != 0;
-    const uint64_t lo = odd ? p1 : p0, hi = odd ? p3 : p2;
-    return high ? hi : lo;
+// The rows of a word that match a text base: the query is kept as the two bit planes of its ranks (q0: low bit, q1: high
+// bit -- 4 registers per word where four match masks are 8), the base as two all-or-nothing words.  Rows past the query's
+// end compare like any other: nothing below the last row flows back up (carries and shifts go towards higher rows).
+__device__ __forceinline__ uint64_t match_rows(uint64_t q0, uint64_t q1, uint64_t not_t0, uint64_t not_t1) {
+    return (q0 ^ not_t0) & (q1 ^ not_t1);                       // (xnor with the base's bits, the negation paid once per step)
 }
+// the all-or-nothing word of one bit of a text base, negated (for match_rows)
+__device__ __forceinline__ uint64_t not_plane(bool bit) { return bit ? 0ull : ~0ull; }
 
 // SLOTS: trace-word pairs a lane keeps during the traceback (16 / SLOTS lanes of a group hold a block's 16
 // columns; needs group >= 16 / SLOTS).  CW: 64-row words per lane.  STRIPS: queries of more than 64 * CW
@@ -155,8 +157,10 @@ __global__ __launch_bounds__(kWave) void bmv_align_kernel(Job J) {
     uint32_t *hbuf = reinterpret_cast<uint32_t *>(ckpt + (size_t)J.trace_blocks * GPW * TW * 2u);
     // (32-bit: bmv_create's limits keep a wave's entries below 2^23)
     auto entry = [&](uint32_t b, uint32_t w) { return (b * GPW + grp) * TW + w; };
+    // behind the deltas: the bit planes of every query word, [group][word], for the traceback
+    uint64_t *planes = reinterpret_cast<uint64_t *>(hbuf + (((size_t)J.trace_blocks * GPW * TW + 1u) & ~(size_t)1));
 
-    uint64_t peq[4][CW];
+    uint64_t q0[CW], q1[CW];                                    // the bit planes of this lane's query words (match_rows)
     int32_t score = (int32_t)m, best = (int32_t)m;              // tracked by the lane that holds row m
     uint32_t best_j = 0;
     const uint32_t last_word = W ? W - 1u : 0u, last_bit = (m - 1u) & 63u;
@@ -178,36 +182,32 @@ __global__ __launch_bounds__(kWave) void bmv_align_kernel(Job J) {
         const bool live = have && strip < n_strips;
         const uint32_t Ws = live ? (W - w0 < strip_words ? W - w0 : strip_words) : 0u;   // words in this strip
         const uint32_t L = (Ws + CW - 1u) / CW;                 // lanes of the group that hold rows of it
-        // match masks of this lane's words, one per base, straight from the read (rows past the query match nothing)
+        // the two bit planes of this lane's words' ranks, straight from the read (rows past the query's end: rank 0 -- they
+        // compare like any other row, nothing below the last row flows back up)
 #pragma unroll
         for (int c = 0; c < CW; c++) {
-            uint64_t p0 = 0, p1 = 0, p2 = 0, p3 = 0;
+            uint64_t p0 = 0, p1 = 0;
             const uint32_t w = gl * CW + c;
             if (live && w < Ws) {
                 const uint32_t row0 = (w0 + w) * 64u, rows = m - row0 < 64u ? m - row0 : 64u;
                 const uint8_t *q = J.reads + J.query_start[a] + row0;
 #pragma unroll 8
                 for (uint32_t k = 0; k < 64u; k++) {
-                    const uint32_t r = k < rows ? lut[q[k]] : 0xFFu;
-                    const uint64_t bit = 1ull << k;
-                    p0 |= r == 0 ? bit : 0;
-                    p1 |= r == 1 ? bit : 0;
-                    p2 |= r == 2 ? bit : 0;
-                    p3 |= r == 3 ? bit : 0;
+                    const uint64_t r = k < rows ? lut[q[k]] : 0u;
+                    p0 |= (r & 1u) << k;
+                    p1 |= (r >> 1) << k;
                 }
             }
-            peq[0][c] = p0;
-            peq[1][c] = p1;
-            peq[2][c] = p2;
-            peq[3][c] = p3;
+            q0[c] = p0;
+            q1[c] = p1;
         }
         uint64_t pv[CW], mv[CW];
-        uint32_t hacc[CW];                                      // horizontal deltas of the current block, 2 bits each
+        uint32_t hacc_p[CW], hacc_m[CW];                        // deltas leaving each word in this block of steps, the latest in bit 0
 #pragma unroll
         for (int c = 0; c < CW; c++) {
             pv[c] = ~0ull;                                      // column 0: H[i][0] = i
             mv[c] = 0;
-            hacc[c] = 0;
+            hacc_p[c] = hacc_m[c] = 0;
         }
         uint32_t steps = (live && Ws) ? n + L - 1u : 0u;
 #pragma unroll
@@ -215,48 +215,61 @@ __global__ __launch_bounds__(kWave) void bmv_align_kernel(Job J) {
             const uint32_t other = (uint32_t)__shfl_xor((int)steps, o, kWave);
             steps = other > steps ? other : steps;
         }
-        uint32_t hout_prev = 0;
-        uint32_t habove = 0u;                                   // deltas leaving the strip above, 16 at a time
+        uint32_t hp_prev = 0, hm_prev = 0;                      // the deltas that left this lane's last word a step ago, in bit 31
+        uint32_t habove = 0u;                                   // deltas leaving the strip above, 16 steps at a time
         const uint32_t above_lane = GROUP - 1u;                 // the lane that held the strip above's last word (a full strip)
+        const bool holds = live && gl < L;                      // this lane carries words of the strip
         for (uint32_t t = 1; t <= steps; t++) {
-            // the delta that left lane l-1's last row a step ago: a DPP move down the whole wave by one lane (wave_shr:1), a
-            // VALU operation -- __shfl_up is a round trip through the LDS crossbar, waited for at the head of every step
-            uint32_t hin = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hout_prev, 0x138, 0xF, 0xF, false);
+            // what left lane l-1's last row a step ago: DPP moves down the whole wave by one lane (wave_shr:1), VALU
+            // operations -- __shfl_up is a round trip through the LDS crossbar, waited for at the head of every step
+            uint32_t hpw = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hp_prev, 0x138, 0xF, 0xF, false);
+            uint32_t hmw = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hm_prev, 0x138, 0xF, 0xF, false);
             const uint32_t j = t - gl;                          // 1-based text column of this lane
             const uint32_t xt = (t - 1u) % kBlock;              // blocks are cut in TIME: the same for every lane of the wave
-            if (gl < L && j >= 1u && j <= n && t >= gl + 1u) {
+            if (holds && j >= 1u && j <= n && t >= gl + 1u) {
                 const uint32_t ch = (text[(j - 1u) / kBlock] >> (2u * ((j - 1u) % kBlock))) & 3u;
+                const uint64_t nt0 = not_plane((ch & 1u) != 0), nt1 = not_plane((ch & 2u) != 0);
                 if (gl == 0) {
                     // row 0 is all zeros (free leading text gaps); below the first strip the deltas come from
                     // the last word of the strip above, which passed column j at its own step j + above_lane
                     if (STRIPS && strip) {
                         const uint32_t ta = j + above_lane - 1u;
                         if (ta % kBlock == 0u || j == 1u) habove = hbuf[entry(ta / kBlock, w0 - 1u)];
-                        hin = (habove >> (2u * (ta % kBlock))) & 3u;
+                        hpw = habove << (kBlock + ta % kBlock); // step x of a block: +1 in bit 15 - x, -1 in bit 31 - x
+                        hmw = habove << (ta % kBlock);
                     } else {
-                        hin = 0;
+                        hpw = hmw = 0;
                     }
                 }
+                // Every word of the lane, also those past the query's end in its last lane: rows nobody looks at.  The test
+                // is never true (trace_words >= GROUP * CW): a scalar branch between the words keeps the scheduler from
+                // interleaving them, which costs registers and so waves (CW = 8: 161 against 148) for nothing.
 #pragma unroll
                 for (int c = 0; c < CW; c++) {
-                    const uint32_t w = gl * CW + c;
-                    if (w < Ws) {
-                        const uint64_t eq0 = pick_mask(peq[0][c], peq[1][c], peq[2][c], peq[3][c], ch);
-                        uint64_t ph, mh, d0;
-                        const uint32_t hout = myers_step(eq0, hin, pv[c], mv[c], ph, mh, d0);
-                        if ((uint32_t)c == last_c && w0 + w == last_word) {
-                            if (CW > 1) asm volatile("" ::: "memory");   // keeps this a branch: not to be if-converted
-                            score += (int32_t)((ph >> last_bit) & 1ull) - (int32_t)((mh >> last_bit) & 1ull);
-                            if (score <= best) {                // the LAST minimum of the bottom row
-                                best = score;
-                                best_j = j;
-                            }
+                    if ((uint32_t)c >= TW) break;
+                    const uint64_t eq0 = match_rows(q0[c], q1[c], nt0, nt1);
+                    uint64_t ph, mh, d0;
+                    myers_step_carry(eq0, hpw, hmw, pv[c], mv[c], ph, mh, d0);
+                    if ((uint32_t)c == last_c && w0 + gl * CW + (uint32_t)c == last_word) {
+                        if (CW > 1) asm volatile("" ::: "memory");   // keeps this a branch: not to be if-converted
+                        score += (int32_t)((ph >> last_bit) & 1ull) - (int32_t)((mh >> last_bit) & 1ull);
+                        if (score <= best) {                    // the LAST minimum of the bottom row
+                            best = score;
+                            best_j = j;
                         }
-                        hin = hout;
-                        hacc[c] |= hout << (2u * xt);
                     }
+                    hacc_p[c] = __builtin_amdgcn_alignbit(hacc_p[c], hpw, 31);     // (hacc << 1) | bit 31 of the delta word
+                    hacc_m[c] = __builtin_amdgcn_alignbit(hacc_m[c], hmw, 31);
                 }
-                hout_prev = hin;
+                hp_prev = hpw;
+                hm_prev = hmw;
+            } else if (holds) {
+                // a step this lane sits out (the skew's ramps): its place in the block's record stays empty
+#pragma unroll
+                for (int c = 0; c < CW; c++) {
+                    hacc_p[c] <<= 1;
+                    hacc_m[c] <<= 1;
+                }
             }
             // End of a time block -- for the whole wave at once, a branch taken one step in 16 (cut by COLUMN, the lanes of
             // a group, one column apart, reached their block ends one after the other and the wave stored something at every
@@ -266,15 +279,25 @@ __global__ __launch_bounds__(kWave) void bmv_align_kernel(Job J) {
 #pragma unroll
                 for (int c = 0; c < CW; c++) {
                     const uint32_t w = gl * CW + c;
-                    if (gl < L && w < Ws) {
+                    if (holds && w < Ws) {
                         const uint32_t e = entry(bt, w0 + w);
-                        hbuf[e] = hacc[c];
+                        // step x of the block to bit 15 - x (+1) and 31 - x (-1), also in a last block of fewer than 16 steps
+                        hbuf[e] = ((hacc_p[c] << (kBlock - 1u - xt)) & 0xFFFFu) | (hacc_m[c] << (2u * kBlock - 1u - xt));
                         uint64_t *ck = ckpt + (size_t)(e + GPW * TW) * 2u;
                         ck[0] = pv[c];
                         ck[1] = mv[c];
                     }
-                    hacc[c] = 0;
+                    hacc_p[c] = hacc_m[c] = 0;
                 }
+            }
+        }
+        // the planes of this strip's words, for the traceback (which recomputes any word of any strip, on any lane)
+#pragma unroll
+        for (int c = 0; c < CW; c++) {
+            const uint32_t w = gl * CW + c;
+            if (holds && w < Ws) {
+                planes[(size_t)(grp * TW + w0 + w) * 2u] = q0[c];
+                planes[(size_t)(grp * TW + w0 + w) * 2u + 1u] = q1[c];
             }
         }
         // the next strip (and the traceback) read what other lanes of this wave wrote: same wave, same L1,
@@ -292,11 +315,17 @@ __global__ __launch_bounds__(kWave) void bmv_align_kernel(Job J) {
         best_j = n;
     }
 
-    // traceback, the whole group in step; lane 0 of the group writes.  The trace words of the current
-    // (word, column block) live in registers: lane x % kHold of the group keeps column x of the block in slot
-    // x / kHold.
+    // Traceback, the whole group in step; lane 0 of the group writes.  A ROUND recomputes not one (word, block) but as many
+    // as the group has lanes to hold: n_cells = GROUP / kHold cells, kHold = 16 / SLOTS lanes each keeping SLOTS columns
+    // of their cell (lane h of a cell's lanes keeps column x in slot x / kHold if x % kHold == h) -- the cells the walk will
+    // cross if it keeps to the diagonal it stands on.  A refill is the same 16 column steps for every lane, whatever cell it
+    // works on, so a round costs what one cell cost; the walk then goes from cell to cell for as long as the cell it enters is
+    // the one the next lanes hold (an indel near a cell's corner can send it elsewhere: a new round starts there).  A 10-kbp
+    // read crosses ~850 cells: that many rounds of ~900 instructions were a quarter of the kernel.
     constexpr int kSlots = SLOTS;
     constexpr uint32_t kHold = kBlock / SLOTS;
+    const uint32_t n_cells = GROUP / kHold ? GROUP / kHold : 1u;
+    const uint32_t cell = gl / kHold, hold = gl % kHold;        // (lanes past the last whole cell: cell >= n_cells, never asked)
     uint64_t db[kSlots], ub[kSlots];
 #pragma unroll
     for (int q = 0; q < kSlots; q++) db[q] = ub[q] = 0;
@@ -320,37 +349,25 @@ __global__ __launch_bounds__(kWave) void bmv_align_kernel(Job J) {
         }
         if (w) {
             const uint32_t lw = lane_of(w), la = lane_of(w - 1u);
+            // (a record holds step x of its block at bit 15 - x, +1, and 31 - x, -1)
             if (la == lw) {
                 k.hw = hbuf[entry(b, w - 1u)];
             } else if (la + 1u == lw) {                         // entry x of this block = entry x - 1 of the word above's
-                const uint32_t lo = b ? hbuf[entry(b - 1u, w - 1u)] : 0u;
-                k.hw = (hbuf[entry(b, w - 1u)] << 2) | (lo >> 30);
+                const uint32_t before = b ? hbuf[entry(b - 1u, w - 1u)] : 0u;
+                k.hw = ((hbuf[entry(b, w - 1u)] >> 1) & 0x7FFF7FFFu) | ((before & 0x00010001u) << 15);
             } else {                                            // first word of a strip: entry x = entry x + (GROUP - 1) above
                 const uint32_t sh = (GROUP - 1u) % kBlock, q = (GROUP - 1u) / kBlock;
                 const uint32_t lo = hbuf[entry(b + q, w - 1u)], hi = hbuf[entry(b + q + 1u, w - 1u)];
-                k.hw = sh ? (lo >> (2u * sh)) | (hi << (32u - 2u * sh)) : lo;
+                const uint32_t plus = (((lo & 0xFFFFu) << sh) | ((hi & 0xFFFFu) >> (kBlock - sh))) & 0xFFFFu;
+                const uint32_t minus = (((lo >> 16) << sh) | ((hi >> 16) >> (kBlock - sh))) & 0xFFFFu;
+                k.hw = plus | (minus << 16);
             }
         }
         return k;
     };
     auto refill = [&](uint32_t w, uint32_t b, Checkpoint k) {
-        uint64_t pm[4];                                         // the word's match masks
-        if (!STRIPS || n_strips == 1) {                         // ... from the lane that owns the word
-            const uint32_t owner = w / CW, c = w % CW;
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                uint64_t v = 0;                                 // (masks, not ?: -- a select chain over the array becomes a
-#pragma unroll                                                  //  dynamic index, and the array then lives in scratch memory)
-                for (int cc = 0; cc < CW; cc++) v |= peq[r][cc] & (0ull - (uint64_t)(c == (uint32_t)cc));
-                pm[r] = shfl64(v, (int)(lane0 + owner));
-            }
-        } else {                                                // ... rebuilt: the registers hold the last strip only.
-            // Several strips mean the group is the whole wave: lane l looks at query row 64 w + l
-            const uint32_t row = w * 64u + lane;
-            const uint32_t rk = row < m ? lut[J.reads[J.query_start[a] + row]] : 0xFFu;
-#pragma unroll
-            for (int r = 0; r < 4; r++) pm[r] = __ballot(rk == (uint32_t)r);
-        }
+        // the word's bit planes, parked beside the checkpoints by the forward pass
+        const uint64_t pm0 = planes[(size_t)(grp * TW + w) * 2u], pm1 = planes[(size_t)(grp * TW + w) * 2u + 1u];
         // the block's 16 text bases: columns 16 b + 1 - lane_of(w) + x, out of two words of the 2-bit stream
         const int32_t c0 = (int32_t)(b * kBlock) - (int32_t)lane_of(w);          // 0-based column of x = 0 (may be negative)
         const int32_t tq = c0 >> 4;                             // floor
@@ -361,11 +378,11 @@ __global__ __launch_bounds__(kWave) void bmv_align_kernel(Job J) {
         for (int x = 0; x < (int)kBlock; x++) {
             const int32_t col = c0 + 1 + x;                     // 1-based
             if (col >= 1 && col <= (int32_t)n) {
-                const uint32_t ch = (tw >> (2 * x)) & 3u;
-                const uint64_t eq0 = pick_mask(pm[0], pm[1], pm[2], pm[3], ch);
+                const uint64_t eq0 = match_rows(pm0, pm1, not_plane(((tw >> (2 * x)) & 1u) != 0), not_plane(((tw >> (2 * x + 1)) & 1u) != 0));
+                uint32_t hpw = k.hw << (x + (int)kBlock), hmw = k.hw << x;     // the step's bits to bit 31
                 uint64_t ph, mh, d0;
-                myers_step(eq0, (k.hw >> (2 * x)) & 3u, k.pv, k.mv, ph, mh, d0);
-                if (gl == (uint32_t)x % kHold) {
+                myers_step_carry(eq0, hpw, hmw, k.pv, k.mv, ph, mh, d0);
+                if (hold == (uint32_t)x % kHold) {
                     db[x / (int)kHold] = ~(eq0 ^ d0);           // diagonal predecessor valid
                     ub[x / (int)kHold] = k.pv;                  // upper predecessor valid
                 }
@@ -374,92 +391,89 @@ __global__ __launch_bounds__(kWave) void bmv_align_kernel(Job J) {
     };
     uint32_t *ops = J.ops_rev + (size_t)slot * J.ops_stride;
     uint32_t i = m, j = best_j, n_rev = 0, cur_op = 3, cur_len = 0;
-    // Rounds: every group that is still walking recomputes its next (word, block) at the same time -- one
-    // pass through the 16 column steps for the whole wave -- and then walks until it leaves that block.  (A
-    // group refilling on its own would run those steps with the other groups masked off: 64/GROUP times the
-    // instructions.)
-    // The walk mostly runs down the diagonal, so the block it enters next is usually the one to the left in
-    // the same word: that checkpoint is requested while the current block is walked.
-    uint32_t nw = 0xFFFFFFFFu, nb = 0;
-    Checkpoint next{0, 0, 0};
+    auto emit = [&](uint32_t op, uint32_t len) {                // run-length CIGAR, in reverse
+        if (op == cur_op) {
+            cur_len += len;
+        } else {
+            if (cur_len && gl == 0) ops[n_rev] = (cur_len << 4) | cur_op;
+            n_rev += cur_len ? 1u : 0u;
+            cur_op = op;
+            cur_len = len;
+        }
+    };
+    constexpr uint32_t kNoCell = 0xFFFFFFFFu;
     while (__ballot(i > 0) != 0) {
-        uint32_t wc = 0, bc = 0, lc = 0;                        // word, time block of the cell, lane of the word
-        if (i > 0 && j > 0) {
-            wc = (i - 1u) >> 6;
-            lc = lane_of(wc);
-            bc = (j + lc - 1u) / kBlock;
-            refill(wc, bc, (wc == nw && bc == nb) ? next : load_checkpoint(wc, bc));
-            if (bc > 0) {
-                nw = wc;
-                nb = bc - 1u;
-                next = load_checkpoint(nw, nb);
+        // the cells of this round: the one the walk stands in, then the ones its diagonal crosses
+        uint32_t my_w = kNoCell, my_b = 0;
+        {
+            uint32_t ci = i, cj = j;
+            for (uint32_t k = 0; k < n_cells && ci > 0 && cj > 0; k++) {
+                const uint32_t w = (ci - 1u) >> 6, tcol = cj + lane_of(w) - 1u;
+                if (cell == k) {
+                    my_w = w;
+                    my_b = tcol / kBlock;
+                }
+                // diagonal steps until the walk leaves the word, the block of STEPS (which reaches lane_of(w) columns before
+                // the text's first) or the text
+                const uint32_t rows = ((ci - 1u) & 63u) + 1u, cols = tcol % kBlock + 1u;
+                uint32_t s = rows < cols ? rows : cols;
+                s = s < cj ? s : cj;
+                ci -= s;
+                cj -= s;
             }
         }
-        while (i > 0 && (j == 0 || (((i - 1u) >> 6) == wc && (j + lc - 1u) / kBlock == bc))) {
-            uint32_t op;
-            if (j == 0) {                                       // column 0: only the upper predecessor
-                op = 1;
+        if (my_w != kNoCell) refill(my_w, my_b, load_checkpoint(my_w, my_b));
+        // walk, from cell to cell while the prediction holds
+        uint32_t at_cell = 0;
+        uint32_t cell_w = (uint32_t)__shfl((int)my_w, (int)lane0, kWave), cell_b = (uint32_t)__shfl((int)my_b, (int)lane0, kWave);
+        while (i > 0) {
+            if (j == 0) {                                       // column 0: only upper predecessors, all the way
+                emit(1u, i);
+                i = 0;
+                break;
+            }
+            const uint32_t wc = (i - 1u) >> 6, lc = lane_of(wc), tcol = j + lc - 1u, bc = tcol / kBlock;
+            if (wc != cell_w || bc != cell_b) {                 // left the cell: into the next one held, or the round is over
+                if (++at_cell >= n_cells) break;
+                cell_w = (uint32_t)__shfl((int)my_w, (int)(lane0 + at_cell * kHold), kWave);
+                cell_b = (uint32_t)__shfl((int)my_b, (int)(lane0 + at_cell * kHold), kWave);
+                if (wc != cell_w || bc != cell_b) break;
+            }
+            const uint32_t first = lane0 + at_cell * kHold;     // the lanes that hold this cell's columns
+            const uint32_t x = tcol % kBlock, held = x / kHold, bit = (i - 1u) & 63u;
+            // A read mostly runs down the diagonal: how far from this cell?  Every lane looks at the columns it holds, at the
+            // rows the diagonal through (i, j) meets them (same word only: the bit index must stay >= 0); one ballot per slot
+            // gathers the answers into a mask over the block's columns, and the run is the stretch of set bits from column x
+            // downwards.  The whole run is then ONE step of the walk instead of up to sixteen.
+            uint32_t colmask = 0;
+#pragma unroll
+            for (int q = 0; q < kSlots; q++) {
+                const uint32_t xq = (uint32_t)q * kHold + hold;
+                const int32_t at = (int32_t)bit - (int32_t)(x - xq);
+                // (columns before the text's first hold stale words: the refill only writes columns 1 .. n)
+                const bool ok = xq <= x && x - xq < j && at >= 0 && ((db[q] >> (at & 63)) & 1ull) != 0;
+                const uint64_t votes = __ballot(ok);
+                colmask |= (uint32_t)((votes >> first) & ((1ull << kHold) - 1ull)) << ((uint32_t)q * kHold);
+            }
+            const uint32_t gaps = ~colmask & ((2u << x) - 1u);
+            const uint32_t run = gaps ? x - (31u - (uint32_t)__builtin_clz(gaps)) : x + 1u;
+            if (run) {
+                emit(0u, run);
+                i -= run;
+                j -= run;
+                continue;
+            }
+            // the diagonal predecessor is not valid: up, else left
+            uint64_t mu = ub[0];
+#pragma unroll
+            for (int q = 1; q < kSlots; q++) mu = held == (uint32_t)q ? ub[q] : mu;
+            const uint64_t u = shfl64(mu, (int)(first + x % kHold));
+            if ((u >> bit) & 1ull) {
+                emit(1u, 1u);
                 i--;
             } else {
-                const uint32_t x = (j + lc - 1u) % kBlock, held = x / kHold;
-                // A read mostly runs down the diagonal: how far from this cell?  Every lane looks at the columns it holds,
-                // at the rows the diagonal through (i, j) meets them (same word only: the bit index must stay >= 0); one
-                // ballot per slot gathers the answers into a mask over the block's columns, and the run is the stretch of
-                // set bits from column x downwards.  The whole run is then ONE step of the walk instead of up to sixteen.
-                {
-                    uint32_t colmask = 0;
-#pragma unroll
-                    for (int q = 0; q < kSlots; q++) {
-                        const uint32_t xq = (uint32_t)q * kHold + gl;
-                        const int32_t bit = (int32_t)((i - 1u) & 63u) - (int32_t)(x - xq);
-                        // (columns before the text's first hold stale words: the refill only writes columns 1 .. n)
-                        const bool ok = gl < kHold && xq <= x && x - xq < j && bit >= 0 && ((db[q] >> (bit & 63)) & 1ull) != 0;
-                        const uint64_t b = __ballot(ok);
-                        colmask |= (uint32_t)((b >> lane0) & ((1ull << kHold) - 1ull)) << ((uint32_t)q * kHold);
-                    }
-                    const uint32_t upto = (2u << x) - 1u, gaps = ~colmask & upto;
-                    const uint32_t run = gaps ? x - (31u - (uint32_t)__builtin_clz(gaps)) : x + 1u;
-                    if (run) {
-                        i -= run;
-                        j -= run;
-                        if (cur_op == 0) {
-                            cur_len += run;
-                        } else {
-                            if (cur_len && gl == 0) ops[n_rev] = (cur_len << 4) | cur_op;
-                            n_rev += cur_len ? 1u : 0u;
-                            cur_op = 0;
-                            cur_len = run;
-                        }
-                        continue;
-                    }
-                }
-                uint64_t md = db[0], mu = ub[0];
-#pragma unroll
-                for (int q = 1; q < kSlots; q++) {
-                    md = held == (uint32_t)q ? db[q] : md;
-                    mu = held == (uint32_t)q ? ub[q] : mu;
-                }
-                const uint64_t d = shfl64(md, (int)(lane0 + x % kHold)), u = shfl64(mu, (int)(lane0 + x % kHold));
-                const uint32_t bit = (i - 1u) & 63u;
-                if ((d >> bit) & 1ull) {
-                    op = 0;
-                    i--;
-                    j--;
-                } else if ((u >> bit) & 1ull) {
-                    op = 1;
-                    i--;
-                } else {
-                    op = 2;
-                    j--;
-                }
-            }
-            if (op == cur_op) {
-                cur_len++;
-            } else {
-                if (cur_len && gl == 0) ops[n_rev] = (cur_len << 4) | cur_op;
-                n_rev += cur_len ? 1u : 0u;
-                cur_op = op;
-                cur_len = 1;
+                emit(2u, 1u);
+                j--;
             }
         }
     }
@@ -517,38 +531,6 @@ __device__ __forceinline__ uint32_t gather_bit(const uint64_t (&words)[kBlock], 
         out |= ((half >> sh) & 1u) << q;
     }
     return out;
-}
-
-// One column step of one word with the horizontal delta carried as two WORDS whose bit 31 counts (hpw: +1 enters, hmw: -1
-// enters; on return the ones that leave): they are simply the high halves of the Ph and Mh of the word above, and the
-// 64-bit shifts take them in through v_alignbit -- the packed 2-bit code of myers_step costs a shift and two masks per word
-// and step to put together and take apart.
-__device__ __forceinline__ uint64_t shl1_carry(uint64_t v, uint32_t carry_word) {
-    const uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
-    return ((uint64_t)__builtin_amdgcn_alignbit(hi, lo, 31) << 32) | __builtin_amdgcn_alignbit(lo, carry_word, 31);
-}
-
-__device__ __forceinline__ void myers_step_carry(uint64_t eq0, uint32_t &hpw, uint32_t &hmw, uint64_t &pv, uint64_t &mv, uint64_t &ph,
-                                                 uint64_t &mh, uint64_t &d0) {
-    const uint64_t xv = eq0 | mv;
-    const uint64_t eq = eq0 | (hmw >> 31);
-    const uint64_t xh = (((eq & pv) + pv) ^ pv) | eq;
-    ph = mv | ~(xh | pv);
-    mh = pv & xh;
-    d0 = xh | mv;
-    const uint64_t phs = shl1_carry(ph, hpw), mhs = shl1_carry(mh, hmw);
-    hpw = (uint32_t)(ph >> 32);
-    hmw = (uint32_t)(mh >> 32);
-    pv = mhs | ~(xv | phs);
-    mv = phs & xv;
-}
-
-// The rows of a word that match a text base: the query is kept as the two bit planes of its ranks (q0: low bit, q1: high
-// bit -- 4 registers per word where four match masks are 8), the base as two all-or-nothing words.  Rows past the query's
-// end compare like any other: nothing below the last row flows back up (carries and shifts go towards higher rows).
-__device__ __forceinline__ uint64_t match_rows(uint64_t q0, uint64_t q1, bool odd, bool high) {
-    const uint64_t t0 = odd ? ~0ull : 0ull, t1 = high ? ~0ull : 0ull;
-    return ~(q0 ^ t0) & ~(q1 ^ t1);
 }
 
 template <int CW>
@@ -694,12 +676,12 @@ __global__ __launch_bounds__(kWave) void bmv_align_lane_kernel(Job J) {
                 tlo = text[2u * ((t - 1u) >> 5)];
                 thi = text[2u * ((t - 1u) >> 5) + 1u];
             }
-            const bool odd = ((tlo >> x32) & 1u) != 0, high = ((thi >> x32) & 1u) != 0;
+            const uint64_t nt0 = not_plane(((tlo >> x32) & 1u) != 0), nt1 = not_plane(((thi >> x32) & 1u) != 0);
             uint32_t hpw = 0, hmw = 0;                          // row 0 is all zeros: free leading text gaps
 #pragma unroll
             for (int c = 0; c < CW; c++) {
                 if ((uint32_t)c >= wave_words) break;
-                const uint64_t eq0 = match_rows(q0[c], q1[c], odd, high);
+                const uint64_t eq0 = match_rows(q0[c], q1[c], nt0, nt1);
                 uint64_t ph, mh, d0;
                 myers_step_carry(eq0, hpw, hmw, pv[c], mv[c], ph, mh, d0);
                 if ((uint32_t)c == last_word) {
@@ -788,7 +770,7 @@ __global__ __launch_bounds__(kWave) void bmv_align_lane_kernel(Job J) {
 #pragma unroll
             for (int x = 0; x < (int)kBlock; x++) {
                 if (bc * kBlock + 1u + (uint32_t)x <= n) {
-                    const uint64_t eq0 = match_rows(w0, w1, ((lo16 >> x) & 1u) != 0, ((hi16 >> x) & 1u) != 0);
+                    const uint64_t eq0 = match_rows(w0, w1, not_plane(((lo16 >> x) & 1u) != 0), not_plane(((hi16 >> x) & 1u) != 0));
                     uint32_t hpw = hw << (x + (int)kBlock), hmw = hw << x;    // the step's bits to bit 31
                     uint64_t ph, mh, d0;
                     myers_step_carry(eq0, hpw, hmw, kpv, kmv, ph, mh, d0);
