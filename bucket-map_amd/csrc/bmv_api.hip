@@ -10,6 +10,11 @@ extern template __global__ void bmv_align_kernel<4, 5, false>(Job);
 extern template __global__ void bmv_align_kernel<4, 6, false>(Job);
 extern template __global__ void bmv_align_kernel<4, 7, false>(Job);
 extern template __global__ void bmv_align_kernel<4, 8, false>(Job);
+extern template __global__ void bmv_align_kernel<8, 4, false>(Job);
+extern template __global__ void bmv_align_kernel<8, 5, false>(Job);
+extern template __global__ void bmv_align_kernel<8, 6, false>(Job);
+extern template __global__ void bmv_align_kernel<8, 7, false>(Job);
+extern template __global__ void bmv_align_kernel<8, 8, false>(Job);
 extern template __global__ void bmv_align_kernel<4, 6, true>(Job);
 extern template __global__ void bmv_align_kernel<4, 8, true>(Job);
 extern template __global__ void bmv_align_lane_kernel<1>(Job);
@@ -136,24 +141,29 @@ Shape pick_shape(uint32_t words, uint32_t max_n) {
     // strips of 64 * CW words, one after the other (max_query_len = 65 536 bases: two of them)
     if (words > kStripsBeyond)
         return words <= 2u * 64u * 6u ? Shape{64u, 6, bmv::bmv_align_kernel<4, 6, true>, false} : Shape{64u, 8, bmv::bmv_align_kernel<4, 8, true>, false};
-    // A group's lanes share the traceback's trace words, 16 / SLOTS lanes to a (word, block) cell and SLOTS columns each:
-    // groups of 4 lanes and more use the SLOTS = 4 kernels (a round of the traceback then recomputes GROUP / 4 cells at
-    // once), groups of 2..3 lanes the SLOTS = 8 ones (CW <= 3), a lone lane SLOTS = 16 (CW = 1; only with BMV_LANE_MAX=0 or
-    // a text window too long for the lane kernel).
+    // A group's lanes share the traceback's trace words, 16 / SLOTS lanes to a (word, block) cell and SLOTS columns each, and
+    // a round of the traceback recomputes as many cells as the group has lanes for: groups of 8 lanes and more use the
+    // SLOTS = 4 kernels (GROUP / 4 cells), groups of 2..7 lanes the SLOTS = 8 ones (GROUP / 2 cells: 1 kbp as 4 lanes x 4
+    // words 12.7 -> 11.8 ms, 600 bases as 2 x 5 instead of 4 x 3 8.6 -> 6.7 ms), a lone lane SLOTS = 16 (CW = 1; only with
+    // BMV_LANE_MAX=0 or a text window too long for the lane kernel).
+    const uint32_t kEightBelow = getenv("BMV_EIGHT_BELOW") ? (uint32_t)atoi(getenv("BMV_EIGHT_BELOW")) : 8u;   // (experiment)
     static const align_fn four_cols[kMaxCw + 1] = {nullptr,
                                                    bmv::bmv_align_kernel<4, 1, false>, bmv::bmv_align_kernel<4, 2, false>,
                                                    bmv::bmv_align_kernel<4, 3, false>, bmv::bmv_align_kernel<4, 4, false>,
                                                    bmv::bmv_align_kernel<4, 5, false>, bmv::bmv_align_kernel<4, 6, false>,
                                                    bmv::bmv_align_kernel<4, 7, false>, bmv::bmv_align_kernel<4, 8, false>};
-    static const align_fn eight_cols[4] = {nullptr, bmv::bmv_align_kernel<8, 1, false>, bmv::bmv_align_kernel<8, 2, false>,
-                                           bmv::bmv_align_kernel<8, 3, false>};
+    static const align_fn eight_cols[kMaxCw + 1] = {nullptr,
+                                                    bmv::bmv_align_kernel<8, 1, false>, bmv::bmv_align_kernel<8, 2, false>,
+                                                    bmv::bmv_align_kernel<8, 3, false>, bmv::bmv_align_kernel<8, 4, false>,
+                                                    bmv::bmv_align_kernel<8, 5, false>, bmv::bmv_align_kernel<8, 6, false>,
+                                                    bmv::bmv_align_kernel<8, 7, false>, bmv::bmv_align_kernel<8, 8, false>};
     int cw = 0;
     double best = 0;
     const char *env = getenv("BMV_CW");                          // experiment / test knob: force CW where it is possible
     const int forced = env ? atoi(env) : 0;
     for (int c = 1; c <= kMaxCw; c++) {
         const uint32_t g = (words + (uint32_t)c - 1u) / (uint32_t)c;
-        const int max_cw = g >= 4u ? kMaxCw : (g >= 2u ? 3 : 1);
+        const int max_cw = g >= 2u ? kMaxCw : 1;
         if (g > 64u || c > max_cw) continue;
         if (forced == c) {
             cw = c;
@@ -166,7 +176,7 @@ Shape pick_shape(uint32_t words, uint32_t max_n) {
         }
     }
     const uint32_t g = std::max(1u, (words + (uint32_t)cw - 1u) / (uint32_t)cw);
-    if (g >= 4) return {g, cw, four_cols[cw], false};
+    if (g >= kEightBelow) return {g, cw, four_cols[cw], false};
     if (g >= 2) return {g, cw, eight_cols[cw], false};
     return {g, 1, bmv::bmv_align_kernel<16, 1, false>, false};
 }

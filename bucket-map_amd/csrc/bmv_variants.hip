@@ -9,6 +9,12 @@ template __global__ void bmv_align_kernel<4, 5, false>(Job);
 template __global__ void bmv_align_kernel<4, 6, false>(Job);
 template __global__ void bmv_align_kernel<4, 7, false>(Job);
 template __global__ void bmv_align_kernel<4, 8, false>(Job);
+// groups of 2..7 lanes: eight columns per lane (two lanes to a cell)
+template __global__ void bmv_align_kernel<8, 4, false>(Job);
+template __global__ void bmv_align_kernel<8, 5, false>(Job);
+template __global__ void bmv_align_kernel<8, 6, false>(Job);
+template __global__ void bmv_align_kernel<8, 7, false>(Job);
+template __global__ void bmv_align_kernel<8, 8, false>(Job);
 // ... the whole wave, queries in strips
 template __global__ void bmv_align_kernel<4, 6, true>(Job);
 template __global__ void bmv_align_kernel<4, 8, true>(Job);
