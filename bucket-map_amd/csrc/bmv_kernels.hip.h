@@ -11,10 +11,11 @@
 // are skewed along the text: at step t lane l works on column t-l and takes the horizontal delta that
 // leaves lane l-1's last row (computed one step earlier) through a DPP move.  A group is exactly as many lanes
 // as the longest query of the batch has words over CW (any size, not a power of two: lanes are addressed explicitly),
-// so a wave verifies 64/G candidates at once: 32 for 300-bp reads (2 lanes x 3 words), 4 for 5-kbp reads (16 x 5),
-// 2 for 10-kbp reads (32 x 5).  The host picks CW (bmv_api.hip, pick_shape): what a step pays once -- the neighbour's
-// delta, the text base, the loop -- is worth about two words' recurrences, so more words per lane and more
-// alignments per wave win until the registers (13 per word) cost waves per SIMD.
+// so a wave verifies 64/G candidates at once: 32 for 1-kbp reads (2 lanes x 8 words), 4 for 5-kbp reads (16 x 5),
+// 2 for 10-kbp reads (32 x 5); queries of up to 512 bases go one per LANE (bmv_align_lane_kernel, below).  The host picks
+// CW (bmv_api.hip, pick_shape): what a step pays once -- the neighbour's delta, the text base, the loop -- is worth about
+// two words' recurrences, so more words per lane and more alignments per wave win until the registers (10 per word) cost
+// waves per SIMD.
 // A query of more than 512 words (32 768 bases) is processed in STRIPS of 64 * CW words, one
 // after the other over the whole text: the horizontal deltas entering a strip's first word are the stored
 // ones that left the last word of the strip above.
@@ -26,10 +27,12 @@
 // kernel's time.  So the forward pass keeps only CHECKPOINTS: every kBlock = 16 STEPS the vertical state
 // (Pv, Mv) of each word, and for every step the horizontal delta that leaves each word (a +1 bit and a -1 bit, 16 steps
 // per 32-bit word): 1.25 B per word and column.  The traceback walks from the LAST minimum of the bottom row,
-// trying diagonal, up, left in that order (include/bmv.h, tie rules 1-2); when it enters a (word, block)
+// trying diagonal, up, left in that order (include/bmv.h, tie rules 1-2); when it enters a (word, block) CELL
 // it recomputes that block's 16 steps from the checkpoint -- the horizontal deltas entering
-// the word are the stored ones of the word above, so one word is recomputed on its own -- and the lanes of
-// the group keep the 16 pairs of trace words in registers.  Blocks are cut in TIME, not by column: lane l is at column
+// the word are the stored ones of the word above, so one word is recomputed on its own -- and 16 / SLOTS lanes of
+// the group keep the cell's 16 pairs of trace words in registers, SLOTS each; the group's other lanes do the same for the
+// cells the walk will reach next if it keeps to its diagonal, so one round of recomputation serves GROUP * SLOTS / 16 cells.
+// Blocks are cut in TIME, not by column: lane l is at column
 // t - l, so a block of a word on lane l is the 16 columns 16 b + 1 - l ..; every lane of the wave ends its block at the
 // same step and the wave stores once in 16 steps (cut by column, a few lanes of every group reached a block end at
 // every step, and the wave ran the store path at every step).  The deltas of the word above for a block's columns are
@@ -111,9 +114,9 @@ __device__ __forceinline__ uint64_t match_rows(uint64_t q0, uint64_t q1, uint64_
 // the all-or-nothing word of one bit of a text base, negated (for match_rows)
 __device__ __forceinline__ uint64_t not_plane(bool bit) { return bit ? 0ull : ~0ull; }
 
-// SLOTS: trace-word pairs a lane keeps during the traceback (16 / SLOTS lanes of a group hold a block's 16
-// columns; needs group >= 16 / SLOTS).  CW: 64-row words per lane.  STRIPS: queries of more than 64 * CW
-// words are allowed (the group is then the whole wave).
+// SLOTS: trace-word pairs a lane keeps during the traceback (16 / SLOTS lanes of a group hold a cell's 16 columns, and the
+// group holds GROUP * SLOTS / 16 cells at a time; needs group >= 16 / SLOTS).  CW: 64-row words per lane.  STRIPS: queries of
+// more than 64 * CW words are allowed (the group is then the whole wave).
 template <int SLOTS, int CW, bool STRIPS>
 __global__ __launch_bounds__(kWave) void bmv_align_kernel(Job J) {
     extern __shared__ uint8_t lds_text[];
