@@ -23,7 +23,7 @@ CSRC = $(PKG)/csrc
 $(CSRC)/%.o: $(CSRC)/%.hip $(wildcard $(CSRC)/*.h) include/bmf.h include/bml.h include/bmv.h
 	$(HIPCC) $(HIPFLAGS) -Wno-unused-result -c -o $@ $<
 
-$(PKG)/libbmf.so: $(CSRC)/bmf_api.o $(CSRC)/bml_api.o $(CSRC)/bmv_api.o $(CSRC)/bmv_variants.o
+$(PKG)/libbmf.so: $(CSRC)/bmf_api.o $(CSRC)/bml_api.o $(CSRC)/bmv_api.o $(CSRC)/bmv_variants.o $(CSRC)/bmv_variants2.o $(CSRC)/bmv_variants3.o
 	$(HIPCC) --offload-arch=$(ARCH) -shared -o $@ $^
 
 $(PKG)/libbmhost.so: $(HOST)/bm_host_api.cpp $(HOST_HDRS)
