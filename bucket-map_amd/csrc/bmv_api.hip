@@ -146,7 +146,8 @@ Shape pick_shape(uint32_t words, uint32_t max_n) {
     // SLOTS = 4 kernels (GROUP / 4 cells), groups of 2..7 lanes the SLOTS = 8 ones (GROUP / 2 cells: 1 kbp as 4 lanes x 4
     // words 12.7 -> 11.8 ms, 600 bases as 2 x 5 instead of 4 x 3 8.6 -> 6.7 ms), a lone lane SLOTS = 16 (CW = 1; only with
     // BMV_LANE_MAX=0 or a text window too long for the lane kernel).
-    const uint32_t kEightBelow = getenv("BMV_EIGHT_BELOW") ? (uint32_t)atoi(getenv("BMV_EIGHT_BELOW")) : 8u;   // (experiment)
+    // (experiment knob; never below 4: a cell of the SLOTS = 4 kernels needs four lanes)
+    const uint32_t kEightBelow = getenv("BMV_EIGHT_BELOW") ? std::max(4u, (uint32_t)atoi(getenv("BMV_EIGHT_BELOW"))) : 8u;
     static const align_fn four_cols[kMaxCw + 1] = {nullptr,
                                                    bmv::bmv_align_kernel<4, 1, false>, bmv::bmv_align_kernel<4, 2, false>,
                                                    bmv::bmv_align_kernel<4, 3, false>, bmv::bmv_align_kernel<4, 4, false>,
