@@ -366,7 +366,7 @@ int bml_locate(bml_ctx *c, const uint32_t *sample_hash, const uint16_t *sample_p
             // as many workgroups as the CUs hold at once (LDS decides: 1 per CU at 262 144-base buckets, 3 at 65 536)
             const uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(8, (size_t)(156 * 1024) / (lds + 1024)));
             const unsigned grid = (unsigned)std::min<uint32_t>(n_heavy, per_cu * (uint32_t)c->n_cu);
-            HIP_TRY(c->heavy_votes.need((size_t)grid * range));
+            HIP_TRY(c->heavy_votes.need((size_t)grid * 2 * range));
             if (!in_lds) HIP_TRY(c->heavy_bitmaps.need((size_t)grid * 3 * words));
             // candidates whose occurrences do not fit the kernel's LDS copy group them by sample in a second buffer
             if (heavy_info[1] > bml::kHeavyLdsOcc) HIP_TRY(c->occ_b.need((size_t)n_occ));

@@ -319,7 +319,7 @@ __global__ __launch_bounds__(kLightThreads) void bml_replay_light_kernel(
 constexpr uint32_t kHeavyLdsOcc = 6144;          // occurrences of one candidate kept in LDS (24 KB)
 
 struct HeavyScratch {
-    uint32_t *votes;        // per workgroup: range entries
+    uint32_t *votes;        // per workgroup: 2 x range entries (the proposals' start positions, then their votes)
     uint32_t *bitmaps;      // per workgroup: 3 x words (used when the bitmaps do not fit LDS)
     uint64_t *by_sample;    // candidates with more than kHeavyLdsOcc occurrences: theirs grouped by sample, same layout as
                             // the occurrence buffer (null when no candidate is that large)
@@ -338,31 +338,42 @@ __global__ __launch_bounds__(kThreads) void bml_replay_heavy_kernel(
     const uint32_t tid = threadIdx.x, words = (range + 31u) / 32u;
     uint32_t *locc = heavy_lds;                  // a candidate's occurrences grouped by sample (kHeavyLdsOcc of them fit)
     uint32_t *exists = lds_bitmaps ? heavy_lds + kHeavyLdsOcc : S.bitmaps + (size_t)blockIdx.x * 3u * words;
-    uint32_t *fresh = exists + words, *fnew = fresh + words;
-    uint32_t *votes = S.votes + (size_t)blockIdx.x * range;
+    uint32_t *fresh = exists + words, *starts = fresh + words;
+    // the proposals, in the order they were made: start position and votes (at most one per start position)
+    uint32_t *prop_pos = S.votes + (size_t)blockIdx.x * 2u * range, *prop_votes = prop_pos + range;
     const int32_t d = P.allowed_indel;
     const uint32_t total = *n_heavy;
     // The bitmaps are all zero between candidates: a candidate only ever sets bits at the start positions of its own
     // occurrences, and clears exactly those words when it is done -- per candidate the work is O(occurrences), not O(range).
     for (uint32_t i = tid; i < 3u * words; i += kThreads) exists[i] = 0;
     __syncthreads();
-    // any bit of bm set in [lo, hi] (inclusive, clamped to the range)?  op(pos) for every set bit.
-    auto for_bits = [&](const uint32_t *bm, int64_t lo, int64_t hi, auto op) {
+    // bm's words over [lo, hi] (inclusive, clamped to the range), masked to it: fn(bits) for each; false stops the walk
+    auto over_bits = [&](const uint32_t *bm, int64_t lo, int64_t hi, auto fn) {
         if (lo < 0) lo = 0;
         if (hi >= (int64_t)range) hi = (int64_t)range - 1;
-        if (lo > hi) return false;
-        bool any = false;
+        if (lo > hi) return;
         for (uint32_t wd = (uint32_t)lo >> 5; wd <= ((uint32_t)hi >> 5); wd++) {
             uint32_t bits = bm[wd];
             if (wd == ((uint32_t)lo >> 5)) bits &= 0xFFFFFFFFu << ((uint32_t)lo & 31u);
             if (wd == ((uint32_t)hi >> 5)) bits &= 0xFFFFFFFFu >> (31u - ((uint32_t)hi & 31u));
-            while (bits) {
-                any = true;
-                op(wd * 32u + (uint32_t)__builtin_ctz(bits));
-                bits &= bits - 1u;
-            }
+            if (!fn(bits)) return;
         }
+    };
+    auto any_bit = [&](const uint32_t *bm, int64_t lo, int64_t hi) {
+        bool any = false;
+        over_bits(bm, lo, hi, [&](uint32_t bits) {
+            any = bits != 0;
+            return !any;
+        });
         return any;
+    };
+    auto count_bits = [&](const uint32_t *bm, int64_t lo, int64_t hi) {
+        uint32_t count = 0;
+        over_bits(bm, lo, hi, [&](uint32_t bits) {
+            count += (uint32_t)__builtin_popcount(bits);
+            return true;
+        });
+        return count;
     };
     // candidates are handed out one at a time (their costs differ a hundredfold): n_heavy[2] is the queue's head
     for (;;) {
@@ -407,15 +418,17 @@ __global__ __launch_bounds__(kThreads) void bml_replay_heavy_kernel(
             // every step below walks the sample's occurrences again: from the LDS copy when the candidate's fit there
             auto for_each_pos = [&](auto fn) {
                 if (in_lds)
-                    for (uint32_t o = o0 + tid; o < o1; o += kThreads) fn(start_of(locc[o]));
+                    for (uint32_t o = o0 + tid; o < o1; o += kThreads) fn(start_of(locc[o]), o - o0);
                 else
-                    for (uint32_t o = o0 + tid; o < o1; o += kThreads) fn(start_of(0x7FFFFFFFu - (uint32_t)mine[o]));
+                    for (uint32_t o = o0 + tid; o < o1; o += kThreads) fn(start_of(0x7FFFFFFFu - (uint32_t)mine[o]), o - o0);
             };
-            if (s_np == 0) {                                         // :247-251 the map was empty: every start goes in
+            const uint32_t np = s_np;                                // proposals before this sample (uniform)
+            if (np == 0) {                                           // :247-251 the map was empty: every start goes in
                 __syncthreads();
-                for_each_pos([&](uint32_t pos) {
+                for_each_pos([&](uint32_t pos, uint32_t nth) {
                     atomicOr(&exists[pos >> 5], 1u << (pos & 31u));
-                    votes[pos] = 1;
+                    prop_pos[nth] = pos;
+                    prop_votes[nth] = 1;
                 });
                 if (tid == 0) s_np = o1 - o0;
                 __syncthreads();
@@ -427,10 +440,10 @@ __global__ __launch_bounds__(kThreads) void bml_replay_heavy_kernel(
                 s_fmin = 0xFFFFFFFFu;
             }
             __syncthreads();
-            // 1. votes for the proposals that were there before this sample
-            for_each_pos([&](uint32_t pos) {
-                const bool hit = for_bits(exists, (int64_t)pos - d, (int64_t)pos + d, [&](uint32_t at) { atomicAdd(&votes[at], 1u); });
-                if (!hit) {
+            // 1. the sample's starts as a bitmap; a start with no proposal within +-indel is marked in `fresh`
+            for_each_pos([&](uint32_t pos, uint32_t) {
+                atomicOr(&starts[pos >> 5], 1u << (pos & 31u));
+                if (!any_bit(exists, (int64_t)pos - d, (int64_t)pos + d)) {
                     atomicOr(&fresh[pos >> 5], 1u << (pos & 31u));
                     atomicAdd(&s_fresh, 1u);
                     atomicMax(&s_fmax, pos);
@@ -438,9 +451,15 @@ __global__ __launch_bounds__(kThreads) void bml_replay_heavy_kernel(
                 }
             });
             __syncthreads();
-            if (s_fresh == 0) continue;
-            // 2. new proposals among the fresh starts, highest first (one wave)
-            if (tid < 64) {
+            // 2. votes for the proposals that were there before this sample: each counts the starts within +-indel of it
+            //    (a thread per proposal and a population count -- not an atomic add per (occurrence, proposal) pair)
+            for (uint32_t q = tid; q < np; q += kThreads) {
+                const uint32_t at = prop_pos[q];
+                const uint32_t got = count_bits(starts, (int64_t)at - d, (int64_t)at + d);
+                if (got) prop_votes[q] += got;
+            }
+            // 3. new proposals among the fresh starts, highest first (one wave)
+            if (s_fresh != 0 && tid < 64) {
                 int64_t limit = (int64_t)s_fmax;                     // the next proposal lies at or below `limit`
                 const int64_t lowest = (int64_t)s_fmin;
                 uint32_t made = 0;
@@ -457,49 +476,36 @@ __global__ __launch_bounds__(kThreads) void bml_replay_heavy_kernel(
                     const int src = __builtin_ctzll(m);
                     const uint32_t hb = 31u - (uint32_t)__builtin_clz((uint32_t)__shfl((int)bits, src, 64));
                     const uint32_t pos = (uint32_t)(top - src) * 32u + hb;
-                    if (tid == 0) {
-                        fnew[pos >> 5] |= 1u << (pos & 31u);
-                        votes[pos] = 1;
-                    }
+                    if (tid == 0) prop_pos[np + made] = pos;
                     made++;
                     limit = (int64_t)pos - d - 1;                    // nothing within indel below a new proposal
                 }
                 if (tid == 0) s_new = made;
             }
             __syncthreads();
-            // 3. votes for the new proposal within indel above an occurrence
-            for_each_pos([&](uint32_t pos) {
-                (void)for_bits(fnew, (int64_t)pos + 1, (int64_t)pos + d, [&](uint32_t at) { atomicAdd(&votes[at], 1u); });
-            });
+            // 4. a new proposal starts with its own vote and gets one from every start within indel BELOW it (those were
+            //    processed after it was inserted; new proposals are more than indel apart, so a start votes for one at most);
+            //    it joins the map
+            for (uint32_t q = np + tid; q < np + s_new; q += kThreads) {
+                const uint32_t at = prop_pos[q];
+                prop_votes[q] = 1u + count_bits(starts, (int64_t)at - d, (int64_t)at - 1);
+                atomicOr(&exists[at >> 5], 1u << (at & 31u));
+            }
             __syncthreads();
-            // 4. the new proposals join the map (they sit at start positions of this sample's occurrences: those words only)
-            for_each_pos([&](uint32_t pos) {
-                const uint32_t nw = fnew[pos >> 5];
-                if (nw) atomicOr(&exists[pos >> 5], nw);
-            });
-            __syncthreads();
-            for_each_pos([&](uint32_t pos) {
+            for_each_pos([&](uint32_t pos, uint32_t) {               // (this sample's words only)
+                starts[pos >> 5] = 0;
                 fresh[pos >> 5] = 0;
-                fnew[pos >> 5] = 0;
             });
-            if (tid == 0) s_np += s_new;
+            if (tid == 0) s_np = np + s_new;
             __syncthreads();
         }
-        // winner: most votes, ties -> smallest start.  Every proposal sits at the start position of some occurrence.
+        // winner: most votes, ties -> smallest start (:281-283)
         if (tid == 0) s_best = 0;
         __syncthreads();
         unsigned long long best = 0;
-        for (uint32_t i = 0; i < P.p; i++) {
-            uint32_t idx = sample_pos[(size_t)w * P.p + (rc ? P.p - 1u - i : i)];
-            if (rc) idx = length - P.k - idx;
-            for (uint32_t o = s_hist[i] + tid; o < s_hist[i + 1]; o += kThreads) {
-                const uint32_t occ = in_lds ? locc[o] : 0x7FFFFFFFu - (uint32_t)mine[o];
-                const uint32_t pos = (uint32_t)((int32_t)(occ - idx) + (int32_t)bias);
-                if ((exists[pos >> 5] >> (pos & 31u)) & 1u) {
-                    const unsigned long long cand = ((unsigned long long)votes[pos] << 32) | (0xFFFFFFFFu - pos);
-                    best = cand > best ? cand : best;
-                }
-            }
+        for (uint32_t q = tid; q < s_np; q += kThreads) {
+            const unsigned long long cand = ((unsigned long long)prop_votes[q] << 32) | (0xFFFFFFFFu - prop_pos[q]);
+            best = cand > best ? cand : best;
         }
         atomicMax(&s_best, best);
         __syncthreads();
@@ -517,15 +523,7 @@ __global__ __launch_bounds__(kThreads) void bml_replay_heavy_kernel(
             out_offset[pair] = off;
             out_votes[pair] = nv;
         }
-        __syncthreads();
-        for (uint32_t i = 0; i < P.p; i++) {                       // leave the map empty for the next candidate
-            uint32_t idx = sample_pos[(size_t)w * P.p + (rc ? P.p - 1u - i : i)];
-            if (rc) idx = length - P.k - idx;
-            for (uint32_t o = s_hist[i] + tid; o < s_hist[i + 1]; o += kThreads) {
-                const uint32_t occ = in_lds ? locc[o] : 0x7FFFFFFFu - (uint32_t)mine[o];
-                exists[((uint32_t)((int32_t)(occ - idx) + (int32_t)bias)) >> 5] = 0;
-            }
-        }
+        for (uint32_t q = tid; q < s_np; q += kThreads) exists[prop_pos[q] >> 5] = 0;   // leave the map empty for the next candidate
         __syncthreads();
     }
 }
