@@ -80,6 +80,7 @@ struct bml_ctx {
     DevBuf<uint64_t> bucket_start, occ_a, occ_b, cand_start;
     DevBuf<uint32_t> bucket_len, sample_hash, seg_len, pair_window, out_votes;
     DevBuf<uint32_t> cand_count, heavy, n_heavy, heavy_votes, heavy_bitmaps;
+    double occ_per_pair = 0;                     // k-mer occurrences per candidate the batches so far needed (sizes the next buffer)
     int n_cu = 256;
     uint32_t last_heavy = 0;
     DevBuf<uint16_t> sample_pos;
@@ -315,13 +316,14 @@ int bml_locate(bml_ctx *c, const uint32_t *sample_hash, const uint16_t *sample_p
     c->last_occ = 0;
     c->last_heavy = 0;
 
-    auto scan = [&](size_t chunk_lo, size_t chunk_hi, unsigned long long cap, unsigned long long *n_occ) -> int {
+    // placed: the candidates' segments are where the scan before this one put them (it found the buffer too small): only write
+    auto scan = [&](size_t chunk_lo, size_t chunk_hi, unsigned long long cap, unsigned long long *n_occ, bool placed = false) -> int {
         HIP_TRY(c->occ_a.need((size_t)cap));
-        HIP_TRY(hipMemsetAsync(c->occ_count.p, 0, sizeof(unsigned long long), c->stream));
+        if (!placed) HIP_TRY(hipMemsetAsync(c->occ_count.p, 0, sizeof(unsigned long long), c->stream));
         HIP_TRY(hipEventRecord(c->ev[0], c->stream));
         hipLaunchKernelGGL(bml::bml_scan_kernel, dim3((unsigned)(chunk_hi - chunk_lo)), dim3(bml::kScanThreads), c->scan_lds, c->stream,
                            c->lp, c->genome.p, c->bucket_start.p, c->bucket_len.p, c->lut.p, c->chunks.p + chunk_lo, c->sample_hash.p,
-                           c->pair_window.p, c->pair_rc.p, c->occ_a.p, c->occ_count.p, cap, c->cand_start.p, c->cand_count.p);
+                           c->pair_window.p, c->pair_rc.p, c->occ_a.p, c->occ_count.p, cap, c->cand_start.p, c->cand_count.p, placed ? 1u : 0u);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(c->ev[1], c->stream));
         HIP_TRY(hipMemcpyAsync(n_occ, c->occ_count.p, sizeof *n_occ, hipMemcpyDeviceToHost, c->stream));
@@ -389,14 +391,20 @@ int bml_locate(bml_ctx *c, const uint32_t *sample_hash, const uint16_t *sample_p
         return BML_OK;
     };
 
-    unsigned long long cap = std::min<unsigned long long>(std::max<unsigned long long>(1ull << 20, 2ull * n_pairs * p), budget);
+    // The buffer's first size: two occurrences per sample asked for -- or what the context's previous batches needed per
+    // candidate, a quarter more (a genome's repeats show in every batch; a buffer found too small costs a second scan).
+    unsigned long long cap = std::max<unsigned long long>(1ull << 20, 2ull * n_pairs * p);
+    cap = std::max<unsigned long long>(cap, (unsigned long long)(c->occ_per_pair * 1.25 * (double)n_pairs));
+    if (const char *env = getenv("BML_FIRST_OCC")) cap = std::max<unsigned long long>(1, strtoull(env, nullptr, 10));   // (tests: force the second scan)
+    cap = std::min(cap, budget);
     unsigned long long n_occ = 0;
     if (int rc = scan(0, chunks.size(), cap, &n_occ)) return rc;
     c->last_occ = n_occ;
+    c->occ_per_pair = std::max(0.5 * c->occ_per_pair, (double)n_occ / (double)std::max<uint32_t>(n_pairs, 1u));
     if (n_occ > cap && n_occ <= budget) {                       // too small, but one buffer will do: grow it and scan again
         cap = n_occ;
-        if (int rc = scan(0, chunks.size(), cap, &n_occ)) return rc;
-        if (n_occ > cap) return fail(BML_ERR_HIP, "occurrence buffer still too small after re-scan");
+        if (int rc = scan(0, chunks.size(), cap, &n_occ, true)) return rc;
+        if (n_occ != cap) return fail(BML_ERR_HIP, "the occurrence count changed between the scans");
     }
     if (n_occ <= cap) {
         if (int rc = replay(0, n_pairs, n_occ)) return rc;

@@ -81,7 +81,7 @@ __global__ __launch_bounds__(kScanThreads) void bml_scan_kernel(
     const uint32_t *__restrict__ bucket_len, const uint8_t *__restrict__ dna4_lut, const Chunk *__restrict__ chunks,
     const uint32_t *__restrict__ sample_hash, const uint32_t *__restrict__ pair_window,
     const uint8_t *__restrict__ pair_rc, uint64_t *__restrict__ occ_keys, unsigned long long *__restrict__ occ_count,
-    unsigned long long occ_cap, uint64_t *__restrict__ cand_start, uint32_t *__restrict__ cand_count) {
+    unsigned long long occ_cap, uint64_t *__restrict__ cand_start, uint32_t *__restrict__ cand_count, uint32_t placed) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint64_t *locc = reinterpret_cast<uint64_t *>(smem);
     unsigned long long &gbase = *reinterpret_cast<unsigned long long *>(locc + kLdsOcc);
@@ -158,6 +158,18 @@ __global__ __launch_bounds__(kScanThreads) void bml_scan_kernel(
     auto key_of = [&](uint32_t t, uint32_t j) {                             // (target, offset descending)
         return ((uint64_t)((ch.pair_begin + t / P.p) * P.p + t % P.p) << 32) | (uint32_t)(0x7FFFFFFFu - j);
     };
+    if (placed) {
+        // A scan before this one has counted the candidates' occurrences and placed their segments (cand_start, cand_count),
+        // but the buffer was too small to take them: this one only writes -- one pass over the bucket, no counting.
+        const uint64_t base = cand_start[ch.pair_begin];
+        for (uint32_t c = tid; c < ch.pair_count; c += kScanThreads) pcnt[c] = (uint32_t)(cand_start[ch.pair_begin + c] - base);
+        __syncthreads();
+        scan_bucket([&](uint32_t t, uint32_t j) {
+            const uint32_t c = t / P.p;
+            occ_keys[base + pcnt[c] + atomicAdd(&pfill[c], 1u)] = key_of(t, j);
+        });
+        return;
+    }
     scan_bucket([&](uint32_t t, uint32_t j) {
         atomicAdd(&pcnt[t / P.p], 1u);
         const uint32_t at_l = atomicAdd(&lds_cnt, 1u);

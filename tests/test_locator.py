@@ -178,6 +178,21 @@ def test_gpu_scan_in_groups_within_an_occurrence_budget(budget, monkeypatch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("first", [1, 5000])
+def test_gpu_scan_again_when_the_first_buffer_was_too_small(first, monkeypatch):
+    """The first scan runs with room for two occurrences per sample; when repeats bring more it has still counted every
+    candidate's and placed their segments, and the second scan only writes them (BML_FIRST_OCC: the first buffer's size)."""
+    rng = np.random.default_rng(777)
+    case = make_case(rng, n_buckets=5, bucket_len=8192, read_len=150, n_reads=300, motif=53)
+    o_ref, v_ref = oracle(case)
+    monkeypatch.setenv("BML_FIRST_OCC", str(first))
+    o_got, v_got, st = gpu_scan(case)
+    assert st["occurrences"] > first
+    assert np.array_equal(o_ref, o_got) and np.array_equal(v_ref, v_got)
+    assert st["heavy_candidates"] > 0
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("bucket_len,read_len,indel", [(262144, 300, 30), (300000, 40000, 700)])
 def test_gpu_scan_heavy_candidates_at_long_read_geometry(bucket_len, read_len, indel):
     """BASELINE configs[4]'s bucket length with satellite-like content: a 171-base monomer fills the bucket, every sampled
