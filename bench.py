@@ -303,6 +303,32 @@ def large_index_leg(args, device, k2i, threads, log):
     return leg
 
 
+def verifier_leg(log):
+    """The alignment verifier (include/bmv.h) beside the headline: tools/bench_verify.py in a process of
+    its own, on the short-read and the long-read shape DESIGN.md 4.4 quotes.  No oracle in that process (--cpu-sample 0):
+    GPU == oracle is tests/test_align.py's business."""
+    import subprocess
+    t0 = time.perf_counter()
+    leg = {"what": "bmv_align: semi-global edit distance + CIGAR of every candidate alignment (Myers bit-vector, checkpoints, "
+                   "traceback on the device); kernel time from HIP events inside the library, inputs resident",
+           "unit": "cell updates/s"}
+    for name, extra in (("short_reads", ["--reads", "1000000", "--len", "300"]),
+                        ("long_reads", ["--reads", "20000", "--len", "10000", "--indel-rate", "0.1", "--sub", "0.03"])):
+        try:
+            out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bench_verify.py"), "--cpu-sample", "0", "--repeat", "2"] + extra,
+                                 capture_output=True, text=True, timeout=300, check=True).stdout
+            d = json.loads(out.strip().splitlines()[-1])
+            leg[name] = {"alignments": d["config"]["alignments"], "query_len": d["config"]["query_len"], "text_len": d["config"]["text_len"],
+                         "ms_kernels": d["ms_kernels"], "value": d["cell_updates_per_s"], "alignments_per_s": d["value"],
+                         "mean_edits": d["mean_edits"]}
+        except (subprocess.SubprocessError, ValueError, KeyError, IndexError) as e:
+            leg[name] = {"error": str(e)[:300]}
+    leg["seconds"] = time.perf_counter() - t0
+    log("verifier leg: " + ", ".join(f"{k} {v['value'] / 1e12:.1f} T cell updates/s ({v['ms_kernels']:.2f} ms)"
+                                     for k, v in leg.items() if isinstance(v, dict) and "value" in v) + f", {leg['seconds']:.0f} s")
+    return leg
+
+
 def under_profiler():
     """True when this process already runs under rocprofv3 / rocprofiler-sdk (a nested profiler must not be started)."""
     pre = os.environ.get("LD_PRELOAD", "")
@@ -401,7 +427,7 @@ def main():
                     help="BMF_FLAG_EARLY_EXIT: identical outputs, fewer rows actually read (off by default so "
                          "that the roofline line prices exactly the reference's row reads)")
     ap.add_argument("--no-pruned-leg", action="store_true", help="skip the extra BMF_FLAG_EARLY_EXIT measurement")
-    ap.add_argument("--no-extra-legs", action="store_true", help="skip the `skewed` and `roofline_large_index` legs (N = 1 only anyway)")
+    ap.add_argument("--no-extra-legs", action="store_true", help="skip the `skewed`, `roofline_large_index` and `verifier` legs (N = 1 only anyway)")
     ap.add_argument("--skewed-parity-reads", type=int, default=50000, help="reads of the skewed leg checked against the oracle")
     ap.add_argument("--large-index-reads", type=int, default=500000, help="reads per step of the large-index leg")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -687,6 +713,8 @@ def main():
             result["skewed"] = skewed_leg(args, device, cli, k2i, threads, log)
         if extra and args.workload == "egu" and not args.total_bp and not args.bucket_len:
             result["roofline_large_index"] = large_index_leg(args, device, k2i, threads, log)
+        if extra and args.workload == "egu" and not args.total_bp and not args.bucket_len:
+            result["verifier"] = verifier_leg(log)
         print(json.dumps(result), flush=True)
 
     if world > 1:

@@ -46,7 +46,7 @@ def test_single_gpu_line_has_roofline_traffic_and_cpu_baseline():
     assert sk["pruned"]["outputs_identical_to_default_kernel"] is True and sk["pruned"]["ms_per_step"] > 0
     assert 0.5 < sk["rows_passing_distinguishability"] < 1.0 and 0.8 < sk["checks"]["reads_with_candidates"] <= 1.0
     assert 0 < sk["roofline"]["frac"] < 1.05
-    assert "roofline_large_index" not in d            # (the 4.6 GB leg belongs to the default `egu` run)
+    assert "roofline_large_index" not in d and "verifier" not in d     # (the 4.6 GB and verifier legs belong to the default `egu` run)
 
 
 @pytest.mark.parametrize("ranks", [2, 4])
@@ -64,7 +64,7 @@ def test_strong_scaling_rehearsal(ranks):
     assert d["weak_scaling"]["value"] > 0 and d["cpu_baseline"] is None
     assert d["pruned"]["outputs_identical_to_headline_run"] is True
     assert d["checks"]["source_bucket_recovered"] > 0.97
-    assert "skewed" not in d and "roofline_large_index" not in d           # N = 1 legs
+    assert "skewed" not in d and "roofline_large_index" not in d and "verifier" not in d           # N = 1 legs
     # every rank's view of the timed region: its shard, its step time, its kernels' time, its setup
     pr = d["per_rank"]
     assert pr["reads"] == per and len(pr["step_ms"]) == ranks
