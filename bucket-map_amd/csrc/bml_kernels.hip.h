@@ -315,17 +315,19 @@ __global__ __launch_bounds__(kLightThreads) void bml_replay_light_kernel(
 // The reference keeps its proposals in a std::map and, for every occurrence of sample i in descending offset order:
 // if the map was empty when the sample began the start position is inserted; else every proposal within +-indel of
 // the start gets a vote, or -- if there is none -- the start is inserted with one vote (:247-270).  Start positions
-// lie in [-window length, bucket length): a DENSE bitmap `exists` of that range and a dense vote array replace the
-// map, and the sample's occurrences are handled in four order-free steps:
-//   1. against the proposals that existed BEFORE the sample (K): every occurrence votes for each of them within
-//      +-indel (atomic adds); an occurrence that finds none is marked in `fresh`.
-//   2. the occurrences in `fresh`, highest first (= the reference's processing order): one becomes a new proposal iff
+// lie in [-window length, bucket length): a DENSE bitmap `exists` of that range and a LIST of the proposals (start, votes)
+// replace the map, and the sample's occurrences are handled in order-free steps:
+//   1. the sample's starts are set in a bitmap `starts`; a start with no proposal within +-indel is marked in `fresh`.
+//   2. the proposals that existed BEFORE the sample (K): a thread per proposal adds the number of starts within +-indel of
+//      it -- a population count over `starts`.  Those are the votes the reference gives one (occurrence, proposal) pair
+//      at a time; as atomic adds on a dense vote array they were 1.2 G scattered atomics per million reads in repeats and a
+//      third of the kernel's time.
+//   3. the starts in `fresh`, highest first (= the reference's processing order): one becomes a new proposal iff
 //      the proposal inserted last lies more than indel above it (proposals made earlier in this sample are all above
 //      it, the last one is the nearest; those of K are not in range by step 1).  One wave walks the bitmap.
-//   3. every occurrence votes for the NEW proposal within indel ABOVE it, if there is one (new proposals are more than
-//      indel apart, so at most one): that proposal was inserted before the occurrence was processed.  Proposals below
-//      an occurrence were inserted after it and get nothing from it.
-//   4. the new proposals join `exists`.
+//   4. a new proposal begins with its own vote and gets one from every start within indel BELOW it (new proposals are more
+//      than indel apart, so a start votes for one at most; the proposal was inserted before those starts were processed,
+//      and starts above it were processed before it existed); then it joins `exists`.
 // Winner: most votes, ties -> smallest start (:281-283), accepted as in the light kernel.
 // Bitmaps live in LDS when 3 of them fit (`lds_bitmaps`), else in the workgroup's global scratch.
 constexpr uint32_t kHeavyLdsOcc = 6144;          // occurrences of one candidate kept in LDS (24 KB)
