@@ -433,8 +433,15 @@ __global__ __launch_bounds__(kThreads) void bml_replay_heavy_kernel(
             auto for_each_pos = [&](auto fn) {
                 if (in_lds)
                     for (uint32_t o = o0 + tid; o < o1; o += kThreads) fn(start_of(locc[o]), o - o0);
-                else
-                    for (uint32_t o = o0 + tid; o < o1; o += kThreads) fn(start_of(0x7FFFFFFFu - (uint32_t)mine[o]), o - o0);
+                else                                             // (from global memory: four loads in flight, one latency)
+                    for (uint32_t o = o0 + tid; o < o1; o += 4u * kThreads) {
+                        uint64_t key[4];
+#pragma unroll
+                        for (int u = 0; u < 4; u++) key[u] = o + u * kThreads < o1 ? mine[o + u * kThreads] : 0ull;
+#pragma unroll
+                        for (int u = 0; u < 4; u++)
+                            if (o + u * kThreads < o1) fn(start_of(0x7FFFFFFFu - (uint32_t)key[u]), o + u * kThreads - o0);
+                    }
             };
             const uint32_t np = s_np;                                // proposals before this sample (uniform)
             if (np == 0) {                                           // :247-251 the map was empty: every start goes in
@@ -467,10 +474,17 @@ __global__ __launch_bounds__(kThreads) void bml_replay_heavy_kernel(
             __syncthreads();
             // 2. votes for the proposals that were there before this sample: each counts the starts within +-indel of it
             //    (a thread per proposal and a population count -- not an atomic add per (occurrence, proposal) pair)
-            for (uint32_t q = tid; q < np; q += kThreads) {
-                const uint32_t at = prop_pos[q];
-                const uint32_t got = count_bits(starts, (int64_t)at - d, (int64_t)at + d);
-                if (got) prop_votes[q] += got;
+            //    (four proposals a thread at a time: the list lives in global memory, and four loads in flight cost one latency)
+            for (uint32_t q0 = tid; q0 < np; q0 += 4u * kThreads) {
+                uint32_t at[4], got[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) at[u] = q0 + u * kThreads < np ? prop_pos[q0 + u * kThreads] : 0u;
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+                    got[u] = q0 + u * kThreads < np ? count_bits(starts, (int64_t)at[u] - d, (int64_t)at[u] + d) : 0u;
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+                    if (got[u]) atomicAdd(&prop_votes[q0 + u * kThreads], got[u]);   // (no return value: fire and forget)
             }
             // 3. new proposals among the fresh starts, highest first (one wave)
             if (s_fresh != 0 && tid < 64) {
@@ -517,9 +531,19 @@ __global__ __launch_bounds__(kThreads) void bml_replay_heavy_kernel(
         if (tid == 0) s_best = 0;
         __syncthreads();
         unsigned long long best = 0;
-        for (uint32_t q = tid; q < s_np; q += kThreads) {
-            const unsigned long long cand = ((unsigned long long)prop_votes[q] << 32) | (0xFFFFFFFFu - prop_pos[q]);
-            best = cand > best ? cand : best;
+        for (uint32_t q0 = tid; q0 < s_np; q0 += 4u * kThreads) {
+            uint32_t v[4], at[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const bool in = q0 + u * kThreads < s_np;
+                v[u] = in ? prop_votes[q0 + u * kThreads] : 0u;
+                at[u] = in ? prop_pos[q0 + u * kThreads] : 0xFFFFFFFFu;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const unsigned long long cand = ((unsigned long long)v[u] << 32) | (0xFFFFFFFFu - at[u]);
+                best = cand > best ? cand : best;
+            }
         }
         atomicMax(&s_best, best);
         __syncthreads();
@@ -537,7 +561,14 @@ __global__ __launch_bounds__(kThreads) void bml_replay_heavy_kernel(
             out_offset[pair] = off;
             out_votes[pair] = nv;
         }
-        for (uint32_t q = tid; q < s_np; q += kThreads) exists[prop_pos[q] >> 5] = 0;   // leave the map empty for the next candidate
+        for (uint32_t q0 = tid; q0 < s_np; q0 += 4u * kThreads) {  // leave the map empty for the next candidate
+            uint32_t at[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) at[u] = q0 + u * kThreads < s_np ? prop_pos[q0 + u * kThreads] : 0xFFFFFFFFu;
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+                if (at[u] != 0xFFFFFFFFu) exists[at[u] >> 5] = 0;
+        }
         __syncthreads();
     }
 }
