@@ -405,7 +405,14 @@ __global__ __launch_bounds__(kThreads) void bml_replay_heavy_kernel(
         for (uint32_t i = tid; i < 65u; i += kThreads) s_hist[i] = 0;
         if (tid == 0) s_np = 0;
         __syncthreads();
-        for (uint64_t i = tid; i < n; i += kThreads) atomicAdd(&s_hist[(uint32_t)(keys[first + i] >> 32) - pair * P.p + 1u], 1u);
+        for (uint64_t i = tid; i < n; i += 4u * kThreads) {      // (four keys in flight per thread)
+            uint64_t key[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) key[u] = i + u * kThreads < n ? keys[first + i + u * kThreads] : 0ull;
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+                if (i + u * kThreads < n) atomicAdd(&s_hist[(uint32_t)(key[u] >> 32) - pair * P.p + 1u], 1u);
+        }
         __syncthreads();
         if (tid == 0) {
             for (uint32_t i = 0; i < P.p; i++) s_hist[i + 1] += s_hist[i];          // s_hist[i] = first occurrence of sample i
@@ -415,11 +422,18 @@ __global__ __launch_bounds__(kThreads) void bml_replay_heavy_kernel(
         // ... into LDS (their bucket offsets, 4 bytes each) when they fit, else into the global scratch
         const bool in_lds = n <= kHeavyLdsOcc;
         uint64_t *mine = S.by_sample ? S.by_sample + first : nullptr;
-        for (uint64_t i = tid; i < n; i += kThreads) {
-            const uint64_t key = keys[first + i];
-            const uint32_t at = atomicAdd(&s_cursor[(uint32_t)(key >> 32) - pair * P.p], 1u);
-            if (in_lds) locc[at] = 0x7FFFFFFFu - (uint32_t)key;
-            else mine[at] = key;
+        for (uint64_t i = tid; i < n; i += 4u * kThreads) {
+            uint64_t key[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) key[u] = i + u * kThreads < n ? keys[first + i + u * kThreads] : 0ull;
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                if (i + u * kThreads < n) {
+                    const uint32_t at = atomicAdd(&s_cursor[(uint32_t)(key[u] >> 32) - pair * P.p], 1u);
+                    if (in_lds) locc[at] = 0x7FFFFFFFu - (uint32_t)key[u];
+                    else mine[at] = key[u];
+                }
+            }
         }
         __syncthreads();
         for (uint32_t i = 0; i < P.p; i++) {
