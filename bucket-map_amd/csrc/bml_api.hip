@@ -360,19 +360,23 @@ int bml_locate(bml_ctx *c, const uint32_t *sample_hash, const uint16_t *sample_p
         c->last_heavy += n_heavy;
         if (n_heavy) {
             const uint32_t range = c->p.max_bucket_bases + max_seg, words = (range + 31u) / 32u;
-            const size_t lds_occ = (size_t)bml::kHeavyLdsOcc * sizeof(uint32_t);
-            const bool in_lds = lds_occ + (size_t)3 * words * sizeof(uint32_t) <= 150 * 1024;
-            const size_t lds = lds_occ + (in_lds ? (size_t)3 * words * sizeof(uint32_t) : 0);
+            // The three bitmaps in LDS while two workgroups still fit a CU (3 x 8 KB at 65 536-base buckets: six workgroups a CU,
+            // 20 ms per million reads in repeats against 52 ms with the bitmaps -- and their atomics -- in global memory); beyond
+            // that, global scratch and eight workgroups a CU (3 x 34 KB at 262 144: 25 ms for configs[4]'s 20 000 reads against
+            // 30 ms at one workgroup a CU).  BML_LDS_BITMAP_KB moves the limit (experiments).
+            const size_t lds_limit = getenv("BML_LDS_BITMAP_KB") ? (size_t)atoi(getenv("BML_LDS_BITMAP_KB")) * 1024 : (size_t)64 * 1024;
+            const bool in_lds = (size_t)3 * words * sizeof(uint32_t) <= lds_limit;
+            const size_t lds = in_lds ? (size_t)3 * words * sizeof(uint32_t) : 16;
             if (lds > 48 * 1024)
                 HIP_TRY(bmhip::raise_dynamic_lds(reinterpret_cast<const void *>(bml::bml_replay_heavy_kernel), lds));
-            // as many workgroups as the CUs hold at once (LDS decides: 1 per CU at 262 144-base buckets, 3 at 65 536)
+            // as many workgroups as the CUs hold at once (LDS decides: 1 per CU at 262 144-base buckets, 6 at 65 536)
             const uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(8, (size_t)(156 * 1024) / (lds + 1024)));
             const unsigned grid = (unsigned)std::min<uint32_t>(n_heavy, per_cu * (uint32_t)c->n_cu);
             HIP_TRY(c->heavy_votes.need((size_t)grid * 2 * range));
             if (!in_lds) HIP_TRY(c->heavy_bitmaps.need((size_t)grid * 3 * words));
-            // candidates whose occurrences do not fit the kernel's LDS copy group them by sample in a second buffer
-            if (heavy_info[1] > bml::kHeavyLdsOcc) HIP_TRY(c->occ_b.need((size_t)n_occ));
-            const bml::HeavyScratch hs{c->heavy_votes.p, c->heavy_bitmaps.p, heavy_info[1] > bml::kHeavyLdsOcc ? c->occ_b.p : nullptr};
+            // the heavy candidates group their occurrences by sample in a second buffer
+            HIP_TRY(c->occ_b.need((size_t)n_occ));
+            const bml::HeavyScratch hs{c->heavy_votes.p, c->heavy_bitmaps.p, c->occ_b.p};
             HIP_TRY(hipEventRecord(c->ev[5], c->stream));        // (the allocations above are not replay time)
             hipLaunchKernelGGL(bml::bml_replay_heavy_kernel, dim3(grid), dim3(bml::kThreads), lds, c->stream, c->lp, c->occ_a.p,
                                c->cand_start.p, c->cand_count.p, c->sample_pos.p, c->seg_len.p, c->pair_window.p, c->pair_rc.p, c->heavy.p,

@@ -329,14 +329,15 @@ __global__ __launch_bounds__(kLightThreads) void bml_replay_light_kernel(
 //      than indel apart, so a start votes for one at most; the proposal was inserted before those starts were processed,
 //      and starts above it were processed before it existed); then it joins `exists`.
 // Winner: most votes, ties -> smallest start (:281-283), accepted as in the light kernel.
-// Bitmaps live in LDS when 3 of them fit (`lds_bitmaps`), else in the workgroup's global scratch.
-constexpr uint32_t kHeavyLdsOcc = 6144;          // occurrences of one candidate kept in LDS (24 KB)
+// Bitmaps live in LDS when 3 of them fit (`lds_bitmaps`), else in the workgroup's global scratch; nothing else does.
 
 struct HeavyScratch {
     uint32_t *votes;        // per workgroup: 2 x range entries (the proposals' start positions, then their votes)
     uint32_t *bitmaps;      // per workgroup: 3 x words (used when the bitmaps do not fit LDS)
-    uint64_t *by_sample;    // candidates with more than kHeavyLdsOcc occurrences: theirs grouped by sample, same layout as
-                            // the occurrence buffer (null when no candidate is that large)
+    uint64_t *by_sample;    // every heavy candidate's occurrences grouped by sample: same layout as the occurrence buffer.
+                            // (Round 3 kept those of candidates with up to 6 144 in LDS: 24 KB a workgroup, three workgroups
+                            // a CU; with the walks' loads batched the global copy costs nothing and six workgroups a CU
+                            // hide each other's barriers: 29 -> 20 ms per million reads in repeats.)
 };
 
 __global__ __launch_bounds__(kThreads) void bml_replay_heavy_kernel(
@@ -350,8 +351,7 @@ __global__ __launch_bounds__(kThreads) void bml_replay_heavy_kernel(
     __shared__ uint32_t s_hist[65], s_cursor[64], s_fresh, s_new, s_np, s_fmax, s_fmin, s_next;
     __shared__ unsigned long long s_best;
     const uint32_t tid = threadIdx.x, words = (range + 31u) / 32u;
-    uint32_t *locc = heavy_lds;                  // a candidate's occurrences grouped by sample (kHeavyLdsOcc of them fit)
-    uint32_t *exists = lds_bitmaps ? heavy_lds + kHeavyLdsOcc : S.bitmaps + (size_t)blockIdx.x * 3u * words;
+    uint32_t *exists = lds_bitmaps ? heavy_lds : S.bitmaps + (size_t)blockIdx.x * 3u * words;
     uint32_t *fresh = exists + words, *starts = fresh + words;
     // the proposals, in the order they were made: start position and votes (at most one per start position)
     uint32_t *prop_pos = S.votes + (size_t)blockIdx.x * 2u * range, *prop_votes = prop_pos + range;
@@ -419,9 +419,8 @@ __global__ __launch_bounds__(kThreads) void bml_replay_heavy_kernel(
             for (uint32_t i = 0; i < P.p; i++) s_cursor[i] = s_hist[i];
         }
         __syncthreads();
-        // ... into LDS (their bucket offsets, 4 bytes each) when they fit, else into the global scratch
-        const bool in_lds = n <= kHeavyLdsOcc;
-        uint64_t *mine = S.by_sample ? S.by_sample + first : nullptr;
+        // ... into the second occurrence buffer
+        uint64_t *mine = S.by_sample + first;
         for (uint64_t i = tid; i < n; i += 4u * kThreads) {
             uint64_t key[4];
 #pragma unroll
@@ -430,8 +429,7 @@ __global__ __launch_bounds__(kThreads) void bml_replay_heavy_kernel(
             for (int u = 0; u < 4; u++) {
                 if (i + u * kThreads < n) {
                     const uint32_t at = atomicAdd(&s_cursor[(uint32_t)(key[u] >> 32) - pair * P.p], 1u);
-                    if (in_lds) locc[at] = 0x7FFFFFFFu - (uint32_t)key[u];
-                    else mine[at] = key[u];
+                    mine[at] = key[u];
                 }
             }
         }
@@ -443,19 +441,16 @@ __global__ __launch_bounds__(kThreads) void bml_replay_heavy_kernel(
             if (o0 == o1) continue;                                  // (uniform: s_hist is shared)
             // start position of an occurrence, shifted by `bias` into [0, range)
             auto start_of = [&](uint32_t occ) { return (uint32_t)((int32_t)(occ - idx) + (int32_t)bias); };
-            // every step below walks the sample's occurrences again: from the LDS copy when the candidate's fit there
+            // every step below walks the sample's occurrences again (global memory: four loads in flight, one latency)
             auto for_each_pos = [&](auto fn) {
-                if (in_lds)
-                    for (uint32_t o = o0 + tid; o < o1; o += kThreads) fn(start_of(locc[o]), o - o0);
-                else                                             // (from global memory: four loads in flight, one latency)
-                    for (uint32_t o = o0 + tid; o < o1; o += 4u * kThreads) {
-                        uint64_t key[4];
+                for (uint32_t o = o0 + tid; o < o1; o += 4u * kThreads) {
+                    uint64_t key[4];
 #pragma unroll
-                        for (int u = 0; u < 4; u++) key[u] = o + u * kThreads < o1 ? mine[o + u * kThreads] : 0ull;
+                    for (int u = 0; u < 4; u++) key[u] = o + u * kThreads < o1 ? mine[o + u * kThreads] : 0ull;
 #pragma unroll
-                        for (int u = 0; u < 4; u++)
-                            if (o + u * kThreads < o1) fn(start_of(0x7FFFFFFFu - (uint32_t)key[u]), o + u * kThreads - o0);
-                    }
+                    for (int u = 0; u < 4; u++)
+                        if (o + u * kThreads < o1) fn(start_of(0x7FFFFFFFu - (uint32_t)key[u]), o + u * kThreads - o0);
+                }
             };
             const uint32_t np = s_np;                                // proposals before this sample (uniform)
             if (np == 0) {                                           // :247-251 the map was empty: every start goes in
