@@ -427,11 +427,21 @@ int bml_locate(bml_ctx *c, const uint32_t *sample_hash, const uint16_t *sample_p
                 sum += cs;
                 hi++;
             }
-            unsigned long long got = 0;
-            if (int rc = scan(lo, hi, std::max<unsigned long long>(sum, 1), &got)) return rc;
-            if (got != sum) return fail(BML_ERR_HIP, "a group's occurrence count changed between scans (%llu, then %llu)", sum, got);
+            // the first scan has counted every candidate's occurrences: the group's segments are placed from those counts
+            // (one after the other, in candidate order) and its scan only writes
             const uint32_t pair_lo = chunks[lo].pair_begin, pair_hi = chunks[hi - 1].pair_begin + chunks[hi - 1].pair_count;
-            if (int rc = replay(pair_lo, pair_hi, got)) return rc;
+            std::vector<uint64_t> placed(pair_hi - pair_lo);
+            unsigned long long at = 0;
+            for (uint32_t i = pair_lo; i < pair_hi; i++) {
+                placed[i - pair_lo] = at;
+                at += counts[i];
+            }
+            if (at != sum) return fail(BML_ERR_HIP, "a group's occurrence count does not add up (%llu, %llu)", sum, at);
+            HIP_TRY(hipMemcpyAsync(c->cand_start.p + pair_lo, placed.data(), placed.size() * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));          // (`placed` is pageable memory and goes out of scope)
+            unsigned long long got = 0;
+            if (int rc = scan(lo, hi, std::max<unsigned long long>(sum, 1), &got, true)) return rc;
+            if (int rc = replay(pair_lo, pair_hi, sum)) return rc;
             lo = hi;
         }
     }
