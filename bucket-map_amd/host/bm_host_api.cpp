@@ -94,6 +94,18 @@ uint64_t bmh_select_qgrams(uint32_t q, float kmer_frac, uint64_t hash_seed, int3
     return ix.num_rows;
 }
 
+// Same with the hash function given outright -- (x*i + y) % p % table, the closure hash_function_generator::generate
+// returns (hash_function_generator.h:105-116) -- so that a selection made by the reference's own header can be reproduced.
+uint64_t bmh_select_qgrams_xy(uint32_t q, float kmer_frac, uint64_t x, uint64_t y, uint64_t p, uint64_t table,
+                              int32_t *out_k2i) {
+    bm::QgramIndex ix;
+    bm::FracMinHash h;
+    h.x = x; h.y = y; h.p = p; h.table = table;
+    bm::select_qgrams(ix, q, h, kmer_frac);
+    std::memcpy(out_k2i, ix.kmer_to_index.data(), ix.kmer_to_index.size() * sizeof(int32_t));
+    return ix.num_rows;
+}
+
 // Walks a FASTQ file with the tool's own reader: number of records, total bases and a checksum over
 // ids, sequences and qualities (for tests of the block reader).
 int bmh_fastq_stats(const char *path, uint64_t *n_records, uint64_t *n_bases, uint64_t *checksum) {

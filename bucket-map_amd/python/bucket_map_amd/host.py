@@ -36,6 +36,7 @@ def lib() -> C.CDLL:
             "bmh_genome_total": (u64, [vp]),
             "bmh_genome_flatten": (None, [vp, vp, vp]),
             "bmh_select_qgrams": (u64, [u32, C.c_float, u64, vp]),
+            "bmh_select_qgrams_xy": (u64, [u32, C.c_float, u64, u64, u64, u64, vp]),
             "bmh_fastq_stats": (C.c_int, [C.c_char_p, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64)]),
             "bmh_awk_bucket_num": (u32, [vp, u32]),
             "bmh_cut_buckets": (u32, [vp, u32, u32, C.POINTER(u32)]),
@@ -81,6 +82,13 @@ def select_qgrams(q: int, kmer_frac: float = 1.0, hash_seed: int = 20240004) -> 
     """FracMinHash row selection (bucket_indexer.h:147-157): kmer_to_index with 4^q entries."""
     out = np.zeros(4 ** q, dtype=np.int32)
     lib().bmh_select_qgrams(q, kmer_frac, hash_seed, out.ctypes.data)
+    return out
+
+
+def select_qgrams_xy(q: int, kmer_frac: float, x: int, y: int, p: int = 116731, table: int = 10000) -> np.ndarray:
+    """The same selection with the hash (x*i + y) % p % table given outright (hash_function_generator.h:105-116)."""
+    out = np.zeros(4 ** q, dtype=np.int32)
+    lib().bmh_select_qgrams_xy(q, kmer_frac, x, y, p, table, out.ctypes.data)
     return out
 
 

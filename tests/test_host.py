@@ -24,6 +24,34 @@ def build_oracle_cli():
     return ORACLE_CLI
 
 
+# ------------------------------------------------------------------ FracMinHash (bucket_indexer.h:147-157)
+
+def test_fracminhash_matches_the_reference_header():
+    """Row f3's q-gram selection pinned by a reference-owned artefact: tests/golden/fracminhash_ref.json holds what the
+    closure of the reference's own hash_function_generator.h (compiled as it lies by make_fracminhash_golden.py)
+    selected after std::srand(seed).  select_qgrams with the same (x, y, p) must give the same kmer_to_index."""
+    import hashlib
+    import json
+    golden = json.load(open(os.path.join(ROOT, "tests", "golden", "fracminhash_ref.json")))
+    inputs = golden["sample_inputs"]
+    assert len(golden["cases"]) >= 8
+    for c in golden["cases"]:
+        k2i = host.select_qgrams_xy(c["q"], c["kmer_frac"], c["x"], c["y"], c["p"], 10000)
+        kept = np.flatnonzero(k2i >= 0)
+        assert kept.size == c["kept"], c
+        assert kept[:24].tolist() == c["first_kept"], c
+        assert np.array_equal(k2i[kept], np.arange(kept.size)), "rows are numbered in ascending q-gram"
+        assert hashlib.sha256(k2i.tobytes()).hexdigest() == c["k2i_sha256"], c
+        # the raw hash values, in Python integers
+        assert [(c["x"] * i + c["y"]) % c["p"] % 10000 for i in inputs] == c["sample_hashes"]
+        assert c["p"] == 116731                       # first listed prime > 10 * 10000
+        assert c["threshold"] == int(np.float32(10000) * np.float32(c["kmer_frac"]))
+    # f = 1 keeps everything whatever x, y are -- the setting every BASELINE config runs with
+    full = [c for c in golden["cases"] if c["kmer_frac"] == 1.0][0]
+    assert full["kept"] == 4 ** full["q"]
+    assert np.array_equal(host.select_qgrams(9, 1.0), np.arange(4 ** 9, dtype=np.int32))
+
+
 # ------------------------------------------------------------------ bucket cutting (utils.h:60-102)
 
 def test_bucket_cutting_rules():
