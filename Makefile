@@ -71,6 +71,14 @@ tests/cpp/bucketmap_align_oracle_asan: $(HOST)/main.cpp tests/cpp/make_mapper_or
 tests/cpp/umm_order: tests/cpp/umm_order.cpp
 	$(CXX) -O2 -std=c++17 -o $@ $<
 
+# TEST ONLY, build container only (the reference does not travel): the reference-side binding compiled against the
+# reference's REAL mapper.h.  The binary travels to the GPU box like the other built files.
+REF ?= /root/reference
+integration/_build/ref_binding: integration/ref_binding_main.cpp integration/gpu_q_gram_mapper.h include/bmf.h $(PKG)/libbmf.so
+	mkdir -p integration/_build
+	$(CXX) -O2 -std=c++17 -Wall -Wextra -o $@ integration/ref_binding_main.cpp -I$(REF)/bucket_map -Iintegration -Iinclude \
+	    -L$(PKG) -lbmf -Wl,-rpath,'$$ORIGIN/../../$(PKG)'
+
 clean:
 	rm -f $(PRODUCT) $(TESTINFRA) $(CSRC)/*.o tests/cpp/*.o
 
