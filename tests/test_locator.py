@@ -305,6 +305,62 @@ def test_gpu_sampling_equals_oracle(k, p, max_len, minq):
     scan.close()
 
 
+def _single_good_kmer_batch(k, b):
+    """Windows whose qualities leave EXACTLY ONE k-mer at b*k or above (bucket_locator.h:325-333 then calls
+    Sampler::sample_deterministically(0), which returns without sampling, utils.h:165), and windows of exactly k bases
+    (one k-mer, whatever its quality).  Returns bases, quals, win_start, win_len and the position of the one k-mer."""
+    rng = np.random.default_rng(97 * k + b)
+    texts, quals, at = [], [], []
+    for length, j0 in ((150, 0), (150, 150 - k), (150, 71), (300, 123), (k + 1, 1), (k + 1, 0), (40, 17)):
+        q = np.full(length, 33, np.uint8)                      # phred 0 everywhere ...
+        q[j0:j0 + k] = 33 + b                                  # ... but k bases at exactly b: that k-mer sums to b*k,
+        texts.append(LETTERS[rng.integers(0, 4, length)])      # its neighbours to b*(k-1) < b*k
+        quals.append(q)
+        at.append(j0)
+    for phred in (40, 0):                                      # exactly k bases: one k-mer, good or not (:330-332)
+        texts.append(LETTERS[rng.integers(0, 4, k)])
+        quals.append(np.full(k, 33 + phred, np.uint8))
+        at.append(0)
+    lens = np.array([len(t) for t in texts], np.uint32)
+    ws = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.uint64)
+    return np.concatenate(texts), np.concatenate(quals), ws, lens, at
+
+
+@pytest.mark.parametrize("p", [10, 20])
+def test_oracle_sampling_with_exactly_one_good_kmer(p):
+    """DOCUMENTED DEVIATION: with one good k-mer the reference's sampler keeps whatever the PREVIOUS
+    window left in `samples` (stale positions indexing a 1-element vector: undefined behaviour; nothing at all for the
+    first window of a run).  Oracle and product define the case instead: all p samples are that one k-mer."""
+    k, b = 12, 25
+    bases, quals, ws, wl, at = _single_good_kmer_batch(k, b)
+    h, pos, has = oc.sample_windows(k, p, b * k, bases, quals, ws, wl)
+    assert has.tolist() == [1] * len(ws)
+    for w, j in enumerate(at):
+        assert pos[w].tolist() == [j] * p, w
+        want = int(onp.kmer_hashes(bases[int(ws[w]): int(ws[w]) + int(wl[w])], k)[j])
+        assert h[w].tolist() == [want] * p, w
+    # one more good k-mer and the sampler really samples: first half of the samples at the first, the rest at the second
+    quals2 = quals.copy()
+    quals2[int(ws[2]) + 100: int(ws[2]) + 100 + k] = 33 + b
+    _, pos2, _ = oc.sample_windows(k, p, b * k, bases, quals2, ws, wl)
+    assert sorted(set(pos2[2].tolist())) == [71, 100] and pos2[2, 0] == 71 and pos2[2, -1] == 100
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("p", [10, 20])
+def test_gpu_sampling_with_exactly_one_good_kmer(p):
+    from bucket_map_amd import locate
+    k, b = 12, 25
+    bases, quals, ws, wl, at = _single_good_kmer_batch(k, b)
+    want = oc.sample_windows(k, p, b * k, bases, quals, ws, wl)
+    scan = locate.LocatorScan(k, p, 4, 6, 70000)
+    got = scan.sample_windows(bases, quals, ws, wl, b * k)
+    scan.close()
+    for a, g, what in zip(want, got, ("hash", "position", "has-samples")):
+        assert np.array_equal(a, g), what
+    assert [got[1][w].tolist() for w in range(len(ws))] == [[j] * p for j in at]
+
+
 def _golden_sampling():
     import json
     here = os.path.dirname(os.path.abspath(__file__))
