@@ -215,6 +215,121 @@ def pruned_leg(inputs, cli, device, k2i, steps, want, shard=None, all_reduce_max
     return out, fp, bp
 
 
+def candidate_pairs(counts, buckets):
+    """The filter's candidate lists as the locator's (bucket, window, strand) triples, grouped by bucket as bucket_locator's
+    loop meets them (bucket_locator.h:651-693: bucket by bucket; inside a bucket the read-as-is list, then the
+    reverse-complement list, each in (read, window) order)."""
+    import numpy as np
+    mask = np.arange(buckets.shape[-1])[None, None, :] < counts[:, :, None]
+    w_idx, s_idx, _ = np.nonzero(mask)
+    b = buckets[mask]
+    order = np.lexsort((w_idx, s_idx, b))
+    return b[order].astype(np.uint32), w_idx[order].astype(np.uint32), s_idx[order].astype(np.uint8)
+
+
+LOCATOR_SAMPLES, LOCATOR_MISMATCH_RATE, LOCATOR_INDEL_RATE = 10, 0.4, 0.02      # -p, -e, -n defaults (main.cpp:30-37)
+
+
+def locator_leg(inp, cli, device, counts, buckets, steps, cpu_seconds, log):
+    """north_star's second replaced subsystem, `bucket_map/locator`'s candidate scan: `_create_kmer_index` +
+    `_find_offset` (bucket_locator.h:162-177,209-290) for EVERY candidate the filter produced for this batch, through
+    bml_locate (include/bml.h).  Kernel times are HIP events inside the library (scan = bml_scan_kernel, replay = the light
+    and heavy vote kernels); `ms_call` is the wall time of the C-ABI call with host buffers in and out.  Algorithmic bytes:
+    every (bucket, chunk of candidates) reads its bucket once (bucket bases) and every k-mer occurrence is written once by
+    the scan and read once by the replay (8 B each way).  cpu_baseline: oracle/bm_locator_oracle.c::bmlo_locate, 1 thread,
+    on the candidates of the first buckets (the analogue of the reference's per-bucket multimap build + vote)."""
+    import numpy as np
+    import bucket_map_amd as bma
+    from bucket_map_amd import locate
+    from oracle import oracle_c
+    t_leg = time.perf_counter()
+    k, p = cli["query_seed"], LOCATOR_SAMPLES
+    L = bma.lib()
+    mismatch = int(L.bmf_ceil_mul_f32(LOCATOR_MISMATCH_RATE, p))
+    indel = int(L.bmf_ceil_mul_f32(LOCATOR_INDEL_RATE, inp.read_len))
+    flat, _ = inp.genome.flat()
+    bstart, blen = inp.genome.bucket_views(inp.bucket_len, inp.read_len)
+    scan = locate.LocatorScan(k, p, mismatch, indel, inp.bucket_len + inp.read_len, device)
+    scan.load_genome(flat, bstart, blen)
+    rd = inp.reads
+    minq = cli["average_base_quality"] * k
+    t0 = time.perf_counter()
+    sh, sp, has = scan.sample_windows(rd.bases, rd.quals, inp.win_start, inp.win_len, minq)
+    sample_s = time.perf_counter() - t0
+    pb, pw, pr = candidate_pairs(counts, buckets)
+    keep = has[pw] != 0
+    pb, pw, pr = pb[keep], pw[keep], pr[keep]
+    seg = inp.win_len.astype(np.uint32)
+    best = None
+    runs = []
+    for it in range(1 + max(1, steps)):                        # the first call sizes the occurrence buffer (untimed)
+        t0 = time.perf_counter()
+        off, votes = scan.locate(sh, sp, seg, pb, pw, pr)
+        wall = time.perf_counter() - t0
+        st = scan.stats()
+        st["ms_call"] = wall * 1e3
+        if it:
+            runs.append(st)
+    ms_scan = float(np.mean([r["ms_scan"] for r in runs]))
+    ms_replay = float(np.mean([r["ms_replay"] for r in runs]))
+    ms_host = float(np.mean([r["ms_host"] for r in runs]))
+    st = runs[-1]
+    chunk_max = (4096 // 2) // p                                # candidates per chunk (bml_kernels.hip.h: kTableSlots / 2 / p)
+    run_len = np.diff(np.flatnonzero(np.concatenate(([True], pb[1:] != pb[:-1], [True]))))
+    n_chunks = int(np.sum((run_len + chunk_max - 1) // chunk_max))
+    bucket_bytes = int(np.sum(((run_len + chunk_max - 1) // chunk_max) * blen[pb[np.concatenate(([0], np.cumsum(run_len)[:-1]))]].astype(np.int64)))
+    occ = int(st["occurrences"])
+    algo = bucket_bytes + 16 * occ + int(pb.size) * (p * 6 + 9 + 8)   # + samples (hash u32, pos u16) and the pair record in, (offset, votes) out
+    kern_ms = ms_scan + ms_replay
+    # the read's own position: a candidate on the true (bucket, strand) must be located at the simulated offset
+    true_pair = (pb == rd.truth_bucket[pw]) & (pr == rd.truth_rc[pw])
+    located = off > 0
+    exact = true_pair & located & (np.abs(off.astype(np.int64) - rd.truth_offset[pw].astype(np.int64)) <= indel)
+    leg = {"what": f"bml_locate over every candidate of the batch ({inp.profile} genome): -l {k} -p {p} mismatch {mismatch} indel {indel}, "
+                   f"{int(pb.size)} candidates in {n_chunks} (bucket, chunk) workgroups",
+           "unit": "candidates/s", "value": pb.size / (kern_ms * 1e-3), "candidates": int(pb.size), "chunks": n_chunks,
+           "occurrences": occ, "heavy_candidates": int(st["heavy_candidates"]),
+           "ms_scan": ms_scan, "ms_replay": ms_replay, "ms_host_between_kernels": ms_host,
+           "ms_call": float(np.mean([r["ms_call"] for r in runs])),
+           "ms_sample_windows_call": sample_s * 1e3, "timed_calls": len(runs),
+           "roofline": {"bound": "hbm", "achieved": algo / (kern_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                        "frac": algo / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "kernel": "bml_scan_kernel + bml_replay_*",
+                        "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": int(algo),
+                        "bytes": {"bucket_bases": bucket_bytes, "occurrences_written_and_read": 16 * occ},
+                        "scan_only": {"achieved": (bucket_bytes + 8 * occ) / (ms_scan * 1e-3) / 1e9,
+                                      "frac": (bucket_bytes + 8 * occ) / (ms_scan * 1e-3) / 1e9 / HBM_PEAK_GBPS},
+                        "note": "the scan is a chain of dependent LDS reads per bucket k-mer (filter, table) and the vote an "
+                                "order-dependent replay: the HBM fraction says how far the path is from moving its bytes at "
+                                "stream speed, not that HBM is what it waits for (profiles/r04/locate_sq_counters_*.txt)"},
+           "checks": {"candidates_located": float(located.mean()),
+                      "true_candidates": int(true_pair.sum()),
+                      "true_candidates_located_at_the_simulated_offset": float(exact.sum() / max(1, true_pair.sum()))}}
+    # CPU baseline + parity: the oracle on the candidates of the first buckets, about `cpu_seconds` of one core
+    if cpu_seconds > 0:
+        ends = np.cumsum(run_len)
+        prm = (k, p, mismatch, indel)
+        n0 = int(ends[min(len(ends) - 1, 15)])
+        t0 = time.perf_counter()
+        o_ref, v_ref = oracle_c.locate(*prm, flat, bstart, blen, sh, sp, seg, pb[:n0], pw[:n0], pr[:n0])
+        probe = time.perf_counter() - t0
+        nb_want = int(min(len(ends), max(16, 16 * cpu_seconds / max(probe, 1e-3))))
+        n1 = int(ends[nb_want - 1])
+        t0 = time.perf_counter()
+        o_ref, v_ref = oracle_c.locate(*prm, flat, bstart, blen, sh, sp, seg, pb[:n1], pw[:n1], pr[:n1])
+        cpu_s = time.perf_counter() - t0
+        leg["cpu_baseline"] = {"value": n1 / cpu_s, "unit": "candidates/s", "cores": 1, "kind": "port",
+                               "sample": f"the {n1} candidates of the first {nb_want} candidate buckets, oracle/bm_locator_oracle.c "
+                                         f"bmlo_locate -O3 (per bucket: index of all its k-mers, then the vote per candidate), "
+                                         f"{cpu_s:.1f} s, {cpu_s / nb_want * 1e3:.2f} ms per bucket"}
+        leg["checks"]["gpu_equals_oracle_on_sample"] = bool(np.array_equal(o_ref, off[:n1]) and np.array_equal(v_ref, votes[:n1]))
+        leg["checks"]["parity_sample_candidates"] = n1
+    scan.close()
+    leg["seconds"] = time.perf_counter() - t_leg
+    log(f"locator leg ({inp.profile}): {pb.size} candidates, {occ} occurrences, scan {ms_scan:.2f} ms + replay {ms_replay:.2f} ms "
+        f"(call {leg['ms_call']:.1f} ms), {leg['roofline']['frac']:.3f} of the HBM peak, {leg['seconds']:.0f} s")
+    return leg
+
+
 def skewed_leg(args, device, cli, k2i, threads, log):
     """BASELINE configs[1]'s geometry on the genome-LIKE genome (bm_synth.h): default kernel, pruned kernels, parity sample."""
     import numpy as np
@@ -269,6 +384,11 @@ def skewed_leg(args, device, cli, k2i, threads, log):
     bp.close()
     fp.close()
     leg["pruned"] = pruned
+    if not args.no_locator_leg:
+        try:
+            leg["locator"] = locator_leg(inp, cli, device, counts, buckets, min(args.steps, 3), args.locator_cpu_seconds, log)
+        except Exception as e:                                 # an optional leg must not cost the others
+            leg["locator"] = {"error": f"{type(e).__name__}: {e}"[:400]}
     leg["seconds"] = time.perf_counter() - t0
     log(f"skewed leg: vote {vote_ms:.2f} ms ({leg['roofline']['frac']:.3f} of peak), pruned {pruned['ms_per_step']:.2f} ms/step "
         f"(fold {pruned['pass1_fold']} x {pruned['pass1_fold_rows']} rows), {leg['seconds']:.0f} s")
@@ -303,30 +423,86 @@ def large_index_leg(args, device, k2i, threads, log):
     return leg
 
 
-def verifier_leg(log):
+VALU_ISSUE_PEAK_GINST = 256 * 4 * 2.4 / 2      # wave64 VALU instructions/s, in G: 256 CUs x 4 SIMD-32 x 2.4 GHz / 2 cycles per
+                                               # instruction (MI355X_MICROARCH.md: "issues each VALU instruction over 2 cycles",
+                                               # table row `v_fma_f32` (wave64) 2 cyc; max clock 2400 MHz) = 1 228.8
+
+
+def verifier_leg(log, pmc=True):
     """The alignment verifier (include/bmv.h) beside the headline: tools/bench_verify.py in a process of
-    its own, on the short-read and the long-read shape DESIGN.md 4.4 quotes.  No oracle in that process (--cpu-sample 0):
-    GPU == oracle is tests/test_align.py's business."""
+    its own, on the short-read shapes and the long-read shape DESIGN.md 4.4 quotes.  No oracle in that process
+    (--cpu-sample 0): GPU == oracle is tests/test_align.py's business.  The kernels are integer VALU work (Myers bit-vector
+    columns), so the bound is the chip's vector issue rate: each shape runs a second time under `rocprofv3 --pmc
+    SQ_INSTS_VALU` (a pass of its own, nothing traced) and `roofline` = counted wave-instructions / kernel time against
+    256 CUs x 4 SIMDs x 2.4 GHz / 2 cycles."""
     import subprocess
     t0 = time.perf_counter()
     leg = {"what": "bmv_align: semi-global edit distance + CIGAR of every candidate alignment (Myers bit-vector, checkpoints, "
                    "traceback on the device); kernel time from HIP events inside the library, inputs resident",
            "unit": "cell updates/s"}
+    tool = os.path.join(ROOT, "tools", "bench_verify.py")
     for name, extra in (("short_reads", ["--reads", "1000000", "--len", "300"]),
+                        ("short_reads_150", ["--reads", "1000000", "--len", "150"]),
                         ("long_reads", ["--reads", "20000", "--len", "10000", "--indel-rate", "0.1", "--sub", "0.03"])):
         try:
-            out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bench_verify.py"), "--cpu-sample", "0", "--repeat", "2"] + extra,
-                                 capture_output=True, text=True, timeout=300, check=True).stdout
+            cmd = [sys.executable, tool, "--cpu-sample", "0", "--repeat", "2"] + extra
+            out = subprocess.run(cmd, capture_output=True, text=True, timeout=300, check=True).stdout
             d = json.loads(out.strip().splitlines()[-1])
             leg[name] = {"alignments": d["config"]["alignments"], "query_len": d["config"]["query_len"], "text_len": d["config"]["text_len"],
                          "ms_kernels": d["ms_kernels"], "value": d["cell_updates_per_s"], "alignments_per_s": d["value"],
                          "mean_edits": d["mean_edits"]}
+            cells = d["cell_updates_per_s"] * d["ms_kernels"] * 1e-3
+            valu = live_pmc_counter(cmd, "SQ_INSTS_VALU", "bmv_align", log) if pmc else None
+            if valu:
+                per_call = valu["sum"] / 2                                # --repeat 2: two identical calls
+                ach = per_call / (d["ms_kernels"] * 1e-3) / 1e9
+                leg[name]["roofline"] = {
+                    "bound": "valu_issue", "achieved": ach, "peak": VALU_ISSUE_PEAK_GINST, "unit": "G wave-instructions/s",
+                    "frac": ach / VALU_ISSUE_PEAK_GINST, "valu_wave_instructions_per_call": per_call,
+                    "valu_wave_instructions_per_cell": per_call / cells, "cells_per_call": cells,
+                    "cycles_per_instruction_and_simd": 256 * 4 * 2.4e9 * d["ms_kernels"] * 1e-3 / per_call,
+                    "source": f"live: rocprofv3 --pmc SQ_INSTS_VALU child of tools/bench_verify.py, bmv_align* kernels, "
+                              f"{valu['dispatches']} dispatches / 2 calls; kernel time from the un-profiled run",
+                    "note": "wave64 on SIMD-32: 2 cycles per VALU instruction is the issue peak; this kernel's 64-bit integer "
+                            "shifts, adds with carry and v_alignbit sustain about 4 (DESIGN.md 4.4)"}
         except (subprocess.SubprocessError, ValueError, KeyError, IndexError) as e:
             leg[name] = {"error": str(e)[:300]}
     leg["seconds"] = time.perf_counter() - t0
-    log("verifier leg: " + ", ".join(f"{k} {v['value'] / 1e12:.1f} T cell updates/s ({v['ms_kernels']:.2f} ms)"
+    log("verifier leg: " + ", ".join(f"{k} {v['value'] / 1e12:.1f} T cell updates/s ({v['ms_kernels']:.2f} ms"
+                                     + (f", {v['roofline']['frac']:.2f} of VALU issue" if "roofline" in v else "") + ")"
                                      for k, v in leg.items() if isinstance(v, dict) and "value" in v) + f", {leg['seconds']:.0f} s")
     return leg
+
+
+def live_pmc_counter(cmd, counter, kernel_substr, log):
+    """Runs `cmd` under `rocprofv3 --pmc <counter>` (a pass of its own: no tracing) and returns {"sum", "dispatches"} of the
+    counter over the kernels whose name contains `kernel_substr`; None when the profiler is not usable here."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    if under_profiler():
+        return None
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None
+    out = tempfile.mkdtemp(prefix="bm_pmc_", dir="/tmp")
+    try:
+        r = subprocess.run([exe, "--pmc", counter, "--output-format", "csv", "-d", out, "--"] + cmd, cwd="/tmp",
+                           env={**os.environ, "TMPDIR": "/tmp"}, capture_output=True, text=True, timeout=600)
+        files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
+        if r.returncode != 0 or not files:
+            log(f"pmc child ({counter}) failed (rc {r.returncode}): {r.stderr[-300:]}")
+            return None
+        vals = [float(row["Counter_Value"]) for row in csv.DictReader(open(max(files, key=os.path.getmtime)))
+                if row["Counter_Name"] == counter and kernel_substr in row["Kernel_Name"]]
+        return {"sum": sum(vals), "dispatches": len(vals)} if vals else None
+    except (OSError, ValueError, KeyError, subprocess.SubprocessError) as e:
+        log(f"pmc child ({counter}) failed: {e}")
+        return None
+    finally:
+        shutil.rmtree(out, ignore_errors=True)
 
 
 def under_profiler():
@@ -428,6 +604,8 @@ def main():
                          "that the roofline line prices exactly the reference's row reads)")
     ap.add_argument("--no-pruned-leg", action="store_true", help="skip the extra BMF_FLAG_EARLY_EXIT measurement")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the `skewed`, `roofline_large_index` and `verifier` legs (N = 1 only anyway)")
+    ap.add_argument("--no-locator-leg", action="store_true", help="skip the `locator` legs (bml_locate over the batch's candidates)")
+    ap.add_argument("--locator-cpu-seconds", type=float, default=8.0, help="CPU time of the locator oracle sample per leg (0 = skip)")
     ap.add_argument("--skewed-parity-reads", type=int, default=50000, help="reads of the skewed leg checked against the oracle")
     ap.add_argument("--large-index-reads", type=int, default=500000, help="reads per step of the large-index leg")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -684,6 +862,11 @@ def main():
     # every GPU resource of the headline is released before the other legs and the profiler child start
     batch.close()
     flt.close()
+    if rank == 0 and world == 1 and not args.no_locator_leg and not args.no_extra_legs:
+        try:
+            result["locator"] = locator_leg(inp, cli, device, counts, buckets, min(args.steps, 3), args.locator_cpu_seconds, log)
+        except Exception as e:                                 # an optional leg must not cost the headline record
+            result["locator"] = {"error": f"{type(e).__name__}: {e}"[:400]}
     del inp, reads, genome, index
 
     if rank == 0:
@@ -709,12 +892,20 @@ def main():
                         result["roofline"]["traffic_source"] = "NOT measured in this run; committed pass " + e["source"]
             except (OSError, ValueError, KeyError):
                 pass
+        def guarded(name, fn, *a):
+            """An optional leg: its failure (out of memory on a shared card, an import error) is recorded under its key and
+            never costs the headline, roofline and cpu_baseline already measured."""
+            try:
+                result[name] = fn(*a)
+            except Exception as e:
+                result[name] = {"error": f"{type(e).__name__}: {e}"[:400]}
+                log(f"{name} leg failed: {result[name]['error']}")
         if extra and args.genome_profile == "uniform":
-            result["skewed"] = skewed_leg(args, device, cli, k2i, threads, log)
+            guarded("skewed", skewed_leg, args, device, cli, k2i, threads, log)
         if extra and args.workload == "egu" and not args.total_bp and not args.bucket_len:
-            result["roofline_large_index"] = large_index_leg(args, device, k2i, threads, log)
+            guarded("roofline_large_index", large_index_leg, args, device, k2i, threads, log)
         if extra and args.workload == "egu" and not args.total_bp and not args.bucket_len:
-            result["verifier"] = verifier_leg(log)
+            guarded("verifier", verifier_leg, log, not args.no_pmc)
         print(json.dumps(result), flush=True)
 
     if world > 1:

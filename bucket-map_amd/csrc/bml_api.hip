@@ -1,7 +1,7 @@
 // bml_api.hip -- C ABI (include/bml.h) over the locator-scan kernels in bml_kernels.hip.h.
 // Host side only: chunking of candidates per bucket, buffers, the two replay kernels (one thread or one workgroup per
 // candidate) and the automatic re-run when the occurrence buffer was too small.  No device-wide sort: the scan kernel
-// writes every candidate's occurrences to a segment of their own.
+// writes every candidate's occurrences to a segment of their own, grouped by sample.
 #include "bml_kernels.hip.h"
 #include "bm_hip_util.h"
 
@@ -14,6 +14,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
 #include <vector>
 
 namespace {
@@ -77,7 +78,7 @@ struct bml_ctx {
     uint32_t n_buckets = 0;
     std::vector<uint32_t> h_bucket_len;
     DevBuf<uint8_t> genome, lut, pair_rc;
-    DevBuf<uint64_t> bucket_start, occ_a, occ_b, cand_start;
+    DevBuf<uint64_t> bucket_start, occ_a, cand_start;
     DevBuf<uint32_t> bucket_len, sample_hash, seg_len, pair_window, out_votes;
     DevBuf<uint32_t> cand_count, heavy, n_heavy, heavy_votes, heavy_bitmaps;
     double occ_per_pair = 0;                     // k-mer occurrences per candidate the batches so far needed (sizes the next buffer)
@@ -94,7 +95,7 @@ struct bml_ctx {
     uint32_t s_table_len = 0;        // windows up to this length are tabulated
     DevBuf<unsigned long long> occ_count;
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // scan | (gap) | light replay | heavy replay
-    float ms[3] = {0, 0, 0};
+    float ms[3] = {0, 0, 0};         // scan kernels | host time between and around the kernels | replay kernels
     uint64_t last_occ = 0;
 };
 
@@ -111,8 +112,8 @@ int bml_create(const bml_params *params, bml_ctx **out) {
     if (p.max_bucket_bases == 0) return fail(BML_ERR_ARG, "max_bucket_bases must be > 0");
     if (p.max_bucket_bases >= (1u << 20)) return fail(BML_ERR_UNSUPPORTED, "buckets of 2^20 bases or more are not supported");   // 20-bit offsets in the light replay's sort keys
     const uint32_t max_words = (p.max_bucket_bases + 15u) / 16u;
-    const uint32_t max_pairs = (bml::kTableSlots / 2) / p.num_samples;
-    const size_t lds = bml::scan_lds_bytes(max_words, max_pairs);
+    const uint32_t max_pairs = bml::kMaxTargets / p.num_samples;
+    const size_t lds = bml::scan_lds_bytes(max_words);
     if (lds > 160 * 1024) return fail(BML_ERR_UNSUPPORTED, "buckets of %u bases do not fit the 160 KiB LDS", p.max_bucket_bases);
     int n_dev = 0;
     HIP_TRY(hipGetDeviceCount(&n_dev));
@@ -136,7 +137,7 @@ int bml_create(const bml_params *params, bml_ctx **out) {
     build_dna4_lut(lut);
     if (e == hipSuccess) e = c->lut.need(256);
     if (e == hipSuccess) e = hipMemcpy(c->lut.p, lut, 256, hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = c->occ_count.need(1);
+    if (e == hipSuccess) e = c->occ_count.need(2);
     if (e == hipSuccess) e = c->n_heavy.need(3);
     if (e == hipSuccess) (void)hipDeviceGetAttribute(&c->n_cu, hipDeviceAttributeMultiprocessorCount, p.device);
     if (c->n_cu <= 0) c->n_cu = 256;
@@ -153,7 +154,7 @@ void bml_destroy(bml_ctx *c) {
     (void)hipSetDevice(c->p.device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     c->genome.release(); c->lut.release(); c->pair_rc.release();
-    c->bucket_start.release(); c->occ_a.release(); c->occ_b.release(); c->cand_start.release();
+    c->bucket_start.release(); c->occ_a.release(); c->cand_start.release();
     c->cand_count.release(); c->heavy.release(); c->n_heavy.release(); c->heavy_votes.release();
     c->heavy_bitmaps.release();
     c->bucket_len.release(); c->sample_hash.release(); c->seg_len.release(); c->pair_window.release();
@@ -316,18 +317,25 @@ int bml_locate(bml_ctx *c, const uint32_t *sample_hash, const uint16_t *sample_p
     c->last_occ = 0;
     c->last_heavy = 0;
 
-    // placed: the candidates' segments are where the scan before this one put them (it found the buffer too small): only write
+    const auto t_begin = std::chrono::steady_clock::now();
+    HIP_TRY(hipMemsetAsync(c->occ_count.p, 0, 2 * sizeof(unsigned long long), c->stream));
+    // placed: the candidates' segments are where the scan before this one put them (it found the buffer too small, or the
+    // host placed a group's segments from its counts): the kernel recounts -- counting costs it one pass over the bucket,
+    // not one step per occurrence -- checks its counts against the segments it was given, and writes
     auto scan = [&](size_t chunk_lo, size_t chunk_hi, unsigned long long cap, unsigned long long *n_occ, bool placed = false) -> int {
         HIP_TRY(c->occ_a.need((size_t)cap));
         if (!placed) HIP_TRY(hipMemsetAsync(c->occ_count.p, 0, sizeof(unsigned long long), c->stream));
         HIP_TRY(hipEventRecord(c->ev[0], c->stream));
         hipLaunchKernelGGL(bml::bml_scan_kernel, dim3((unsigned)(chunk_hi - chunk_lo)), dim3(bml::kScanThreads), c->scan_lds, c->stream,
-                           c->lp, c->genome.p, c->bucket_start.p, c->bucket_len.p, c->lut.p, c->chunks.p + chunk_lo, c->sample_hash.p,
+                           c->lp, c->genome.p, c->bucket_start.p, c->bucket_len.p, c->chunks.p + chunk_lo, c->sample_hash.p,
                            c->pair_window.p, c->pair_rc.p, c->occ_a.p, c->occ_count.p, cap, c->cand_start.p, c->cand_count.p, placed ? 1u : 0u);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(c->ev[1], c->stream));
-        HIP_TRY(hipMemcpyAsync(n_occ, c->occ_count.p, sizeof *n_occ, hipMemcpyDeviceToHost, c->stream));
+        unsigned long long state[2] = {0, 0};
+        HIP_TRY(hipMemcpyAsync(state, c->occ_count.p, sizeof state, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
+        *n_occ = state[0];
+        if (state[1]) return fail(BML_ERR_HIP, "a scan's recount disagrees with the segments it was given");
         float ms = 0.f;
         HIP_TRY(hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
         c->ms[0] += ms;
@@ -372,11 +380,11 @@ int bml_locate(bml_ctx *c, const uint32_t *sample_hash, const uint16_t *sample_p
             // as many workgroups as the CUs hold at once (LDS decides: 1 per CU at 262 144-base buckets, 6 at 65 536)
             const uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(8, (size_t)(156 * 1024) / (lds + 1024)));
             const unsigned grid = (unsigned)std::min<uint32_t>(n_heavy, per_cu * (uint32_t)c->n_cu);
-            HIP_TRY(c->heavy_votes.need((size_t)grid * 2 * range));
+            // a candidate makes at most one proposal per start position and at most one per occurrence
+            const uint32_t vote_stride = std::min(range, heavy_info[1]);
+            HIP_TRY(c->heavy_votes.need((size_t)grid * 2 * vote_stride));
             if (!in_lds) HIP_TRY(c->heavy_bitmaps.need((size_t)grid * 3 * words));
-            // the heavy candidates group their occurrences by sample in a second buffer
-            HIP_TRY(c->occ_b.need((size_t)n_occ));
-            const bml::HeavyScratch hs{c->heavy_votes.p, c->heavy_bitmaps.p, c->occ_b.p};
+            const bml::HeavyScratch hs{c->heavy_votes.p, c->heavy_bitmaps.p, vote_stride};
             HIP_TRY(hipEventRecord(c->ev[5], c->stream));        // (the allocations above are not replay time)
             hipLaunchKernelGGL(bml::bml_replay_heavy_kernel, dim3(grid), dim3(bml::kThreads), lds, c->stream, c->lp, c->occ_a.p,
                                c->cand_start.p, c->cand_count.p, c->sample_pos.p, c->seg_len.p, c->pair_window.p, c->pair_rc.p, c->heavy.p,
@@ -406,9 +414,11 @@ int bml_locate(bml_ctx *c, const uint32_t *sample_hash, const uint16_t *sample_p
     c->last_occ = n_occ;
     c->occ_per_pair = std::max(0.5 * c->occ_per_pair, (double)n_occ / (double)std::max<uint32_t>(n_pairs, 1u));
     if (n_occ > cap && n_occ <= budget) {                       // too small, but one buffer will do: grow it and scan again
+        // (with the quarter of headroom the next batch's estimate will ask for: growing a 10 GB buffer a second time costs
+        // hundreds of milliseconds of hipFree + hipMalloc)
+        HIP_TRY(c->occ_a.need((size_t)std::min<unsigned long long>(budget, n_occ + n_occ / 4)));
         cap = n_occ;
         if (int rc = scan(0, chunks.size(), cap, &n_occ, true)) return rc;
-        if (n_occ != cap) return fail(BML_ERR_HIP, "the occurrence count changed between the scans");
     }
     if (n_occ <= cap) {
         if (int rc = replay(0, n_pairs, n_occ)) return rc;
@@ -445,16 +455,18 @@ int bml_locate(bml_ctx *c, const uint32_t *sample_hash, const uint16_t *sample_p
             lo = hi;
         }
     }
+    // what the call spent outside its kernels from the first scan on: syncs, the count downloads, buffer growth, group placement
+    c->ms[1] = std::max(0.f, std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_begin).count() - c->ms[0] - c->ms[2]);
     HIP_TRY(hipMemcpyAsync(out_offset, c->out_offset.p, (size_t)n_pairs * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipMemcpyAsync(out_votes, c->out_votes.p, (size_t)n_pairs * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return BML_OK;
 }
 
-int bml_last_stats(bml_ctx *c, float *ms_scan, float *ms_sort, float *ms_replay, uint64_t *n_occurrences) {
+int bml_last_stats(bml_ctx *c, float *ms_scan, float *ms_host, float *ms_replay, uint64_t *n_occurrences) {
     if (!c) return fail(BML_ERR_ARG, "bml_last_stats: null context");
     if (ms_scan) *ms_scan = c->ms[0];
-    if (ms_sort) *ms_sort = c->ms[1];
+    if (ms_host) *ms_host = c->ms[1];
     if (ms_replay) *ms_replay = c->ms[2];
     if (n_occurrences) *n_occurrences = c->last_occ;
     return BML_OK;

@@ -1,16 +1,23 @@
 // bml_kernels.hip.h -- gfx950 kernels of the locator candidate scan (include/bml.h).
 //
-//   bml_scan_kernel   : one 256-thread workgroup per (bucket, chunk of <= max_pairs candidates).  Packs the
-//                       bucket to 2 bits/base in LDS, hashes the k-mers the chunk's candidates ask for
-//                       into an LDS open-addressing table, scans every k-mer of the bucket against the
-//                       table and emits (target, offset) occurrences -- the work the reference does by
-//                       building an unordered_multimap of ALL k-mers per bucket
-//                       (bucket_locator.h:162-177) and calling equal_range per sample (:246).
-//                       A candidate belongs to ONE chunk, so the workgroup counts its candidates' occurrences,
-//                       reserves one stretch of the occurrence buffer and writes every candidate's occurrences
-//                       to a segment of their own in it (from the LDS staging area; a chunk with more occurrences
-//                       than that holds -- repeats -- scans its bucket a second time and writes them directly).
-//                       No device-wide sort or grouping pass: the order inside a segment is settled per candidate.
+//   bml_scan_kernel   : one 1 024-thread workgroup per (bucket, chunk of <= max_pairs candidates).  Packs the
+//                       bucket to 2 bits/base in LDS and puts the DISTINCT k-mers the chunk's candidates ask for into
+//                       an LDS open-addressing table (+ a presence filter).  The work the reference does by building an
+//                       unordered_multimap of ALL k-mers per bucket (bucket_locator.h:162-177) and calling equal_range
+//                       per sample (:246) is a join of the bucket's k-mers with the chunk's targets; its size (the
+//                       occurrences) is unbounded in repeats -- a sampled k-mer of a satellite occurs 1 500 times in a
+//                       bucket and a hundred candidates ask for it -- so nothing here is done once per occurrence
+//                       except the one coalesced store that writes it:
+//                         sweep 1  every k-mer of the bucket: filter, table; COUNT per distinct k-mer (O(bucket));
+//                         layout   a target (candidate, sample) has as many occurrences as its k-mer was counted:
+//                                  exclusive prefix over the <= 2 048 targets = every candidate's count and segment,
+//                                  one atomic add reserves the chunk's stretch of the occurrence buffer;
+//                         sweep 2  every k-mer of the bucket again: its rank among its equals, and ONE store -- into the
+//                                  list of the first target that asked for it (O(bucket));
+//                         copy     every other target with that k-mer copies the list (a wave per list, 512-byte
+//                                  stores; a workgroup for long lists) and puts its own id in the keys.
+//                       A candidate's segment comes out grouped by sample, in processing order (inside a group: any
+//                       order).  No counting per occurrence, no second walk of the table per occurrence, no LDS staging.
 //   bml_replay_light_kernel : one thread per candidate with at most kLightMax occurrences: orders them by
 //                       (sample in processing order, offset descending) -- the order libstdc++'s equal_range
 //                       yields equal keys -- and replays _find_offset's order-dependent vote
@@ -33,12 +40,18 @@ constexpr int kThreads = 256;        // replay kernel
 constexpr int kScanThreads = 1024;   // scan kernel: its loops are chains of dependent LDS reads, and the 66 KB of
                                      // LDS per workgroup allow two workgroups per CU -- 16 waves each hide the latency
                                      // that 4 waves each did not (6.96 -> 2.70 ms per 1 M candidates)
-constexpr uint32_t kTableSlots = 4096;        // LDS open-addressing table (targets of one chunk)
-constexpr uint32_t kLdsOcc = 2048;            // occurrences staged in LDS per workgroup
+constexpr uint32_t kTableSlots = 4096;        // LDS open-addressing table: the distinct k-mers one chunk asks for
+constexpr uint32_t kMaxTargets = kTableSlots / 2;   // (candidate, sample) pairs per chunk: the table stays at most half full
+constexpr uint32_t kSpecialSlot = kTableSlots;      // slot of the one hash that equals kEmpty (k = 16: TTTTTTTTTTTTTTTT)
+constexpr uint32_t kTableAlloc = kTableSlots + 4;
 constexpr uint32_t kEmpty = 0xFFFFFFFFu;
+constexpr uint32_t kNone = 0xFFFFFFFFu;
 constexpr uint32_t kFilterWords = 2048;       // 64 Kbit presence filter in front of the table: a bucket has 65 825 k-mers
                                               // and a chunk asks for at most 2 040 of all 4^k, so 97 % of the scan's
                                               // probes end at ONE LDS read instead of walking a half-full table
+constexpr uint32_t kLongList = 1024;          // occurrence lists from this length on are copied by the whole workgroup
+constexpr uint32_t kStage = 896;              // asked-for k-mers of the bucket that sweep 1 remembers (slot << 20 | offset): a chunk
+                                              // outside repeats has a few hundred, and its sweep 2 is a walk of this list
 
 struct Chunk {
     uint32_t bucket;
@@ -50,12 +63,22 @@ struct LocParams {
     uint32_t k, p;
     int32_t allowed_mismatch, allowed_indel;
     uint32_t max_words;        // LDS words reserved for the packed bucket
-    uint32_t max_pairs;        // most candidates a chunk holds
+    uint32_t max_pairs;        // most candidates a chunk holds: max_pairs * p <= kMaxTargets
 };
 
-__host__ __device__ inline size_t scan_lds_bytes(uint32_t max_words, uint32_t max_pairs) {
-    return (size_t)kLdsOcc * 8 + 16 + (size_t)kFilterWords * 4 + (size_t)kTableSlots * 8 + (size_t)((2u * max_pairs + 3u) & ~3u) * 4 +
-           ((size_t)max_words + 4) * 4;
+// LDS layout of the scan (all dynamic, 16-byte aligned base):
+//   header 128 B: gbase u64 | total u32 | n_short u32 | n_long u32 | n_stage u32 | ... | wsum[16] u32 at byte 64
+//   filter[kFilterWords] u32          (after sweep 2: short_list u16[kMaxTargets] | long_list u16[kMaxTargets])
+//   tkey[kTableAlloc] u32             the distinct k-mers (kEmpty = free)
+//   tcnt[kTableAlloc] u32             occurrences of each in the bucket (sweep 2 counts it down again)
+//   thead[kTableAlloc] u16            the first target that asked for it: the owner of the list
+//   tstart[kMaxTargets + 4] u32       exclusive prefix of the targets' occurrence counts (relative to gbase)
+//   tslot[kMaxTargets] u16            every target's table slot
+//   stage[kStage] u32                 the asked-for k-mers sweep 1 met, while they fit
+//   packed[max_words + 4] u32
+__host__ __device__ inline size_t scan_lds_bytes(uint32_t max_words) {
+    return 128 + (size_t)kFilterWords * 4 + (size_t)kTableAlloc * (4 + 4 + 2) + (size_t)(kMaxTargets + 4) * 4 + (size_t)kMaxTargets * 2 +
+           (size_t)kStage * 4 + ((size_t)max_words + 4) * 4;
 }
 
 __device__ __forceinline__ uint32_t filter_bit(uint32_t h) { return (h * 2246822519u) >> 16; }   // 16 bits
@@ -72,37 +95,43 @@ __device__ __forceinline__ uint32_t hash_reverse_complement(uint32_t h, uint32_t
 
 __device__ __forceinline__ uint32_t slot_of(uint32_t h) { return (h * 2654435761u) >> 20; }   // 12 bits
 
-// LDS layout (all dynamic, 16-byte aligned base): locc[kLdsOcc] u64 | gbase u64 | lds_cnt u32 (+pad) |
-//                       filter[kFilterWords] u32 | tkey[kTableSlots] u32 | ttgt[kTableSlots] u32 |
-//                       pcnt[max_pairs] u32 (occurrences per candidate of the chunk, then their first place) |
-//                       pfill[max_pairs] u32 | packed[max_words + 4] u32
+// occ_count[0]: occurrences reserved so far; occ_count[1]: set when a `placed` scan's recount disagrees with the segments
+// it was given (never expected: the host checks it after every scan).
 __global__ __launch_bounds__(kScanThreads) void bml_scan_kernel(
     LocParams P, const uint8_t *__restrict__ genome, const uint64_t *__restrict__ bucket_start,
-    const uint32_t *__restrict__ bucket_len, const uint8_t *__restrict__ dna4_lut, const Chunk *__restrict__ chunks,
+    const uint32_t *__restrict__ bucket_len, const Chunk *__restrict__ chunks,
     const uint32_t *__restrict__ sample_hash, const uint32_t *__restrict__ pair_window,
     const uint8_t *__restrict__ pair_rc, uint64_t *__restrict__ occ_keys, unsigned long long *__restrict__ occ_count,
     unsigned long long occ_cap, uint64_t *__restrict__ cand_start, uint32_t *__restrict__ cand_count, uint32_t placed) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    uint64_t *locc = reinterpret_cast<uint64_t *>(smem);
-    unsigned long long &gbase = *reinterpret_cast<unsigned long long *>(locc + kLdsOcc);
-    uint32_t &lds_cnt = *reinterpret_cast<uint32_t *>(locc + kLdsOcc + 1);
-    uint32_t *filter = reinterpret_cast<uint32_t *>(locc + kLdsOcc + 2);
+    unsigned long long &gbase = *reinterpret_cast<unsigned long long *>(smem);
+    uint32_t &total = *reinterpret_cast<uint32_t *>(smem + 8);
+    uint32_t &n_short = *reinterpret_cast<uint32_t *>(smem + 12);
+    uint32_t &n_long = *reinterpret_cast<uint32_t *>(smem + 16);
+    uint32_t *wsum = reinterpret_cast<uint32_t *>(smem + 64);
+    uint32_t *filter = reinterpret_cast<uint32_t *>(smem + 128);
     uint32_t *tkey = filter + kFilterWords;
-    uint32_t *ttgt = tkey + kTableSlots;
-    uint32_t *pcnt = ttgt + kTableSlots;
-    uint32_t *pfill = pcnt + P.max_pairs;
-    uint32_t *packed = pcnt + ((2u * P.max_pairs + 3u) & ~3u);
-    (void)dna4_lut;
+    uint32_t *tcnt = tkey + kTableAlloc;
+    uint16_t *thead = reinterpret_cast<uint16_t *>(tcnt + kTableAlloc);
+    uint32_t *tstart = reinterpret_cast<uint32_t *>(thead + kTableAlloc);
+    uint16_t *tslot = reinterpret_cast<uint16_t *>(tstart + kMaxTargets + 4);
+    uint32_t *stage = reinterpret_cast<uint32_t *>(tslot + kMaxTargets);
+    uint32_t *packed = stage + kStage;
+    uint32_t &n_stage = *reinterpret_cast<uint32_t *>(smem + 20);
+    uint16_t *short_list = reinterpret_cast<uint16_t *>(filter), *long_list = short_list + kMaxTargets;   // (after sweep 2)
 
     const Chunk ch = chunks[blockIdx.x];
-    const uint32_t tid = threadIdx.x;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t nb = bucket_len[ch.bucket];
     const uint64_t start = bucket_start[ch.bucket];
+    const uint32_t n_t = ch.pair_count * P.p;                    // <= kMaxTargets (the host cuts the chunks so)
 
-    if (tid == 0) lds_cnt = 0;
-    for (uint32_t s = tid; s < kTableSlots; s += kScanThreads) ttgt[s] = kEmpty;
+    if (tid == 0) n_short = n_long = n_stage = 0;
+    for (uint32_t s = tid; s < kTableAlloc; s += kScanThreads) {
+        tkey[s] = kEmpty;
+        tcnt[s] = 0;
+    }
     for (uint32_t s = tid; s < kFilterWords; s += kScanThreads) filter[s] = 0;
-    for (uint32_t s = tid; s < ch.pair_count; s += kScanThreads) pcnt[s] = pfill[s] = 0;
 
     // 2-bit packing, first base in the most significant bits of each word: one aligned 16-byte load per stream
     // word (the bucket may start at any byte: the stream starts at the aligned chunk that holds its first base,
@@ -120,8 +149,7 @@ __global__ __launch_bounds__(kScanThreads) void bml_scan_kernel(
         packed[w] = word;
     }
     __syncthreads();
-    // the k-mers this chunk's candidates ask for: target t = (candidate, i-th processed sample)
-    const uint32_t n_t = ch.pair_count * P.p;
+    // the k-mers this chunk's candidates ask for: target t = (candidate, i-th processed sample); equal k-mers share a slot
     for (uint32_t t = tid; t < n_t; t += kScanThreads) {
         const uint32_t pair = ch.pair_begin + t / P.p, i = t % P.p;
         const uint32_t w = pair_window[pair];
@@ -129,89 +157,151 @@ __global__ __launch_bounds__(kScanThreads) void bml_scan_kernel(
         // bucket_locator.h:235-242: reverse-complement candidates start from the last sample
         uint32_t h = sample_hash[(size_t)w * P.p + (rc ? P.p - 1u - i : i)];
         if (rc) h = hash_reverse_complement(h, P.k);
-        uint32_t slot = slot_of(h);
-        while (atomicCAS(&ttgt[slot], kEmpty, t) != kEmpty) slot = (slot + 1u) & (kTableSlots - 1u);
-        tkey[slot] = h;
+        uint32_t slot;
+        if (h == kEmpty) {                                       // cannot be told from a free slot: a slot of its own
+            slot = kSpecialSlot;
+            if (atomicCAS(&tkey[slot], kEmpty, 0u) == kEmpty) thead[slot] = (uint16_t)t;
+        } else {
+            slot = slot_of(h);
+            for (;;) {
+                const uint32_t old = atomicCAS(&tkey[slot], kEmpty, h);
+                if (old == kEmpty) thead[slot] = (uint16_t)t;    // the first to ask for it owns the list
+                if (old == kEmpty || old == h) break;
+                slot = (slot + 1u) & (kTableSlots - 1u);
+            }
+        }
+        tslot[t] = (uint16_t)slot;
         const uint32_t fb = filter_bit(h);
         atomicOr(&filter[fb >> 5], 1u << (fb & 31u));
     }
     __syncthreads();
 
-    // scan every k-mer of the bucket (bucket_locator.h:172-176 enumerates the same k-mers); found(t, j) for every
-    // k-mer j that target t asked for
+    // every k-mer of the bucket (bucket_locator.h:172-176 enumerates the same k-mers): hit(slot, j) for every k-mer j
+    // that somebody asked for
     const uint32_t nk = nb >= P.k ? nb - P.k + 1u : 0u;
     const uint32_t kmask = P.k >= 16 ? 0xFFFFFFFFu : ((1u << (2u * P.k)) - 1u);
-    auto scan_bucket = [&](auto found) {
+    auto sweep = [&](auto hit) {
         for (uint32_t j = tid; j < nk; j += kScanThreads) {
             const uint32_t at = shift + j;
             const uint64_t two = ((uint64_t)packed[at >> 4] << 32) | packed[(at >> 4) + 1];
             const uint32_t h = (uint32_t)(two >> (64u - 2u * (at & 15u) - 2u * P.k)) & kmask;
             const uint32_t fb = filter_bit(h);
             if (!((filter[fb >> 5] >> (fb & 31u)) & 1u)) continue;          // nobody asked for this k-mer
-            uint32_t slot = slot_of(h), t;
-            while ((t = ttgt[slot]) != kEmpty) {
-                if (tkey[slot] == h) found(t, j);
-                slot = (slot + 1u) & (kTableSlots - 1u);
+            uint32_t slot;
+            if (h == kEmpty) {
+                slot = tkey[kSpecialSlot] != kEmpty ? kSpecialSlot : kNone;
+            } else {
+                slot = slot_of(h);
+                for (;;) {
+                    const uint32_t key = tkey[slot];
+                    if (key == h) break;
+                    if (key == kEmpty) {
+                        slot = kNone;
+                        break;
+                    }
+                    slot = (slot + 1u) & (kTableSlots - 1u);
+                }
             }
+            if (slot != kNone) hit(slot, j);
         }
     };
-    auto key_of = [&](uint32_t t, uint32_t j) {                             // (target, offset descending)
-        return ((uint64_t)((ch.pair_begin + t / P.p) * P.p + t % P.p) << 32) | (uint32_t)(0x7FFFFFFFu - j);
-    };
-    if (placed) {
-        // A scan before this one has counted the candidates' occurrences and placed their segments (cand_start, cand_count),
-        // but the buffer was too small to take them: this one only writes -- one pass over the bucket, no counting.
-        const uint64_t base = cand_start[ch.pair_begin];
-        for (uint32_t c = tid; c < ch.pair_count; c += kScanThreads) pcnt[c] = (uint32_t)(cand_start[ch.pair_begin + c] - base);
-        __syncthreads();
-        scan_bucket([&](uint32_t t, uint32_t j) {
-            const uint32_t c = t / P.p;
-            occ_keys[base + pcnt[c] + atomicAdd(&pfill[c], 1u)] = key_of(t, j);
-        });
-        return;
-    }
-    scan_bucket([&](uint32_t t, uint32_t j) {
-        atomicAdd(&pcnt[t / P.p], 1u);
-        const uint32_t at_l = atomicAdd(&lds_cnt, 1u);
-        if (at_l < kLdsOcc) locc[at_l] = key_of(t, j);
+    sweep([&](uint32_t slot, uint32_t j) {
+        atomicAdd(&tcnt[slot], 1u);
+        // remembered for sweep 2 while the list has room (one LDS atomic per wave and step, not per k-mer)
+        const uint64_t m = __ballot(1), special = __ballot(slot == kSpecialSlot);   // (the special slot does not fit an entry:
+        const int leader = __builtin_ctzll(m);                                      //  its k-mers make the list overflow)
+        uint32_t at = 0;
+        if ((int)lane == leader) at = atomicAdd(&n_stage, (uint32_t)__popcll(m) + (special ? kStage + 1u : 0u));
+        at = (uint32_t)__shfl((int)at, leader, 64) + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        if (at < kStage && slot != kSpecialSlot) stage[at] = (slot << 20) | j;
     });
     __syncthreads();
-    // one stretch of the occurrence buffer for the chunk, one segment in it per candidate
-    const uint32_t total = lds_cnt;
-    if (tid == 0) gbase = atomicAdd(occ_count, (unsigned long long)total);
-    if (tid < 64) {                                                         // exclusive prefix of pcnt, one wave
-        uint32_t carry = 0;
-        for (uint32_t c0 = 0; c0 < ch.pair_count; c0 += 64) {
-            const uint32_t c = c0 + tid, v = c < ch.pair_count ? pcnt[c] : 0u;
-            uint32_t incl = v;
+
+    // layout: tstart = exclusive prefix of the targets' counts (two targets a thread, a wave scan, the 16 wave totals)
+    {
+        const uint32_t t0 = 2u * tid, t1 = t0 + 1u;
+        const uint32_t v0 = t0 < n_t ? tcnt[tslot[t0]] : 0u, v1 = t1 < n_t ? tcnt[tslot[t1]] : 0u;
+        uint32_t incl = v0 + v1;
 #pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                const uint32_t u = __shfl_up(incl, o, 64);
-                if (tid >= (uint32_t)o) incl += u;
-            }
-            if (c < ch.pair_count) {
-                cand_count[ch.pair_begin + c] = v;
-                pcnt[c] = carry + incl - v;
-            }
-            carry += (uint32_t)__shfl((int)incl, 63, 64);
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t u = __shfl_up(incl, o, 64);
+            if (lane >= (uint32_t)o) incl += u;
+        }
+        if (lane == 63u) wsum[wave] = incl;
+        __syncthreads();
+        uint32_t before = 0;
+        for (uint32_t w = 0; w < wave; w++) before += wsum[w];
+        const uint32_t excl = before + incl - (v0 + v1);
+        tstart[t0] = excl;
+        tstart[t1] = excl + v0;
+        if (tid == kScanThreads - 1u) {
+            tstart[kMaxTargets] = before + incl;
+            total = before + incl;
         }
     }
     __syncthreads();
-    const bool fits = gbase + total <= occ_cap;                            // else the host grows the buffer and scans again
-    for (uint32_t c = tid; c < ch.pair_count; c += kScanThreads) cand_start[ch.pair_begin + c] = gbase + pcnt[c];
-    if (!fits) return;
-    if (total <= kLdsOcc) {
-        for (uint32_t i = tid; i < total; i += kScanThreads) {
-            const uint64_t key = locc[i];
-            const uint32_t c = (uint32_t)(key >> 32) / P.p - ch.pair_begin;
-            occ_keys[gbase + pcnt[c] + atomicAdd(&pfill[c], 1u)] = key;
+    // one stretch of the occurrence buffer for the chunk, one segment in it per candidate (a candidate belongs to ONE chunk)
+    if (tid == 0) gbase = placed ? (unsigned long long)cand_start[ch.pair_begin] : atomicAdd(occ_count, (unsigned long long)total);
+    __syncthreads();
+    const unsigned long long base = gbase;
+    for (uint32_t c = tid; c < ch.pair_count; c += kScanThreads) {
+        const uint32_t first = tstart[c * P.p], count = tstart[(c + 1u) * P.p] - first;
+        if (placed) {
+            // the scan before this one counted the same occurrences and the host placed the segments from its counts
+            if (cand_count[ch.pair_begin + c] != count || cand_start[ch.pair_begin + c] != base + first) occ_count[1] = 1ull;
+        } else {
+            cand_count[ch.pair_begin + c] = count;
+            cand_start[ch.pair_begin + c] = base + first;
         }
-    } else {                                                               // repeats: more than the staging area holds
-        scan_bucket([&](uint32_t t, uint32_t j) {
-            const uint32_t c = t / P.p;
-            occ_keys[gbase + pcnt[c] + atomicAdd(&pfill[c], 1u)] = key_of(t, j);
-        });
     }
+    if (total == 0u || base + total > occ_cap) return;                     // (too small: the host grows the buffer and scans again)
+
+    // sweep 2: the rank of every asked-for k-mer among its equals, and one store into its owner's list
+    const uint64_t gid0 = (uint64_t)ch.pair_begin * P.p;                   // target t's id in the keys: gid0 + t
+    auto place = [&](uint32_t slot, uint32_t j) {
+        const uint32_t rank = atomicSub(&tcnt[slot], 1u) - 1u;
+        const uint32_t owner = thead[slot];
+        occ_keys[base + tstart[owner] + rank] = ((gid0 + owner) << 32) | (uint32_t)(0x7FFFFFFFu - j);   // (target, offset descending)
+    };
+    const uint32_t staged = n_stage;
+    if (staged <= kStage) {                                                // (never when the special slot was met)
+        for (uint32_t e = tid; e < staged; e += kScanThreads) place(stage[e] >> 20, stage[e] & 0xFFFFFu);
+    } else {
+        sweep(place);
+    }
+    // The lists are read back below by this workgroup only: __syncthreads() orders them at workgroup scope (all its waves
+    // share the CU's vector cache).  A device-scope fence here writes the XCD's whole L2 back, once per workgroup: 11 ms
+    // instead of 1.5 per million candidates.
+    __syncthreads();
+    // the targets that asked for a k-mer somebody else owns: their lists are copies
+    for (uint32_t t = tid; t < kMaxTargets; t += kScanThreads) {
+        uint32_t len = 0;
+        if (t < n_t && thead[tslot[t]] != t) len = tstart[t + 1u] - tstart[t];
+        const uint64_t ms = __ballot(len != 0u && len < kLongList), ml = __ballot(len >= kLongList);
+        uint32_t bs = 0, bl = 0;
+        if (lane == 0) {
+            if (ms) bs = atomicAdd(&n_short, (uint32_t)__popcll(ms));
+            if (ml) bl = atomicAdd(&n_long, (uint32_t)__popcll(ml));
+        }
+        bs = (uint32_t)__shfl((int)bs, 0, 64);
+        bl = (uint32_t)__shfl((int)bl, 0, 64);
+        const uint64_t below = (1ull << lane) - 1ull;
+        if (len != 0u && len < kLongList) short_list[bs + (uint32_t)__popcll(ms & below)] = (uint16_t)t;
+        if (len >= kLongList) long_list[bl + (uint32_t)__popcll(ml & below)] = (uint16_t)t;
+    }
+    __syncthreads();
+    auto copy_list = [&](uint32_t t, uint32_t first, uint32_t step) {
+        const uint32_t owner = thead[tslot[t]], len = tstart[t + 1u] - tstart[t];
+        const uint64_t *src = occ_keys + base + tstart[owner];
+        uint64_t *dst = occ_keys + base + tstart[t];
+        const uint64_t hi = (gid0 + t) << 32;
+        for (uint32_t e = first; e < len; e += step) {
+            dst[e] = hi | (uint32_t)src[e];
+        }
+    };
+    const uint32_t ns = n_short, nl = n_long;
+    for (uint32_t i = 0; i < nl; i++) copy_list(long_list[i], tid, kScanThreads);
+    for (uint32_t i = wave; i < ns; i += kScanThreads / 64u) copy_list(short_list[i], lane, 64u);
 }
 
 // Occurrences a candidate may have for the one-thread replay: room for one true occurrence per sample and a few chance
@@ -332,12 +422,10 @@ __global__ __launch_bounds__(kLightThreads) void bml_replay_light_kernel(
 // Bitmaps live in LDS when 3 of them fit (`lds_bitmaps`), else in the workgroup's global scratch; nothing else does.
 
 struct HeavyScratch {
-    uint32_t *votes;        // per workgroup: 2 x range entries (the proposals' start positions, then their votes)
+    uint32_t *votes;        // per workgroup: 2 x vote_stride entries (the proposals' start positions, then their votes)
     uint32_t *bitmaps;      // per workgroup: 3 x words (used when the bitmaps do not fit LDS)
-    uint64_t *by_sample;    // every heavy candidate's occurrences grouped by sample: same layout as the occurrence buffer.
-                            // (Round 3 kept those of candidates with up to 6 144 in LDS: 24 KB a workgroup, three workgroups
-                            // a CU; with the walks' loads batched the global copy costs nothing and six workgroups a CU
-                            // hide each other's barriers: 29 -> 20 ms per million reads in repeats.)
+    uint32_t vote_stride;   // min(range, the most occurrences a heavy candidate has): a candidate makes at most one proposal
+                            // per start position and at most one per occurrence
 };
 
 __global__ __launch_bounds__(kThreads) void bml_replay_heavy_kernel(
@@ -348,13 +436,13 @@ __global__ __launch_bounds__(kThreads) void bml_replay_heavy_kernel(
     uint32_t range, uint32_t bias, uint32_t lds_bitmaps, HeavyScratch S, int32_t *__restrict__ out_offset,
     uint32_t *__restrict__ out_votes) {
     extern __shared__ uint32_t heavy_lds[];
-    __shared__ uint32_t s_hist[65], s_cursor[64], s_fresh, s_new, s_np, s_fmax, s_fmin, s_next;
+    __shared__ uint32_t s_hist[65], s_fresh, s_new, s_np, s_fmax, s_fmin, s_next;
     __shared__ unsigned long long s_best;
     const uint32_t tid = threadIdx.x, words = (range + 31u) / 32u;
     uint32_t *exists = lds_bitmaps ? heavy_lds : S.bitmaps + (size_t)blockIdx.x * 3u * words;
     uint32_t *fresh = exists + words, *starts = fresh + words;
     // the proposals, in the order they were made: start position and votes (at most one per start position)
-    uint32_t *prop_pos = S.votes + (size_t)blockIdx.x * 2u * range, *prop_votes = prop_pos + range;
+    uint32_t *prop_pos = S.votes + (size_t)blockIdx.x * 2u * S.vote_stride, *prop_votes = prop_pos + S.vote_stride;
     const int32_t d = P.allowed_indel;
     const uint32_t total = *n_heavy;
     // The bitmaps are all zero between candidates: a candidate only ever sets bits at the start positions of its own
@@ -401,37 +489,19 @@ __global__ __launch_bounds__(kThreads) void bml_replay_heavy_kernel(
         const uint32_t w = pair_window[pair];
         const bool rc = pair_rc[pair] != 0;
         const uint32_t length = seg_len[w];
-        // 0. the occurrences grouped by sample (counting sort on the sample number)
-        for (uint32_t i = tid; i < 65u; i += kThreads) s_hist[i] = 0;
+        // 0. the scan wrote the candidate's occurrences grouped by sample, in processing order: s_hist[i] = the first of
+        //    sample i, found by a binary search on the keys' target id (p + 1 threads, ~log2(n) loads each)
+        const uint64_t *mine = keys + first;
         if (tid == 0) s_np = 0;
-        __syncthreads();
-        for (uint64_t i = tid; i < n; i += 4u * kThreads) {      // (four keys in flight per thread)
-            uint64_t key[4];
-#pragma unroll
-            for (int u = 0; u < 4; u++) key[u] = i + u * kThreads < n ? keys[first + i + u * kThreads] : 0ull;
-#pragma unroll
-            for (int u = 0; u < 4; u++)
-                if (i + u * kThreads < n) atomicAdd(&s_hist[(uint32_t)(key[u] >> 32) - pair * P.p + 1u], 1u);
-        }
-        __syncthreads();
-        if (tid == 0) {
-            for (uint32_t i = 0; i < P.p; i++) s_hist[i + 1] += s_hist[i];          // s_hist[i] = first occurrence of sample i
-            for (uint32_t i = 0; i < P.p; i++) s_cursor[i] = s_hist[i];
-        }
-        __syncthreads();
-        // ... into the second occurrence buffer
-        uint64_t *mine = S.by_sample + first;
-        for (uint64_t i = tid; i < n; i += 4u * kThreads) {
-            uint64_t key[4];
-#pragma unroll
-            for (int u = 0; u < 4; u++) key[u] = i + u * kThreads < n ? keys[first + i + u * kThreads] : 0ull;
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                if (i + u * kThreads < n) {
-                    const uint32_t at = atomicAdd(&s_cursor[(uint32_t)(key[u] >> 32) - pair * P.p], 1u);
-                    mine[at] = key[u];
-                }
+        if (tid <= P.p) {
+            const uint64_t want = ((uint64_t)pair * P.p + tid) << 32;     // first key of sample `tid` or later
+            uint64_t lo = 0, hi = n;
+            while (lo < hi) {
+                const uint64_t mid = (lo + hi) >> 1;
+                if (mine[mid] < want) lo = mid + 1;
+                else hi = mid;
             }
+            s_hist[tid] = (uint32_t)lo;
         }
         __syncthreads();
         for (uint32_t i = 0; i < P.p; i++) {

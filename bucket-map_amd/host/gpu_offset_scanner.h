@@ -130,7 +130,7 @@ public:
             n += occ[d];
         }
         std::cerr << "[BENCHMARK]\tGPU locator scan: " << n_pairs << " candidates, " << n << " k-mer occurrences; scan " << a
-                  << " ms, grouping " << b << " ms, vote replay " << c << " ms" << (D > 1 ? " (slowest of " + std::to_string(D) + " devices)" : "")
+                  << " ms, host between kernels " << b << " ms, vote replay " << c << " ms" << (D > 1 ? " (slowest of " + std::to_string(D) + " devices)" : "")
                   << ".\n";
     }
 };

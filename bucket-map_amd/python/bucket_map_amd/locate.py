@@ -104,7 +104,7 @@ class LocatorScan:
         _check(lib().bml_last_stats(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(n)))
         h = C.c_uint32()
         _check(lib().bml_last_heavy_candidates(self._h, C.byref(h)))
-        return {"ms_scan": a.value, "ms_sort": b.value, "ms_replay": c.value, "occurrences": n.value, "heavy_candidates": h.value}
+        return {"ms_scan": a.value, "ms_host": b.value, "ms_replay": c.value, "occurrences": n.value, "heavy_candidates": h.value}
 
     def close(self) -> None:
         if self._h:

@@ -17,8 +17,8 @@
  * which results are appended per read (:651-693), _filter_best_locations (:350-405) and SAM output (:455-611).
  *
  * Instead of one hash multimap per bucket (65 k node allocations per bucket in the reference) the
- * device scans each candidate bucket once against the few hundred k-mers actually asked of it, groups
- * the occurrences by candidate and replays the order-dependent vote of _find_offset exactly -- per sample,
+ * device scans each candidate bucket against the few hundred k-mers actually asked of it, writes every candidate's
+ * occurrences to a segment of their own (grouped by sample) and replays the order-dependent vote of _find_offset exactly -- per sample,
  * occurrences in the order libstdc++'s unordered_multimap::equal_range yields them, i.e. DESCENDING bucket
  * offset: one thread per candidate orders and replays a handful of occurrences; a candidate with many (a k-mer
  * of a tandem repeat occurs thousands of times in a bucket) gets a workgroup and dense bitmaps of the start
@@ -79,10 +79,10 @@ int  bml_locate(bml_ctx *ctx, const uint32_t *sample_hash, const uint16_t *sampl
                 uint32_t n_windows, const uint32_t *pair_bucket, const uint32_t *pair_window, const uint8_t *pair_rc,
                 uint32_t n_pairs, int32_t *out_offset, uint32_t *out_votes);
 
-/* Kernel times of the last bml_locate in ms -- scan, grouping of the occurrences by candidate (ms_sort: the
- * name dates from the device-wide sort this step replaced), vote replay -- and the number of k-mer occurrences
- * it handled. */
-int  bml_last_stats(bml_ctx *ctx, float *ms_scan, float *ms_sort, float *ms_replay, uint64_t *n_occurrences);
+/* Times of the last bml_locate in ms: ms_scan = its scan kernels, ms_replay = its vote kernels (HIP events on the
+ * context's stream), ms_host = what the call spent outside those kernels from the first scan on (stream syncs, the
+ * count downloads, growth of the occurrence buffer, placing the groups' segments) -- and the k-mer occurrences it handled. */
+int  bml_last_stats(bml_ctx *ctx, float *ms_scan, float *ms_host, float *ms_replay, uint64_t *n_occurrences);
 
 /* Candidates of the last bml_locate that had more occurrences than one thread replays (repeats): they went through
  * the workgroup-per-candidate kernel. */

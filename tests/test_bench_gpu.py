@@ -19,7 +19,7 @@ def _line(out):
 
 
 def test_single_gpu_line_has_roofline_traffic_and_cpu_baseline():
-    r = subprocess.run([sys.executable, "bench.py", "--workload", "mini", "--steps", "3", "--warmup", "1", "--cpu-sample", "5000"],
+    r = subprocess.run([sys.executable, "bench.py", "--workload", "mini", "--steps", "3", "--warmup", "1", "--cpu-sample", "5000", "--locator-cpu-seconds", "2"],
                        cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     d = _line(r.stdout)
@@ -47,6 +47,17 @@ def test_single_gpu_line_has_roofline_traffic_and_cpu_baseline():
     assert 0.5 < sk["rows_passing_distinguishability"] < 1.0 and 0.8 < sk["checks"]["reads_with_candidates"] <= 1.0
     assert 0 < sk["roofline"]["frac"] < 1.05
     assert "roofline_large_index" not in d and "verifier" not in d     # (the 4.6 GB and verifier legs belong to the default `egu` run)
+    # north_star's second subsystem, the locator's candidate scan, on the headline's and on the skewed leg's candidates:
+    # kernel times, occurrences, a fraction of the HBM peak, the CPU oracle beside it and parity on its sample
+    for loc in (d["locator"], sk["locator"]):
+        assert "error" not in loc, loc
+        assert loc["candidates"] > 0 and loc["ms_scan"] > 0 and loc["ms_replay"] > 0 and loc["occurrences"] > 0
+        assert loc["roofline"]["bound"] == "hbm" and 0 < loc["roofline"]["frac"] < 1
+        assert abs(loc["roofline"]["frac"] - loc["roofline"]["achieved"] / loc["roofline"]["peak"]) < 1e-9
+        assert loc["cpu_baseline"]["kind"] == "port" and loc["cpu_baseline"]["cores"] == 1 and loc["cpu_baseline"]["value"] > 0
+        assert loc["checks"]["gpu_equals_oracle_on_sample"] is True and loc["checks"]["parity_sample_candidates"] > 0
+    assert d["locator"]["checks"]["true_candidates_located_at_the_simulated_offset"] > 0.97
+    assert sk["locator"]["occurrences"] > d["locator"]["occurrences"]       # repeats: the genome-like genome's signature
 
 
 @pytest.mark.parametrize("ranks", [2, 4])
