@@ -1423,6 +1423,16 @@ int bmf_batch_run(bmf_ctx *c, bmf_batch *b) {
     return rc;
 }
 
+int bmf_device_memory(int device, uint64_t *free_bytes, uint64_t *total_bytes) {
+    if (!free_bytes || !total_bytes) return fail(BMF_ERR_ARG, "bmf_device_memory: null argument");
+    HIP_TRY(hipSetDevice(device));
+    size_t f = 0, t = 0;
+    HIP_TRY(hipMemGetInfo(&f, &t));
+    *free_bytes = f;
+    *total_bytes = t;
+    return BMF_OK;
+}
+
 int bmf_sync(bmf_ctx *c) {
     if (!c) return fail(BMF_ERR_ARG, "bmf_sync: null context");
     HIP_TRY(hipSetDevice(c->p.device));

@@ -500,6 +500,10 @@ private:
                 b.failed = std::current_exception();
             }
         };
+        // BM_DUMP_ALIGNMENTS=<file> (tests): every alignment the verifier returned, kept or not, one line each --
+        // read, text start in the concatenated genome, text length, strand, query length, score, begin, CIGAR
+        std::ofstream dump;
+        if (const char *e = std::getenv("BM_DUMP_ALIGNMENTS")) dump.open(e);
         auto write = [&](Block &b) {
             if (b.failed) std::rethrow_exception(b.failed);
             size_t a = 0;
@@ -507,6 +511,12 @@ private:
             for (size_t r = 0; r < b.reads.size(); r++) {
                 for (auto &[bucket_id, offset, segment_offset, votes, is_original] : locate_res[b.first_read + r]) {
                     (void)segment_offset; (void)votes;
+                    if (dump.is_open()) {
+                        dump << b.first_read + r << ' ' << b.text_start[a] << ' ' << b.text_len[a] << ' ' << int(b.text_rc[a]) << ' '
+                             << b.query_len[a] << ' ' << b.score[a] << ' ' << b.begin[a] << ' ';
+                        for (uint64_t x = b.cigar_offset[a]; x < b.cigar_offset[a + 1]; x++) dump << (b.cigar[x] >> 4) << "MID"[b.cigar[x] & 15u];
+                        dump << (b.cigar_offset[a] == b.cigar_offset[a + 1] ? "*\n" : "\n");
+                    }
                     const unsigned int wrapped = 60u + static_cast<unsigned int>(b.score[a]);        // :570
                     const size_t map_qual = wrapped;
                     if (!(map_qual < quality_threshold)) {                                            // :571-573

@@ -28,6 +28,9 @@ bool bm_gpu_index(const bm::cmd_arguments &args, const bm::Genome &genome, unsig
 // on a thread of its own while the genome is read; errors are left for the real calls to report.  main() joins it.
 std::thread bm_warm_up(const bm::cmd_arguments &args);
 
+// One [INFO] line when the run is done: device memory in use (the contexts are still alive) and the host's peak RSS.
+void bm_report_resources(const bm::cmd_arguments &args);
+
 int main(int argc, char **argv) {
     bm::cmd_arguments args;
     try {
@@ -129,6 +132,7 @@ int main(int argc, char **argv) {
         loc.initialize(genome, cwd, args.index_indicator);                                    // main.cpp:221
         loc.locate(args.fastq_path.string(), cwd / (args.index_indicator + ".bucket_id"),     // main.cpp:224
                    args.output_sam_path, args.locator_quality_threshold);
+        bm_report_resources(args);
     } catch (const std::exception &e) {
         std::cerr << "[ERROR]\t\t" << e.what() << "\n";
         return 2;

@@ -7,6 +7,8 @@
 #include "gpu_offset_scanner.h"
 #include "gpu_q_gram_mapper.h"
 
+#include <sys/resource.h>
+
 #include <memory>
 #include <thread>
 
@@ -101,4 +103,19 @@ std::unique_ptr<bm::offset_scanner> bm_make_scanner(const bm::cmd_arguments &arg
 
 std::unique_ptr<bm::alignment_verifier> bm_make_verifier(const bm::cmd_arguments &args) {
     return std::make_unique<bm::gpu_alignment_verifier>(args.gpus);
+}
+
+void bm_report_resources(const bm::cmd_arguments &args) {
+    struct rusage ru {};
+    getrusage(RUSAGE_SELF, &ru);
+    std::vector<int> seen;
+    for (int dev : args.gpus) {
+        if (std::find(seen.begin(), seen.end(), dev) != seen.end()) continue;
+        seen.push_back(dev);
+        uint64_t free_b = 0, total_b = 0;
+        if (bmf_device_memory(dev, &free_b, &total_b) != BMF_OK) continue;
+        std::cerr << "[INFO]\t\tDevice " << dev << ": " << static_cast<double>(total_b - free_b) / (1u << 30) << " GiB of "
+                  << static_cast<double>(total_b) / (1u << 30) << " GiB in use at the end of the run.\n";
+    }
+    std::cerr << "[INFO]\t\tHost peak resident set: " << static_cast<double>(ru.ru_maxrss) / (1u << 20) << " GiB.\n";
 }

@@ -67,6 +67,7 @@ SYMBOLS = {
     "bmf_batch_rows_anded": (C.c_int, [C.c_void_p, C.c_void_p, _u64p]),
     "bmf_batch_destroy": (None, [C.c_void_p, C.c_void_p]),
     "bmf_sync": (C.c_int, [C.c_void_p]),
+    "bmf_device_memory": (C.c_int, [C.c_int, _u64p, _u64p]),
     "bmf_profile_begin": (C.c_int, [C.c_void_p, C.c_uint32]),
     "bmf_profile_end": (C.c_int, [C.c_void_p, _u32p, _f32p, _f32p]),
     "bmf_pinned_alloc": (C.c_int, [C.c_size_t, C.POINTER(C.c_void_p)]),

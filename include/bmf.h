@@ -161,6 +161,10 @@ int  bmf_profile_end(bmf_ctx *ctx, uint32_t *n_runs, float *ms_sample, float *ms
 int  bmf_pinned_alloc(size_t bytes, void **out);
 void bmf_pinned_free(void *p);
 
+/* Free and total memory of a device (hipMemGetInfo): the tools print what is in use when they are done -- the
+ * contexts' buffers only grow, so that is the run's peak but for buffers that were re-allocated larger. */
+int  bmf_device_memory(int device, uint64_t *free_bytes, uint64_t *total_bytes);
+
 /* Introspection for DESIGN.md / bench: bytes per padded row in HBM, kernel variant chosen. */
 int  bmf_info(bmf_ctx *ctx, uint32_t *row_pitch_bytes, uint32_t *chunks_per_lane, uint32_t *planes,
               uint32_t *rows_in_flight);

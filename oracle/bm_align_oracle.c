@@ -95,3 +95,75 @@ int bmao_align_batch(const uint8_t *genome, const uint8_t *reads, const uint64_t
     out_cigar_offset[n] = at;
     return short_buf;
 }
+
+/* one row of the two-row programme; compiled a second time for AVX2 where the CPU has it (the first loop is 8 cells an instruction) */
+__attribute__((target_clones("avx2", "default")))
+static void two_row_step(const uint32_t *prev, uint32_t *cur, const uint8_t *t, uint8_t qi, uint32_t n) {
+    for (uint32_t j = 1; j <= n; j++) {                 /* diagonal and up first: no dependence along the row */
+        const uint32_t d = prev[j - 1] + (qi != t[j - 1] ? 1u : 0u), u = prev[j] + 1u;
+        cur[j] = d < u ? d : u;
+    }
+    uint32_t run = cur[0];                              /* then the gap in the query, left to right (carried in a register) */
+    for (uint32_t j = 1; j <= n; j++) {
+        const uint32_t v = cur[j], l = run + 1u;
+        run = l < v ? l : v;
+        cur[j] = run;
+    }
+}
+
+int bmao_check(const uint8_t *text, uint32_t n, int text_rc, const uint8_t *query, uint32_t m, int32_t score, uint32_t begin,
+               const uint32_t *cigar, uint64_t n_cigar, int32_t *out_optimum) {
+    uint8_t *t = (uint8_t *)malloc(n ? n : 1), *q = (uint8_t *)malloc(m ? m : 1);
+    uint32_t *prev = (uint32_t *)malloc(((size_t)n + 1) * sizeof(uint32_t)), *cur = (uint32_t *)malloc(((size_t)n + 1) * sizeof(uint32_t));
+    if (!t || !q || !prev || !cur) {
+        free(t); free(q); free(prev); free(cur);
+        return 8;
+    }
+    for (uint32_t j = 0; j < n; j++) t[j] = text_rc ? (uint8_t)(3 - rank_of(text[n - 1 - j])) : rank_of(text[j]);
+    for (uint32_t i = 0; i < m; i++) q[i] = rank_of(query[i]);
+    /* (a) two rows of the same recurrence: row 0 is free, column 0 costs i */
+    for (uint32_t j = 0; j <= n; j++) prev[j] = 0;
+    for (uint32_t i = 1; i <= m; i++) {
+        cur[0] = i;
+        two_row_step(prev, cur, t, q[i - 1], n);
+        uint32_t *x = prev; prev = cur; cur = x;
+    }
+    uint32_t best = prev[0];
+    for (uint32_t j = 1; j <= n; j++)
+        if (prev[j] < best) best = prev[j];
+    *out_optimum = -(int32_t)best;
+    int bad = score == -(int32_t)best ? 0 : 1;
+    /* (b) the CIGAR as a path */
+    uint64_t i = 0, j = begin, cost = 0;
+    int shape_ok = begin <= n;
+    for (uint64_t x = 0; x < n_cigar && shape_ok; x++) {
+        const uint32_t len = cigar[x] >> 4, op = cigar[x] & 15u;
+        if (len == 0 || op > BMAO_OP_D || (x && (cigar[x - 1] & 15u) == op)) shape_ok = 0;      /* run-length form */
+        else if (op == BMAO_OP_M) {
+            if (i + len > m || j + len > n) shape_ok = 0;
+            else for (uint32_t y = 0; y < len; y++) cost += q[i + y] != t[j + y];
+            i += len; j += len;
+        } else if (op == BMAO_OP_I) {
+            if (i + len > m) shape_ok = 0;
+            i += len; cost += len;
+        } else {
+            if (j + len > n) shape_ok = 0;
+            j += len; cost += len;
+        }
+    }
+    if (!shape_ok || i != m) bad |= 2;
+    else if ((int64_t)cost != -(int64_t)score) bad |= 4;
+    free(t); free(q); free(prev); free(cur);
+    return bad;
+}
+
+void bmao_check_batch(const uint8_t *genome, const uint8_t *reads, const uint64_t *text_start, const uint32_t *text_len,
+                      const uint8_t *text_rc, const uint64_t *query_start, const uint32_t *query_len, uint32_t first,
+                      uint32_t last, const int32_t *score, const uint32_t *begin, const uint64_t *cigar_offset,
+                      const uint32_t *cigar, uint8_t *out_bad) {
+    for (uint32_t a = first; a < last; a++) {
+        int32_t opt = 0;
+        out_bad[a] = (uint8_t)bmao_check(genome + text_start[a], text_len[a], text_rc[a], reads + query_start[a], query_len[a], score[a],
+                                         begin[a], cigar + cigar_offset[a], cigar_offset[a + 1] - cigar_offset[a], &opt);
+    }
+}

@@ -48,6 +48,22 @@ int bmao_align_batch(const uint8_t *genome, const uint8_t *reads, const uint64_t
                      int32_t *out_score, uint32_t *out_begin, uint64_t *out_cigar_offset, uint32_t *out_cigar,
                      uint64_t cigar_cap);
 
+/* O(n)-memory CHECK of a reported alignment (thousands of 10-kbp alignments without the 440 MB matrix):
+ *   (a) the optimal score by a two-row dynamic programme over the same recurrence (no traceback);
+ *   (b) the reported CIGAR walked from `begin` over text and query: it must consume the whole query, stay inside the
+ *       text, and cost exactly -score edits (mismatches under M, one per I and D base).
+ * Returns 0 when score == optimum and the CIGAR is a valid alignment of that cost; otherwise a bit set:
+ *   1 score differs from the optimum, 2 the CIGAR does not consume the query exactly / leaves the text,
+ *   4 the CIGAR's cost differs from -score, 8 out of memory.  *out_optimum receives the optimum (<= 0). */
+int bmao_check(const uint8_t *text, uint32_t n, int text_rc, const uint8_t *query, uint32_t m, int32_t score, uint32_t begin,
+               const uint32_t *cigar, uint64_t n_cigar, int32_t *out_optimum);
+
+/* bmao_check for alignments [first, last) of a batch laid out as bmao_align_batch's; out_bad[a] = its result. */
+void bmao_check_batch(const uint8_t *genome, const uint8_t *reads, const uint64_t *text_start, const uint32_t *text_len,
+                      const uint8_t *text_rc, const uint64_t *query_start, const uint32_t *query_len, uint32_t first,
+                      uint32_t last, const int32_t *score, const uint32_t *begin, const uint64_t *cigar_offset,
+                      const uint32_t *cigar, uint8_t *out_bad);
+
 #ifdef __cplusplus
 }
 #endif

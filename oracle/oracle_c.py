@@ -190,6 +190,33 @@ def align_batch(genome, reads, text_start, text_len, text_rc, query_start, query
     return score, begin, off, cg[: int(off[n])].copy()
 
 
+def check_alignments(genome, reads, text_start, text_len, text_rc, query_start, query_len, score, begin, cigar_offset, cigar,
+                     threads=None):
+    """bmao_check_batch over host threads: per alignment 0 = the score is the two-row DP's optimum AND the CIGAR is a valid
+    path of exactly that cost; else a bit set (1 score, 2 CIGAR shape, 4 CIGAR cost, 8 memory)."""
+    from concurrent.futures import ThreadPoolExecutor
+    g, r = np.ascontiguousarray(genome, np.uint8), np.ascontiguousarray(reads, np.uint8)
+    ts, tl = np.ascontiguousarray(text_start, np.uint64), np.ascontiguousarray(text_len, np.uint32)
+    trc = np.ascontiguousarray(text_rc, np.uint8)
+    qs, ql = np.ascontiguousarray(query_start, np.uint64), np.ascontiguousarray(query_len, np.uint32)
+    sc, bg = np.ascontiguousarray(score, np.int32), np.ascontiguousarray(begin, np.uint32)
+    co, cg = np.ascontiguousarray(cigar_offset, np.uint64), np.ascontiguousarray(cigar if len(cigar) else np.zeros(1), np.uint32)
+    n = len(ts)
+    bad = np.full(n, 255, np.uint8)
+    threads = threads or max(1, min(len(os.sched_getaffinity(0)), 32))
+    fn = lib().bmao_check_batch
+    fn.restype = None
+    fn.argtypes = [_u8p, _u8p, _u64p, _u32p, _u8p, _u64p, _u32p, C.c_uint32, C.c_uint32, _i32p, _u32p, _u64p, _u32p, _u8p]
+    # cut by cells, not by count: the alignments of a batch differ a hundredfold in size
+    cells = np.cumsum(tl.astype(np.float64) * ql.astype(np.float64))
+    cuts = [0] + [int(np.searchsorted(cells, cells[-1] * (t + 1) / (4 * threads))) for t in range(4 * threads - 1)] + [n] if n else [0, 0]
+    with ThreadPoolExecutor(threads) as pool:
+        list(pool.map(lambda ab: fn(_p(g, _u8p), _p(r, _u8p), _p(ts, _u64p), _p(tl, _u32p), _p(trc, _u8p), _p(qs, _u64p),
+                                    _p(ql, _u32p), ab[0], ab[1], _p(sc, _i32p), _p(bg, _u32p), _p(co, _u64p), _p(cg, _u32p),
+                                    _p(bad, _u8p)) if ab[1] > ab[0] else None, zip(cuts[:-1], cuts[1:])))
+    return bad
+
+
 class Index:
     def __init__(self, params: Params, rows: np.ndarray | None = None, kmer_to_index: np.ndarray | None = None, *,
                  rows_ptr=None, n_rows=None, k2i_ptr=None, n_kmers=None, files=None):

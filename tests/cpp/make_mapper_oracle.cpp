@@ -123,6 +123,7 @@ std::unique_ptr<bm::mapper> bm_make_mapper(const bm::cmd_arguments &args, unsign
 // the oracle-backed tool always uses the host indexer
 bool bm_gpu_index(const bm::cmd_arguments &, const bm::Genome &, unsigned int, bm::QgramIndex &) { return false; }
 std::thread bm_warm_up(const bm::cmd_arguments &) { return {}; }
+void bm_report_resources(const bm::cmd_arguments &) {}
 
 std::unique_ptr<bm::offset_scanner> bm_make_scanner(const bm::cmd_arguments &args, int allowed_mismatch, int allowed_indel) {
     return std::make_unique<oracle_scanner>(args.query_seed_length, static_cast<uint32_t>(args.locator_sample_size),

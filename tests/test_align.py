@@ -107,6 +107,32 @@ def test_oracle_batch_layout():
     assert [oc.cigar_string(cg[off[i]:off[i + 1]]) for i in range(2)] == ["2M1D4M", "4M"]
 
 
+def test_two_row_checker_agrees_with_the_full_matrix_and_catches_wrong_alignments():
+    """oracle/bm_align_oracle.c::bmao_check (what tests/test_configs_gpu.py holds thousands of 10-kbp alignments to): the
+    two-row optimum equals the full matrix's score, the oracle's own alignments pass, and every kind of wrong answer --
+    a score off by one, a begin off by one, a CIGAR with a swapped or lengthened run -- is reported."""
+    rng = np.random.default_rng(20240031)
+    genome = np.frombuffer(bytes(rng.choice(list(b"ACGT"), 30_000).astype(np.uint8)), np.uint8)
+    reads, ts, tl, trc, qs, ql = _random_batch(rng, genome, 300, 400, (0.03, 0.02, 0.02))
+    score, begin, off, cg = oc.align_batch(genome, reads, ts, tl, trc, qs, ql)
+    assert not oc.check_alignments(genome, reads, ts, tl, trc, qs, ql, score, begin, off, cg, threads=4).any()
+    # a worse score with a matching CIGAR cost cannot be produced by editing the score alone: bit 1 (and 4: the cost differs)
+    bad = oc.check_alignments(genome, reads, ts, tl, trc, qs, ql, score - 1, begin, off, cg, threads=2)
+    assert ((bad & 1) != 0).all()
+    has_path = (off[1:] - off[:-1]) > 0
+    assert ((bad[has_path] & 4) != 0).all()
+    # a shifted begin: the path leaves the text or costs more (almost always; never reported clean with a cheaper cost)
+    bad = oc.check_alignments(genome, reads, ts, tl, trc, qs, ql, score, begin + 1, off, cg, threads=2)
+    long_enough = ql > 30
+    assert (bad[long_enough & (score > -ql.astype(np.int64) // 2)] != 0).mean() > 0.95
+    # a CIGAR whose first run is one longer no longer consumes the query exactly: bit 2
+    cg2 = cg.copy()
+    first = off[:-1][has_path].astype(np.int64)
+    cg2[first] += 16
+    bad = oc.check_alignments(genome, reads, ts, tl, trc, qs, ql, score, begin, off, cg2, threads=2)
+    assert ((bad[has_path] & 6) != 0).all()
+
+
 # ------------------------------------------------------------------------------------------------ GPU
 
 def _mutate(rng, seq, sub, ins, dele):

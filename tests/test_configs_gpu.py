@@ -227,6 +227,33 @@ def parse_sam(path):
     return recs
 
 
+def check_dumped_alignments(path, genome, reads):
+    """OPTIMALITY of every alignment the verifier returned for the batch (thousands of 10 000 x 11 000 alignments) without the
+    440 MB matrix per alignment: oracle/bm_align_oracle.c::bmao_check -- the score equals a two-row O(n)-memory DP's optimum,
+    and the CIGAR, walked over text and query from `begin`, consumes the whole query and costs exactly -score edits."""
+    from oracle import oracle_c
+    flat, _ = genome.flat()
+    rows = [l.split() for l in open(path)]
+    assert len(rows) > 4 * reads.n                                    # ~5 located candidates per ONT read
+    rd = np.array([int(r[0]) for r in rows])
+    ts, tl = np.array([int(r[1]) for r in rows], np.uint64), np.array([int(r[2]) for r in rows], np.uint32)
+    rc, ql = np.array([int(r[3]) for r in rows], np.uint8), np.array([int(r[4]) for r in rows], np.uint32)
+    score, begin = np.array([int(r[5]) for r in rows], np.int32), np.array([int(r[6]) for r in rows], np.uint32)
+    assert np.array_equal(ql, np.diff(reads.offsets)[rd].astype(np.uint32))
+    import re
+    cig, off = [], [0]
+    for r in rows:
+        if r[7] != "*":
+            cig += [(int(n) << 4) | "MID".index(op) for n, op in re.findall(r"(\d+)([MID])", r[7])]
+        off.append(len(cig))
+    bad = oracle_c.check_alignments(flat, reads.bases, ts, tl, rc, reads.offsets[rd], ql, score, begin, np.array(off, np.uint64),
+                                    np.array(cig, np.uint32))
+    assert not bad.any(), (int((bad != 0).sum()), np.flatnonzero(bad)[:5], bad[bad != 0][:5])
+    # the batch is what configs[4] is: true loci at ~8 % edits, wrong loci at half the bases
+    per_base = -score / ql
+    assert (per_base < 0.12).mean() > 0.15 and (per_base > 0.3).mean() > 0.3
+
+
 def test_config4_long_reads_bucketmap_align(tmp_path):
     import bench
     from bucket_map_amd import host
@@ -253,8 +280,10 @@ def test_config4_long_reads_bucketmap_align(tmp_path):
     run("oracle", ["-i", "idx", *flags, "-q", "few.fastq", "-o", "few_plain_cpu.sam"], tmp_path)
     assert (tmp_path / "few_plain_gpu.sam").read_bytes() == (tmp_path / "few_plain_cpu.sam").read_bytes()
     # (ii) 1 500 reads: the three-context split (filter, scan and verifier sharded) writes the same file
-    err = run("gpu_align", ["-i", "idx", *flags, "-q", "many.fastq", "-o", "one.sam"], tmp_path)
+    err = run("gpu_align", ["-i", "idx", *flags, "-q", "many.fastq", "-o", "one.sam"], tmp_path,
+              env={"BM_DUMP_ALIGNMENTS": str(tmp_path / "alignments.txt")})
     assert "GPU alignment verification" in err
+    check_dumped_alignments(tmp_path / "alignments.txt", genome, many)
     run("gpu_align", ["-i", "idx", *flags, "-q", "many.fastq", "-o", "three.sam", "--gpus", "0,0,0"], tmp_path)
     assert (tmp_path / "one.sam").read_bytes() == (tmp_path / "three.sam").read_bytes()
     recs = parse_sam(tmp_path / "one.sam")

@@ -30,6 +30,7 @@ ap.add_argument("--index-seed", default="", help="-k of the index (default 9; 26
 ap.add_argument("--gpus", default="", help="--gpus of the tool, e.g. 0,0,0")
 ap.add_argument("--profile", default="uniform", choices=["uniform", "genome"],
                 help="uniform = i.i.d. bases; genome = bm_synth.h's skewed, repetitive genome (q = 9 works at 262144-bp buckets)")
+ap.add_argument("--verbose", action="store_true", help="BML_LOG / BMV_LOG_CLASSES: the locator's groups and the verifier's rounds")
 ap.add_argument("--long", action="store_true",
                 help="the reference's long-read profile (benchmark/long_read/benchmark_map.sh:25): 10-kbp ONT-like reads "
                      "(sub 0.03, ins = del 0.025), -s 30 -e 0.9 -n 0.1 -l 12 -p 20 -u 5; the workload's 65536-bp buckets "
@@ -78,10 +79,12 @@ say(f"[e2e] index: exit {r.returncode}, {time.perf_counter() - t:.1f} s")
 t = time.perf_counter()
 map_exe = exe + "_align" if args.align else exe
 r = subprocess.run([map_exe, *common, "-q", "reads.fastq", "-o", "out.sam", *args.extra.split()], cwd=args.dir,
-                   capture_output=True, text=True)
+                   capture_output=True, text=True,
+                   env={**os.environ, **({"BML_LOG": "1", "BMV_LOG_CLASSES": "1"} if args.verbose else {})})
 say(f"[e2e] map ({os.path.basename(map_exe)} {args.extra}): exit {r.returncode}, {time.perf_counter() - t:.1f} s wall")
 for line in r.stderr.splitlines():
-    if "[BENCHMARK]" in line or "[ERROR]" in line or line.startswith(("[bm]", "[bmv]")):
+    if ("[BENCHMARK]" in line or "[ERROR]" in line or line.startswith(("[bm]", "[bmv]", "[bml]")) or "in use at the end" in line
+            or "Host peak resident" in line):
         say("    " + line)
 truth = [l.split() for l in open(os.path.join(args.dir, "reads.position_ground_truth"))]
 names = [g.record_id(i).split(" ")[0] for i in range(g.n_records)]
@@ -99,6 +102,7 @@ for line in open(os.path.join(args.dir, "out.sam")):
     ref, pos, rc = int(truth[i][0]), int(truth[i][1]), int(truth[i][2])
     # (long reads: a record's POS is where its first located window starts, up to a read length away)
     ok += int(f[2] == names[ref] and abs(int(f[3]) - pos) <= (sim_len if args.long else 10) and (int(f[1]) == 16) == bool(rc))
+say(f"[e2e] out.sam: {os.path.getsize(os.path.join(args.dir, 'out.sam')) / 1e9:.2f} GB")
 say(f"[e2e] reads with a SAM record: {mapped}/{rd.n} ({100.0 * mapped / rd.n:.3f} %), first record at the true position "
     f"(+-10): {ok} ({100.0 * ok / rd.n:.3f} %)")
 if args.out:
