@@ -20,6 +20,7 @@
 #include <algorithm>
 #include <chrono>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace {
@@ -279,6 +280,8 @@ struct bmf_ctx {
         size_t h_views_cap = 0;
         uint32_t *h_out = nullptr;       // pinned: counts (2n) then the head of `pack`
         size_t h_out_cap = 0;
+        uint8_t *h_bases = nullptr, *h_quals = nullptr;   // pinned: the piece's windows gathered back to back (bmf_map_text_windows_compact)
+        size_t h_bases_cap = 0, h_quals_cap = 0;
         hipEvent_t uploaded = nullptr, ran = nullptr, landed = nullptr;
         // the piece in flight
         uint32_t first = 0, n = 0;
@@ -711,6 +714,8 @@ static void free_map_slots(bmf_ctx *c) {
         sl->pack.release();
         if (sl->h_views) (void)hipHostFree(sl->h_views);
         if (sl->h_out) (void)hipHostFree(sl->h_out);
+        if (sl->h_bases) (void)hipHostFree(sl->h_bases);
+        if (sl->h_quals) (void)hipHostFree(sl->h_quals);
         for (hipEvent_t e : {sl->uploaded, sl->ran, sl->landed})
             if (e) (void)hipEventDestroy(e);
         delete sl;
@@ -1507,7 +1512,9 @@ static uint32_t piece_windows_of(uint32_t n_windows) {
     }
     // at least four pieces where the batch allows it, pieces of 8 Ki ... 128 Ki windows (a piece costs the host about
     // half a millisecond of submissions and unpacking: with the pruning kernels a 64 Ki piece is 1.3 ms of GPU work)
-    return std::min<uint32_t>(131072u, std::max<uint32_t>(8192u, (n_windows + 3u) / 4u));
+    // (round 4: at most 32 Ki windows -- a larger call is more pieces, not larger ones: what a call pays for filling and
+    // draining its pipeline is one piece's gather + upload + kernels, whatever the number of pieces behind it)
+    return std::min<uint32_t>(32768u, std::max<uint32_t>(8192u, (n_windows + 3u) / 4u));
 }
 
 static int map_slots_init(bmf_ctx *c) {
@@ -1540,14 +1547,30 @@ constexpr size_t kIdsPerItemCopied = 2;
 
 // Uploads piece [first, first + n) and queues its kernels and its downloads.  `whole`: the read buffer is
 // already in HBM as a whole (c->whole_*), window starts stay absolute.
+// `qual_start` != nullptr: gather mode -- window w's bases are at bases[win_start[w]], its qualities at quals[qual_start[w]]
+// (a FASTQ text): the piece's windows are copied back to back into the slot's page-locked buffers by a few host threads
+// (while the piece before is on the device) and go up from there.
+static unsigned gather_threads(uint32_t n_windows) {
+    if (const char *e = getenv("BMF_GATHER_THREADS"))             // (tests, experiments: exactly that many)
+        return (unsigned)std::max(1, std::min<int>(std::min(64u, std::max(1u, n_windows)), atoi(e)));
+    static const unsigned hw = std::max(1u, std::min(6u, std::thread::hardware_concurrency() / 2u));
+    return std::min(hw, std::max(1u, n_windows / 2048u));         // a thread is worth starting for a few thousand windows
+}
+
 static int map_piece_issue(bmf_ctx *c, bmf_ctx::MapSlot *sl, const uint8_t *bases, const uint8_t *quals,
-                           const uint64_t *win_start, const uint32_t *win_len, uint32_t first, uint32_t n, bool whole) {
+                           const uint64_t *win_start, const uint32_t *win_len, uint32_t first, uint32_t n, bool whole,
+                           const uint64_t *qual_start = nullptr) {
     sl->first = first;
     sl->n = n;
     uint64_t lo = ~0ull, hi = 0;
-    for (uint32_t w = first; w < first + n; w++) {
-        lo = std::min(lo, win_start[w]);
-        hi = std::max(hi, win_start[w] + win_len[w]);
+    if (qual_start) {
+        lo = 0;
+        for (uint32_t w = first; w < first + n; w++) hi += win_len[w];
+    } else {
+        for (uint32_t w = first; w < first + n; w++) {
+            lo = std::min(lo, win_start[w]);
+            hi = std::max(hi, win_start[w] + win_len[w]);
+        }
     }
     if (whole) lo = 0;
     const size_t span = whole ? 0 : (size_t)(hi - lo);
@@ -1563,11 +1586,40 @@ static int map_piece_issue(bmf_ctx *c, bmf_ctx::MapSlot *sl, const uint8_t *base
     HIP_TRY(pinned_need(reinterpret_cast<void **>(&sl->h_out), &sl->h_out_cap, (n_items + 1 + sl->ids_copied) * sizeof(uint32_t)));
     uint64_t *hs = reinterpret_cast<uint64_t *>(sl->h_views);
     uint32_t *hl = reinterpret_cast<uint32_t *>(sl->h_views + (size_t)n * 8);
-    for (uint32_t w = 0; w < n; w++) hs[w] = win_start[first + w] - lo;
     memcpy(hl, win_len + first, (size_t)n * sizeof(uint32_t));
-    if (span) {
-        HIP_TRY(hipMemcpyAsync(b->bases.p, bases + lo, span, hipMemcpyHostToDevice, c->h2d));
-        HIP_TRY(hipMemcpyAsync(b->quals.p, quals + lo, span, hipMemcpyHostToDevice, c->h2d));
+    if (qual_start) {
+        uint64_t at = 0;
+        for (uint32_t w = 0; w < n; w++) {
+            hs[w] = at;
+            at += hl[w];
+        }
+        HIP_TRY(pinned_need(reinterpret_cast<void **>(&sl->h_bases), &sl->h_bases_cap, span + 64));
+        HIP_TRY(pinned_need(reinterpret_cast<void **>(&sl->h_quals), &sl->h_quals_cap, span + 64));
+        auto gather = [&](uint32_t w0, uint32_t w1) {
+            for (uint32_t w = w0; w < w1; w++) {
+                memcpy(sl->h_bases + hs[w], bases + win_start[first + w], hl[w]);
+                memcpy(sl->h_quals + hs[w], quals + qual_start[first + w], hl[w]);
+            }
+        };
+        const unsigned T = gather_threads(n);
+        if (T <= 1) {
+            gather(0, n);
+        } else {
+            std::vector<std::thread> pool;
+            for (unsigned t = 1; t < T; t++) pool.emplace_back(gather, (uint32_t)((uint64_t)n * t / T), (uint32_t)((uint64_t)n * (t + 1) / T));
+            gather(0, (uint32_t)((uint64_t)n / T));
+            for (auto &t : pool) t.join();
+        }
+        if (span) {
+            HIP_TRY(hipMemcpyAsync(b->bases.p, sl->h_bases, span, hipMemcpyHostToDevice, c->h2d));
+            HIP_TRY(hipMemcpyAsync(b->quals.p, sl->h_quals, span, hipMemcpyHostToDevice, c->h2d));
+        }
+    } else {
+        for (uint32_t w = 0; w < n; w++) hs[w] = win_start[first + w] - lo;
+        if (span) {
+            HIP_TRY(hipMemcpyAsync(b->bases.p, bases + lo, span, hipMemcpyHostToDevice, c->h2d));
+            HIP_TRY(hipMemcpyAsync(b->quals.p, quals + lo, span, hipMemcpyHostToDevice, c->h2d));
+        }
     }
     HIP_TRY(hipMemcpyAsync(b->win_start.p, hs, (size_t)n * 8, hipMemcpyHostToDevice, c->h2d));
     HIP_TRY(hipMemcpyAsync(b->win_len.p, hl, (size_t)n * 4, hipMemcpyHostToDevice, c->h2d));
@@ -1637,7 +1689,8 @@ static int map_piece_finish(bmf_ctx *c, bmf_ctx::MapSlot *sl, MapOut &out) {
 }
 
 static int map_windows_impl(bmf_ctx *c, const uint8_t *bases, const uint8_t *quals, uint64_t n_bytes,
-                            const uint64_t *win_start, const uint32_t *win_len, uint32_t n_windows, MapOut &out);
+                            const uint64_t *win_start, const uint32_t *win_len, uint32_t n_windows, MapOut &out,
+                            const uint64_t *qual_start = nullptr);
 
 int bmf_map_windows(bmf_ctx *c, const uint8_t *bases, const uint8_t *quals, uint64_t n_bytes,
                     const uint64_t *win_start, const uint32_t *win_len, uint32_t n_windows,
@@ -1667,11 +1720,54 @@ int bmf_map_windows_compact(bmf_ctx *c, const uint8_t *bases, const uint8_t *qua
     return rc;
 }
 
+int bmf_map_reserve(bmf_ctx *c, uint32_t max_windows_per_call, int text_windows) {
+    if (!c) return fail(BMF_ERR_ARG, "bmf_map_reserve: null context");
+    if (max_windows_per_call == 0) return BMF_OK;
+    HIP_TRY(hipSetDevice(c->p.device));
+    int rc = map_slots_init(c);
+    if (rc != BMF_OK) return rc;
+    const size_t n = std::min(piece_windows_of(max_windows_per_call), max_windows_per_call), span = n * (size_t)c->p.read_len;
+    const size_t n_items = 2 * n, mc = c->p.max_candidates;
+    for (auto *sl : c->slot) {
+        bmf_batch *b = &sl->dev;
+        HIP_TRY(batch_reserve(c, b, n, span));
+        HIP_TRY(b->offsets.need(n_items + 1));
+        HIP_TRY(sl->pack.need(1 + n_items * mc));
+        HIP_TRY(b->scan_tmp.need(bmscan::tmp_elems(n_items) * sizeof(uint32_t)));
+        HIP_TRY(pinned_need(reinterpret_cast<void **>(&sl->h_views), &sl->h_views_cap, n * 12));
+        HIP_TRY(pinned_need(reinterpret_cast<void **>(&sl->h_out), &sl->h_out_cap, (n_items + 1 + kIdsPerItemCopied * n_items) * sizeof(uint32_t)));
+        if (text_windows) {
+            HIP_TRY(pinned_need(reinterpret_cast<void **>(&sl->h_bases), &sl->h_bases_cap, span + 64));
+            HIP_TRY(pinned_need(reinterpret_cast<void **>(&sl->h_quals), &sl->h_quals_cap, span + 64));
+        }
+    }
+    return BMF_OK;
+}
+
+int bmf_map_text_windows_compact(bmf_ctx *c, const uint8_t *text, uint64_t n_bytes, const uint64_t *seq_start,
+                                 const uint64_t *qual_start, const uint32_t *win_len, uint32_t n_windows,
+                                 uint32_t *out_counts, uint32_t *out_ids, uint64_t ids_capacity, uint64_t *n_ids) {
+    if (!c) return fail(BMF_ERR_ARG, "bmf_map_text_windows_compact: null context");
+    if (!n_ids || (n_windows && (!out_counts || !qual_start || (!out_ids && ids_capacity))))
+        return fail(BMF_ERR_ARG, "bmf_map_text_windows_compact: null argument");
+    *n_ids = 0;
+    static uint32_t none;
+    MapOut out;
+    out.counts = out_counts;
+    out.ids = out_ids ? out_ids : &none;
+    out.ids_cap = ids_capacity;
+    const int rc = map_windows_impl(c, text, text, n_bytes, seq_start, win_len, n_windows, out, qual_start);
+    *n_ids = out.ids_used;
+    return rc;
+}
+
 static int map_windows_impl(bmf_ctx *c, const uint8_t *bases, const uint8_t *quals, uint64_t n_bytes,
-                            const uint64_t *win_start, const uint32_t *win_len, uint32_t n_windows, MapOut &out) {
+                            const uint64_t *win_start, const uint32_t *win_len, uint32_t n_windows, MapOut &out,
+                            const uint64_t *qual_start) {
     if (!c->loaded) return fail(BMF_ERR_STATE, "the q-gram index is empty; cannot accept query");
     if (n_windows == 0) return BMF_OK;
     int rc = check_windows(c, bases, quals, n_bytes, win_start, win_len, n_windows);
+    if (rc == BMF_OK && qual_start) rc = check_windows(c, bases, quals, n_bytes, qual_start, win_len, n_windows);
     if (rc != BMF_OK) return rc;
     HIP_TRY(hipSetDevice(c->p.device));
     rc = map_slots_init(c);
@@ -1689,7 +1785,7 @@ static int map_windows_impl(bmf_ctx *c, const uint8_t *bases, const uint8_t *qua
         }
         span_sum += hi - lo;
     }
-    const bool whole = n_pieces > 1 && span_sum > n_bytes + n_bytes / 2;
+    const bool whole = !qual_start && n_pieces > 1 && span_sum > n_bytes + n_bytes / 2;
     if (whole) {
         HIP_TRY(hipStreamSynchronize(c->stream));
         HIP_TRY(c->whole_bases.need((size_t)n_bytes + 64));
@@ -1702,7 +1798,7 @@ static int map_windows_impl(bmf_ctx *c, const uint8_t *bases, const uint8_t *qua
     for (uint32_t p = 0; p < n_pieces + kLag && rc == BMF_OK; p++) {
         if (p < n_pieces)
             rc = map_piece_issue(c, c->slot[p % bmf_ctx::kMapSlots], bases, quals, win_start, win_len, p * piece,
-                                 std::min(piece, n_windows - p * piece), whole);
+                                 std::min(piece, n_windows - p * piece), whole, qual_start);
         if (rc == BMF_OK && p >= kLag) rc = map_piece_finish(c, c->slot[(p - kLag) % bmf_ctx::kMapSlots], out);
     }
     if (rc != BMF_OK) {   // leave nothing in flight that still reads the caller's buffers

@@ -17,6 +17,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string_view>
+#include <condition_variable>
 #include <fstream>
 #include <functional>
 #include <stdexcept>
@@ -189,15 +190,9 @@ struct FastqRecord {
     std::string_view qual;    // phred+33
 };
 
-// Calls op for every record of a 4-line FASTQ file, in file order.  The mapper, the locator's sampling pass and
-// the SAM pass each walk the whole FASTQ, as the reference does, so this is the host-side bottleneck of the tool.
-//
-// for_each_fastq_stream: the portable form -- the file is read in blocks and lines are found with memchr.
-// for_each_fastq:        the file is mapped and cut into chunks of io_block_bytes(); a few threads find and check the
-//                        records that START in each chunk (a record start is a line that begins with '@' whose line
-//                        after next begins with '+': a quality line may begin with '@', but then the line after
-//                        next is a sequence, and sequences do not begin with '+'), a group of chunks ahead of the one
-//                        whose records are being handed to op; op itself runs on the calling thread only.
+// for_each_fastq_stream: the portable reader for anything that is not a regular file (a pipe) -- the stream is read in
+// blocks and lines are found with memchr; op runs for every record of a 4-line FASTQ stream, in order.  Regular files go
+// through FastqFile / for_each_fastq below.
 inline void for_each_fastq_stream(const std::string &path, const std::function<void(const FastqRecord &)> &op) {
     // closed on every way out, the callback's exceptions included
     std::unique_ptr<FILE, int (*)(FILE *)> file(std::fopen(path.c_str(), "rb"), &std::fclose);
@@ -283,14 +278,20 @@ inline const char *find_record(const char *from, const char *limit, const char *
     return nullptr;
 }
 
+// One record as offsets into the mapped file.
+struct Rec {
+    uint64_t id, seq, qual;     // first byte of the header (after '@'), of the sequence, of the qualities
+    uint32_t id_len, len;
+};
+
 struct Chunk {
-    std::vector<FastqRecord> recs;
+    std::vector<Rec> recs;
     const char *first = nullptr, *stop = nullptr;   // where its first record starts / where parsing stopped
     std::string error;
 };
 
 // Records that start in [begin, limit).  `begin` is a line start (or the start of the file).
-inline void parse_chunk(const char *begin, const char *limit, const char *end, bool is_first, Chunk &out) {
+inline void parse_chunk(const char *data, const char *begin, const char *limit, const char *end, bool is_first, Chunk &out) {
     const char *p = begin;
     if (is_first) {
         while (p < end && (*p == '\n' || *p == '\r')) p++;          // leading blank lines
@@ -334,9 +335,12 @@ inline void parse_chunk(const char *begin, const char *limit, const char *end, b
             out.error = "sequence and quality lengths differ";
             return;
         }
-        out.recs.push_back(FastqRecord{std::string_view(p + 1, static_cast<size_t>(e0 - p - 1)),
-                                       std::string_view(n0, static_cast<size_t>(e1 - n0)),
-                                       std::string_view(n2, static_cast<size_t>(e3 - n2))});
+        if (static_cast<size_t>(e1 - n0) > 0xFFFFFFFFull || static_cast<size_t>(e0 - p - 1) > 0xFFFFFFFFull) {
+            out.error = "FASTQ record longer than 4 Gbases";
+            return;
+        }
+        out.recs.push_back(Rec{static_cast<uint64_t>(p + 1 - data), static_cast<uint64_t>(n0 - data), static_cast<uint64_t>(n2 - data),
+                               static_cast<uint32_t>(e0 - p - 1), static_cast<uint32_t>(e1 - n0)});
         p = n3;
     }
     out.stop = p;
@@ -344,91 +348,186 @@ inline void parse_chunk(const char *begin, const char *limit, const char *end, b
 
 }  // namespace fastq_detail
 
+// A regular FASTQ file, mapped ONCE and indexed ONCE for every pass over it: the reference walks the file three times
+// (mapper, the locator's k-mer sampling, the SAM pass) and so did rounds 1-3 here.  The index (32 bytes a record) is built
+// by a thread of its own -- the file is cut into chunks, a few threads find and check the records that START in each (a
+// record start is a line that begins with '@' whose line after next begins with '+': a quality line may begin with '@',
+// but then the line after next is a sequence, and sequences do not begin with '+') -- and published group by group, so a
+// consumer works on the first records while the last are still being found.  Readers only ever see published records.
+class FastqFile {
+public:
+    using Rec = fastq_detail::Rec;
+    static constexpr size_t kBlock = 1u << 16;       // records per storage block
+
+    // nullptr when `path` is not a regular file that can be mapped (a pipe: for_each_fastq_stream serves it)
+    static std::shared_ptr<FastqFile> open(const std::string &path) {
+        struct stat st {};
+        if (::stat(path.c_str(), &st) != 0) throw std::runtime_error("cannot open FASTQ file " + path);
+        if (!S_ISREG(st.st_mode)) return nullptr;
+        // one file is kept: the passes of a run follow each other (or run side by side) on the same file
+        static std::mutex mu;
+        static std::shared_ptr<FastqFile> last;
+        std::lock_guard<std::mutex> lock(mu);
+        if (last && last->path_ == path && last->dev_ == st.st_dev && last->ino_ == st.st_ino &&
+            last->size_ == static_cast<size_t>(st.st_size) && last->mtime_ns_ == mtime_ns(st))
+            return last;
+        const int fd = ::open(path.c_str(), O_RDONLY);
+        if (fd < 0) throw std::runtime_error("cannot open FASTQ file " + path);
+        const size_t size = static_cast<size_t>(st.st_size);
+        void *map = size ? ::mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0) : nullptr;
+        ::close(fd);
+        if (map == MAP_FAILED) return nullptr;                       // no address space: the block reader
+        std::shared_ptr<FastqFile> f(new FastqFile());
+        f->path_ = path;
+        f->dev_ = st.st_dev;
+        f->ino_ = st.st_ino;
+        f->mtime_ns_ = mtime_ns(st);
+        f->data_ = static_cast<const char *>(map);
+        f->size_ = size;
+        if (size) ::madvise(map, size, MADV_SEQUENTIAL);
+        f->blocks_.resize(size / (6 * kBlock) + 2);                  // a record is at least "@\n\n+\n\n"
+        f->builder_ = std::thread([raw = f.get()]() { raw->build(); });
+        last = f;
+        return f;
+    }
+
+    ~FastqFile() {
+        if (builder_.joinable()) builder_.join();
+        if (data_ && size_) ::munmap(const_cast<char *>(data_), size_);
+    }
+    FastqFile(const FastqFile &) = delete;
+    FastqFile &operator=(const FastqFile &) = delete;
+
+    const char *data() const { return data_; }
+    size_t size() const { return size_; }
+    const std::string &path() const { return path_; }
+
+    // Blocks until `want` records are published or the whole file is indexed; returns how many are (never fewer than an
+    // earlier call returned).  Throws the file's parse error once every record before it has been handed out.
+    size_t wait(size_t want) {
+        size_t n = ready_.load(std::memory_order_acquire);
+        if (n >= want) return n;
+        std::unique_lock<std::mutex> lock(mu_);
+        cv_.wait(lock, [&]() { return ready_.load(std::memory_order_acquire) >= want || done_; });
+        n = ready_.load(std::memory_order_acquire);
+        if (n < want && !error_.empty()) throw std::runtime_error(error_ + " in " + path_);
+        return n;
+    }
+    size_t count() { return wait(~static_cast<size_t>(0)); }         // all of them (waits for the end of the file)
+
+    const Rec &rec(size_t i) const { return blocks_[i / kBlock][i % kBlock]; }
+    FastqRecord view(size_t i) const {
+        const Rec &r = rec(i);
+        return FastqRecord{std::string_view(data_ + r.id, r.id_len), std::string_view(data_ + r.seq, r.len),
+                           std::string_view(data_ + r.qual, r.len)};
+    }
+
+private:
+    FastqFile() = default;
+    static int64_t mtime_ns(const struct stat &st) { return static_cast<int64_t>(st.st_mtim.tv_sec) * 1000000000ll + st.st_mtim.tv_nsec; }
+
+    void publish(size_t n, bool done, std::string error = {}) {
+        std::lock_guard<std::mutex> lock(mu_);
+        ready_.store(n, std::memory_order_release);
+        if (done) {
+            error_ = std::move(error);
+            done_ = true;
+        }
+        cv_.notify_all();
+    }
+
+    void build() {
+        using fastq_detail::Chunk;
+        const char *data = data_, *end = data_ + size_;
+        const size_t chunk = std::min<size_t>(io_block_bytes(), 4u << 20), n_chunks = (size_ + chunk - 1) / chunk;
+        const unsigned threads = std::min<unsigned>(16, std::max(1u, std::thread::hardware_concurrency()));
+        const size_t group = std::max<size_t>(1, std::min<size_t>(threads, n_chunks));
+        size_t n = 0;
+        try {
+            // chunk c covers [c * chunk, (c + 1) * chunk), moved forward to the next line start
+            auto parse_group = [&](size_t g0, std::vector<Chunk> &out) {
+                const size_t cnt = std::min(group, n_chunks - g0);
+                out.assign(cnt, Chunk());
+                std::atomic<size_t> next{0};
+                auto work = [&]() {
+                    for (size_t i = next.fetch_add(1); i < cnt; i = next.fetch_add(1)) {
+                        const size_t c = g0 + i;
+                        const char *b = data + c * chunk, *limit = std::min(end, data + (c + 1) * chunk);
+                        if (c > 0 && b[-1] != '\n') {                // inside a line: this chunk starts at the next one
+                            const char *nl = static_cast<const char *>(std::memchr(b, '\n', static_cast<size_t>(end - b)));
+                            b = nl ? nl + 1 : end;
+                        }
+                        if (b < limit || c == 0) fastq_detail::parse_chunk(data, b, limit, end, c == 0, out[i]);
+                    }
+                };
+                std::vector<std::thread> pool;
+                for (size_t t = 1; t < std::min<size_t>(threads, cnt); t++) pool.emplace_back(work);
+                work();
+                for (auto &t : pool) t.join();
+            };
+            std::vector<Chunk> cur;
+            const char *expect = nullptr;                            // where the next record must start
+            for (size_t g0 = 0; g0 < n_chunks; g0 += group) {
+                parse_group(g0, cur);
+                for (Chunk &c : cur) {
+                    if (c.first) {
+                        // every byte between two records was looked at: the chunks' records join up exactly (blank lines aside)
+                        if (expect) {
+                            const char *q = expect;
+                            while (q < c.first && (*q == '\n' || *q == '\r')) q++;
+                            if (q != c.first) return publish(n, true, "malformed FASTQ record");
+                        }
+                        for (size_t at = 0; at < c.recs.size();) {   // into the storage blocks
+                            const size_t blk = n / kBlock, off = n % kBlock, take = std::min(c.recs.size() - at, kBlock - off);
+                            if (blk >= blocks_.size()) return publish(n, true, "more FASTQ records than the file can hold");
+                            if (!blocks_[blk]) blocks_[blk].reset(new Rec[kBlock]);
+                            std::memcpy(blocks_[blk].get() + off, c.recs.data() + at, take * sizeof(Rec));
+                            at += take;
+                            n += take;
+                        }
+                        expect = c.stop;
+                    }
+                    if (!c.error.empty()) return publish(n, true, c.error);
+                }
+                publish(n, false);
+            }
+            // whatever follows the last record must be blank
+            for (const char *q = expect ? expect : data; q < end; q++)
+                if (*q != '\n' && *q != '\r') return publish(n, true, "truncated FASTQ record");
+            publish(n, true);
+        } catch (const std::exception &e) {
+            publish(n, true, std::string("FASTQ index: ") + e.what());
+        }
+    }
+
+    std::string path_;
+    dev_t dev_ = 0;
+    ino_t ino_ = 0;
+    int64_t mtime_ns_ = 0;
+    const char *data_ = nullptr;
+    size_t size_ = 0;
+    std::vector<std::unique_ptr<Rec[]>> blocks_;
+    std::atomic<size_t> ready_{0};
+    bool done_ = false;
+    std::string error_;
+    std::mutex mu_;
+    std::condition_variable cv_;
+    std::thread builder_;
+};
+
+// Calls op for every record of a 4-line FASTQ file, in file order, on the calling thread (views into the mapped file: valid
+// while the FastqFile lives -- at least for the duration of the call).
 inline void for_each_fastq(const std::string &path, const std::function<void(const FastqRecord &)> &op) {
-    // A pipe (or anything else that is not a regular file) goes to the block reader, and is opened ONCE: opening a FIFO
-    // to look at it and closing it again takes the read end away from the writer.
-    struct stat st {};
-    if (::stat(path.c_str(), &st) != 0) throw std::runtime_error("cannot open FASTQ file " + path);
-    if (!S_ISREG(st.st_mode)) {
+    std::shared_ptr<FastqFile> f = FastqFile::open(path);
+    if (!f) {                                                        // a pipe, or no address space: opened ONCE, read in blocks
         for_each_fastq_stream(path, op);
         return;
     }
-    const int fd = ::open(path.c_str(), O_RDONLY);
-    if (fd < 0) throw std::runtime_error("cannot open FASTQ file " + path);
-    const size_t size = static_cast<size_t>(st.st_size);
-    void *map = size ? ::mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0) : MAP_FAILED;
-    ::close(fd);
-    if (map == MAP_FAILED) {
-        if (size == 0) return;
-        for_each_fastq_stream(path, op);                             // no address space: the block reader
-        return;
+    for (size_t i = 0;;) {
+        const size_t n = f->wait(i + 1);
+        if (n <= i) break;
+        for (; i < n; i++) op(f->view(i));
     }
-    struct Unmap {
-        void *p;
-        size_t n;
-        ~Unmap() { ::munmap(p, n); }
-    } unmap{map, size};
-    ::madvise(map, size, MADV_SEQUENTIAL);
-    const char *data = static_cast<const char *>(map), *end = data + size;
-    const size_t chunk = io_block_bytes(), n_chunks = (size + chunk - 1) / chunk;
-    const unsigned threads = std::min<unsigned>(8, std::max(1u, std::thread::hardware_concurrency()));
-    const size_t group = std::max<size_t>(1, std::min<size_t>(threads, n_chunks));
-    using fastq_detail::Chunk;
-    // chunk c covers [c * chunk, (c + 1) * chunk), moved forward to the next line start
-    auto parse_group = [&](size_t g0, std::vector<Chunk> &out) {
-        const size_t n = std::min(group, n_chunks - g0);
-        out.assign(n, Chunk());
-        std::atomic<size_t> next{0};
-        auto work = [&]() {
-            for (size_t i = next.fetch_add(1); i < n; i = next.fetch_add(1)) {
-                const size_t c = g0 + i;
-                const char *b = data + c * chunk, *limit = std::min(end, data + (c + 1) * chunk);
-                if (c > 0 && b[-1] != '\n') {                        // inside a line: this chunk starts at the next one
-                    const char *nl = static_cast<const char *>(std::memchr(b, '\n', static_cast<size_t>(end - b)));
-                    b = nl ? nl + 1 : end;
-                }
-                if (b < limit || c == 0) fastq_detail::parse_chunk(b, limit, end, c == 0, out[i]);
-            }
-        };
-        std::vector<std::thread> pool;
-        for (size_t t = 1; t < std::min<size_t>(threads, n); t++) pool.emplace_back(work);
-        work();
-        for (auto &t : pool) t.join();
-    };
-    std::vector<Chunk> cur, ahead;
-    std::thread prefetch;
-    struct Joiner {
-        std::thread &t;
-        ~Joiner() {
-            if (t.joinable()) t.join();
-        }
-    } joiner{prefetch};
-    parse_group(0, cur);
-    const char *expect = nullptr;                                    // where the next record must start
-    for (size_t g0 = 0; g0 < n_chunks; g0 += group) {
-        const bool more = g0 + group < n_chunks;
-        if (more) prefetch = std::thread([&, g0]() { parse_group(g0 + group, ahead); });
-        for (Chunk &c : cur) {
-            if (c.first) {
-                // every byte between two records was looked at: the chunks' records join up exactly (blank lines aside)
-                if (expect) {
-                    const char *q = expect;
-                    while (q < c.first && (*q == '\n' || *q == '\r')) q++;
-                    if (q != c.first) throw std::runtime_error("malformed FASTQ record in " + path);
-                }
-                for (const FastqRecord &r : c.recs) op(r);
-                expect = c.stop;
-            }
-            if (!c.error.empty()) throw std::runtime_error(c.error + " in " + path);
-        }
-        if (more) {
-            prefetch.join();
-            cur.swap(ahead);
-        }
-    }
-    // whatever follows the last record must be blank
-    for (const char *q = expect ? expect : data; q < end; q++)
-        if (*q != '\n' && *q != '\r') throw std::runtime_error("truncated FASTQ record in " + path);
 }
 
 // One kept bucket of iterate_through_buckets (utils.h:72-97).

@@ -4,7 +4,7 @@
 // q_gram_mapper (bucket_map/mapper/q_gram_mapper.h:204-646), except that NB is a run-time value.
 // map() keeps the reference's host work -- FASTQ loop, long-read windowing, scatter into per-bucket
 // lists (q_gram_mapper.h:483-557) -- and hands the arithmetic of query_sequence (:414-480) to
-// bmf_map_windows in batches.  With several devices the windows of a batch are split into contiguous
+// bmf_map_text_windows_compact in batches (the windows are views into the mapped FASTQ file).  With several devices the windows of a batch are split into contiguous
 // ranges, one host thread + context per device (index replicated, no collective), and merged in order.
 #pragma once
 
@@ -26,88 +26,99 @@ namespace bm {
 
 // The host half of q_gram_mapper::map, independent of where query_sequence runs.
 //
-// Two batch slots: while the devices work on one batch, the next one is parsed from the FASTQ file into
-// the other (staging buffers come from host_alloc; a batch is at most batch_reads_ reads and batch_bytes_ bases).  Results are
-// scattered strictly in batch order, so the per-bucket lists keep the reference's (read, window) order.
+// The FASTQ file is mapped and indexed ONCE (FastqFile, shared with the locator's passes) and nothing of it is copied on
+// this side: a batch is the window views of a range of reads -- (offset of the bases, offset of the qualities, length) into
+// the mapped file -- and query_windows gathers them where it needs them (the GPU library: into page-locked piece buffers,
+// by a few threads, while the piece before is on the device).  Two batch slots: while the devices work on one batch, the
+// windows of the next are laid out.  The per-bucket lists are built at the END, by a stable counting sort over all
+// batches' results (threads own bucket ranges), so they keep the reference's (read, window) order (q_gram_mapper.h:526-533)
+// and no list is ever grown entry by entry.
 class batched_mapper : public mapper {
 protected:
     unsigned int num_buckets_, read_length_, num_segment_samples_, max_candidates_;
-    size_t batch_reads_ = 1u << 18;   // reads per batch: small enough to overlap parsing with the devices
-    size_t batch_bytes_ = 32u << 20;  // ... and bases per batch (BM_BATCH_MB): 100 000 reads of 300 bp, 3 000 of 10 kbp.  The
-                                      // first batch leaves early and the staging buffers stay small: `mapper::map` for 1 M x 300 bp
-                                      // 0.36 s at 96 MB, 0.18-0.27 s at 32 MB, 0.31 s at 16 MB (tools/e2e_cli.py, BM_LOG_BATCHES=1)
+    size_t batch_reads_ = 1u << 18;   // reads per batch (BM_BATCH_READS) -- the first two are an eighth and a half of it, so that the
+                                      // devices start early; a call's fixed cost (filling and draining its pipeline) is a piece's worth
+    size_t batch_bytes_ = 96u << 20;  // ... and bases per batch (BM_BATCH_MB): 260 000 reads of 300 bp, 9 600 of 10 kbp
+    bool ramp_ = true;                // (off when BM_BATCH_READS is given: tests count on exact batch sizes)
     bool log_batches_ = std::getenv("BM_LOG_BATCHES") != nullptr;   // one stderr line per batch: when it went out, how long it took
 
-    // query_sequence for n windows (views into bases/quals); counts: 2 per window (read as-is, reverse complement),
-    // ids: the candidate lists back to back in that order (resized by the callee).  Returns false on failure
-    // (message already printed).
-    virtual bool query_windows(const uint8_t *bases, const uint8_t *quals, uint64_t n_bytes,
-                               const uint64_t *win_start, const uint32_t *win_len, uint32_t n, uint32_t *counts,
-                               std::vector<uint32_t> &ids) = 0;
+    // query_sequence for n windows: window w = text[seq_start[w], +win_len[w]) with qualities text[qual_start[w], +win_len[w]);
+    // counts: 2 per window (read as-is, reverse complement), ids: the candidate lists back to back in that order (resized
+    // by the callee).  Returns false on failure (message already printed).
+    virtual bool query_windows(const uint8_t *text, uint64_t n_bytes, const uint64_t *seq_start, const uint64_t *qual_start,
+                               const uint32_t *win_len, uint32_t n, uint32_t *counts, std::vector<uint32_t> &ids) = 0;
     virtual bool index_loaded() const = 0;
-    // staging memory for reads (overridden with pinned memory where a device copies from it)
-    virtual uint8_t *host_alloc(size_t bytes) { return static_cast<uint8_t *>(std::malloc(bytes ? bytes : 1)); }
-    virtual void host_free(uint8_t *p) { std::free(p); }
+
+    // for implementations that want the windows back to back (bases and qualities at the same offsets)
+    static void gather_windows(const uint8_t *text, const uint64_t *seq_start, const uint64_t *qual_start, const uint32_t *win_len,
+                               uint32_t n, std::vector<uint8_t> &bases, std::vector<uint8_t> &quals, std::vector<uint64_t> &start) {
+        start.resize(n);
+        uint64_t at = 0;
+        for (uint32_t w = 0; w < n; w++) {
+            start[w] = at;
+            at += win_len[w];
+        }
+        bases.resize(at + 1);
+        quals.resize(at + 1);
+        for (uint32_t w = 0; w < n; w++) {
+            std::memcpy(bases.data() + start[w], text + seq_start[w], win_len[w]);
+            std::memcpy(quals.data() + start[w], text + qual_start[w], win_len[w]);
+        }
+    }
 
 private:
     struct Slot {
-        uint8_t *bases = nullptr, *quals = nullptr;
-        size_t cap = 0, n_bytes = 0, n_reads = 0;
-        unsigned int first_read = 0;
-        std::vector<uint64_t> win_start;
+        std::vector<uint8_t> own;            // pipes only: the batch's sequences and qualities, copied from the stream
+        std::vector<uint64_t> seq_start, qual_start;
         std::vector<uint32_t> win_len, win_read, counts, ids;
         std::vector<int> win_pos;
+        size_t n_reads = 0, n_bases = 0;
         bool ok = true;
+        void clear() {
+            own.clear(); seq_start.clear(); qual_start.clear(); win_len.clear(); win_read.clear(); win_pos.clear();
+            n_reads = n_bases = 0;
+        }
     };
-
-    void slot_reserve(Slot &s, size_t need) {
-        if (need <= s.cap) return;
-        // first allocation: room for a whole batch (one allocation: growing a page-locked buffer by doubling cost a
-        // 10-kbp batch half a second); more only for a single read longer than a batch
-        size_t cap = s.cap ? s.cap : std::max<size_t>(1u << 20, std::min(batch_bytes_, batch_reads_ * static_cast<size_t>(read_length_ + 8)));
-        while (cap < need) cap *= 2;
-        uint8_t *b = host_alloc(cap), *q = b ? host_alloc(cap) : nullptr;
-        if (!b || !q) {
-            if (b) host_free(b);
-            throw std::runtime_error("out of host memory for the read staging buffers");
-        }
-        if (s.n_bytes) {
-            std::memcpy(b, s.bases, s.n_bytes);
-            std::memcpy(q, s.quals, s.n_bytes);
-        }
-        if (s.bases) host_free(s.bases);
-        if (s.quals) host_free(s.quals);
-        s.bases = b;
-        s.quals = q;
-        s.cap = cap;
-    }
+    // what a finished batch leaves behind for the final scatter
+    struct Done {
+        std::vector<uint32_t> win_read, counts, ids;
+        std::vector<int> win_pos;
+    };
 
 public:
     batched_mapper(unsigned int num_buckets, unsigned int read_len, unsigned int num_candidate_buckets,
                    unsigned int num_segment_samples)
         : num_buckets_(num_buckets), read_length_(read_len), num_segment_samples_(num_segment_samples),
           max_candidates_(num_candidate_buckets) {
-        if (const char *e = std::getenv("BM_BATCH_READS")) batch_reads_ = std::max<size_t>(1, std::strtoull(e, nullptr, 10));
+        if (const char *e = std::getenv("BM_BATCH_READS")) {
+            batch_reads_ = std::max<size_t>(1, std::strtoull(e, nullptr, 10));
+            ramp_ = false;
+        }
         if (const char *e = std::getenv("BM_BATCH_MB")) batch_bytes_ = std::max<size_t>(1, std::strtoull(e, nullptr, 10)) << 20;
     }
 
     // q_gram_mapper::map (q_gram_mapper.h:483-557)
     std::pair<segments_t, segments_t> map(std::filesystem::path const &sequence_file) override {
-        unsigned int mapped_reads = 0, num_buckets_orig = 0, num_buckets_rev_comp = 0;
-        segments_t res_orig(num_buckets_), res_rev_comp(num_buckets_);
         auto t0 = std::chrono::steady_clock::now();
+        std::shared_ptr<FastqFile> fq = FastqFile::open(sequence_file.string());   // nullptr: a pipe
+        const uint8_t *text = fq ? reinterpret_cast<const uint8_t *>(fq->data()) : nullptr;
+        const uint64_t text_bytes = fq ? fq->size() : 0;
         Slot slots[2];
+        std::vector<Done> done;
         std::thread worker;
         int cur = 0, in_flight = -1;
+        size_t n_submitted = 0;
+        // the batch being filled is full at: an eighth of a batch, half a batch, then whole batches
+        auto reads_limit = [&]() { return !ramp_ || n_submitted >= 2 ? batch_reads_ : std::max<size_t>(1, batch_reads_ >> (n_submitted ? 1 : 3)); };
+        auto bytes_limit = [&]() { return !ramp_ || n_submitted >= 2 ? batch_bytes_ : std::max<size_t>(1, batch_bytes_ >> (n_submitted ? 1 : 3)); };
         std::vector<uint32_t> starts(num_segment_samples_ ? num_segment_samples_ : 1);
-        std::vector<uint8_t> read_mapped;
 
         // runs on the worker thread: query_sequence for every window of the slot
-        // (an exception must not leave a std::thread: it is turned into a failed batch, reported by scatter)
+        // (an exception must not leave a std::thread: it is turned into a failed batch, reported by collect)
         auto run = [&](Slot &s) {
             s.ok = false;
             try {
-                const uint32_t n = static_cast<uint32_t>(s.win_start.size());
+                const uint32_t n = static_cast<uint32_t>(s.seq_start.size());
                 s.counts.assign(2 * static_cast<size_t>(n), 0);
                 s.ids.clear();
                 s.ok = true;
@@ -117,9 +128,11 @@ public:
                     std::cerr << "[ERROR]\t\tThe q-gram index is empty. Cannot accept query.\n";
                 } else {
                     const auto q0 = std::chrono::steady_clock::now();
-                    s.ok = query_windows(s.bases, s.quals, s.n_bytes, s.win_start.data(), s.win_len.data(), n, s.counts.data(), s.ids);
+                    const uint8_t *src = fq ? text : s.own.data();
+                    s.ok = query_windows(src, fq ? text_bytes : s.own.size(), s.seq_start.data(), s.qual_start.data(), s.win_len.data(), n,
+                                         s.counts.data(), s.ids);
                     if (log_batches_)
-                        std::cerr << "[bm] batch of " << s.n_reads << " reads, " << n << " windows, " << s.n_bytes << " bases: filter "
+                        std::cerr << "[bm] batch of " << s.n_reads << " reads, " << n << " windows, " << s.n_bases << " bases: filter "
                                   << std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - q0).count()
                                   << " ms, " << std::chrono::duration<float, std::milli>(q0 - t0).count() << " ms after map() began\n";
                 }
@@ -128,81 +141,143 @@ public:
                 s.ok = false;
             }
         };
-        // q_gram_mapper.h:526-538: scatter (read, window start) into the per-bucket lists, in batch order
-        auto scatter = [&](Slot &s) {
+        // keeps a finished batch's results for the final scatter, in batch order
+        // ... and counts what it adds to every list (this runs beside the next batch's device work)
+        std::vector<uint32_t> n_orig(num_buckets_, 0), n_rev(num_buckets_, 0);
+        unsigned int mapped_reads = 0, num_buckets_orig = 0, num_buckets_rev_comp = 0, last_mapped = ~0u;
+        auto collect = [&](Slot &s) {
             if (!s.ok) throw std::runtime_error("the candidate-bucket filter failed (see the [ERROR] line above)");
-            const uint32_t n = static_cast<uint32_t>(s.win_start.size());
-            read_mapped.assign(s.n_reads, 0);
+            const size_t n = s.win_read.size();
             const uint32_t *next = s.ids.data();
-            for (uint32_t w = 0; w < n; w++) {
-                const segment_info_t seg{s.win_read[w], s.win_pos[w]};
+            for (size_t w = 0; w < n; w++) {
                 const uint32_t cf = s.counts[2 * w], cr = s.counts[2 * w + 1];
-                const uint32_t *bf = next, *br = next + cf;
-                next += cf + cr;
-                for (uint32_t i = 0; i < cf; i++) res_orig[bf[i]].push_back(seg);
-                for (uint32_t i = 0; i < cr; i++) res_rev_comp[br[i]].push_back(seg);
                 if (cf || cr) {
-                    read_mapped[s.win_read[w] - s.first_read] = 1;
+                    if (s.win_read[w] != last_mapped) ++mapped_reads;
+                    last_mapped = s.win_read[w];
                     num_buckets_orig += cf;
                     num_buckets_rev_comp += cr;
+                    for (uint32_t i = 0; i < cf; i++) ++n_orig[next[i]];
+                    for (uint32_t i = cf; i < cf + cr; i++) ++n_rev[next[i]];
+                    next += cf + cr;
                 }
             }
-            for (uint8_t m : read_mapped) mapped_reads += m;
-            s.win_start.clear(); s.win_len.clear(); s.win_read.clear(); s.win_pos.clear();
-            s.n_bytes = 0;
-            s.n_reads = 0;
+            done.emplace_back();
+            Done &d = done.back();
+            d.win_read.swap(s.win_read);
+            d.win_pos.swap(s.win_pos);
+            d.counts.swap(s.counts);
+            d.ids.swap(s.ids);
+            s.clear();
         };
         auto finish_in_flight = [&]() {
             if (in_flight < 0) return;
             worker.join();
-            scatter(slots[in_flight]);
+            collect(slots[in_flight]);
             in_flight = -1;
         };
-        auto submit = [&]() {   // hand the filled slot to the devices, continue parsing into the other one
+        auto submit = [&]() {   // hand the filled slot to the devices, continue laying out windows in the other one
             finish_in_flight();
             in_flight = cur;
             worker = std::thread(run, std::ref(slots[cur]));
             cur ^= 1;
+            ++n_submitted;
         };
-
-        try {
-            for_each_fastq(sequence_file.string(), [&](const FastqRecord &rec) {
-                const uint32_t len = static_cast<uint32_t>(rec.seq.size());
-                if (slots[cur].n_reads && slots[cur].n_bytes + len > batch_bytes_) submit();   // the batch is full by bytes
-                Slot &s = slots[cur];
-                if (s.n_reads == 0) s.first_read = num_records;
-                slot_reserve(s, s.n_bytes + len);
-                std::memcpy(s.bases + s.n_bytes, rec.seq.data(), len);
-                std::memcpy(s.quals + s.n_bytes, rec.qual.data(), len);
-                // q_gram_mapper.h:510-523: window starts {0}, or Sampler(5) for reads longer than 2*read_len
+        // q_gram_mapper.h:510-523: window starts {0}, or Sampler(5) for reads longer than 2*read_len
+        auto add_read = [&](uint64_t seq_off, uint64_t qual_off, uint32_t len) {
+            Slot &s = slots[cur];
+            if (len <= 2 * read_length_) {
+                s.seq_start.push_back(seq_off);
+                s.qual_start.push_back(qual_off);
+                s.win_len.push_back(std::min(read_length_, len));
+                s.win_read.push_back(num_records);
+                s.win_pos.push_back(0);
+            } else {
                 const uint32_t nw = bmf_window_starts(len, read_length_, num_segment_samples_, starts.data());
                 for (uint32_t i = 0; i < nw; i++) {
                     const uint32_t st = starts[i];
-                    s.win_start.push_back(s.n_bytes + st);
+                    s.seq_start.push_back(seq_off + st);
+                    s.qual_start.push_back(qual_off + st);
                     s.win_len.push_back(std::min(st + read_length_, len) - st);
                     s.win_read.push_back(num_records);
                     s.win_pos.push_back(static_cast<int>(st));
                 }
-                s.n_bytes += len;
-                ++num_records;
-                if (++s.n_reads >= batch_reads_) submit();
-            });
+            }
+            s.n_bases += len;
+            ++num_records;
+            if (++s.n_reads >= reads_limit()) submit();
+        };
+
+        try {
+            if (fq) {
+                for (size_t i = 0;;) {
+                    const size_t n = fq->wait(i + 1);
+                    if (n <= i) break;
+                    for (; i < n; i++) {
+                        const FastqFile::Rec &r = fq->rec(i);
+                        if (slots[cur].n_reads && slots[cur].n_bases + r.len > bytes_limit()) submit();   // the batch is full by bytes
+                        add_read(r.seq, r.qual, r.len);
+                    }
+                }
+            } else {
+                for_each_fastq_stream(sequence_file.string(), [&](const FastqRecord &rec) {
+                    const uint32_t len = static_cast<uint32_t>(rec.seq.size());
+                    if (slots[cur].n_reads && slots[cur].n_bases + len > bytes_limit()) submit();
+                    Slot &s = slots[cur];
+                    const uint64_t at = s.own.size();
+                    s.own.insert(s.own.end(), rec.seq.begin(), rec.seq.end());
+                    s.own.insert(s.own.end(), rec.qual.begin(), rec.qual.end());
+                    add_read(at, at + len, len);
+                });
+            }
             if (slots[cur].n_reads) submit();
             finish_in_flight();
         } catch (...) {
             if (worker.joinable()) worker.join();
-            for (Slot &s : slots) {
-                if (s.bases) host_free(s.bases);
-                if (s.quals) host_free(s.quals);
-            }
             throw;
         }
-        for (Slot &s : slots) {
-            if (s.bases) host_free(s.bases);
-            if (s.quals) host_free(s.quals);
+
+        // q_gram_mapper.h:526-538: (read, window start) into the per-bucket lists, in (batch, window) order = read order.
+        // A stable counting sort: threads own bucket ranges, count their lists' lengths, size them once, fill them.
+        const auto t_batches = std::chrono::steady_clock::now();
+        segments_t res_orig(num_buckets_), res_rev_comp(num_buckets_);
+        {
+            const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+            const unsigned T = static_cast<unsigned>(std::min<size_t>(std::min(16u, hw), std::max<size_t>(1, (static_cast<size_t>(num_buckets_orig) + num_buckets_rev_comp) / 50000)));
+            auto scatter = [&](unsigned t) {
+                const uint32_t b0 = static_cast<uint32_t>(static_cast<uint64_t>(num_buckets_) * t / T);
+                const uint32_t b1 = static_cast<uint32_t>(static_cast<uint64_t>(num_buckets_) * (t + 1) / T);
+                for (uint32_t b = b0; b < b1; b++) {                 // every list sized once
+                    if (n_orig[b]) res_orig[b].reserve(n_orig[b]);
+                    if (n_rev[b]) res_rev_comp[b].reserve(n_rev[b]);
+                }
+                for (const Done &d : done) {
+                    const size_t n = d.win_read.size();
+                    const uint32_t *next = d.ids.data();
+                    for (size_t w = 0; w < n; w++) {
+                        const uint32_t cf = d.counts[2 * w], cr = d.counts[2 * w + 1];
+                        for (uint32_t i = 0; i < cf + cr; i++) {
+                            const uint32_t b = next[i];
+                            if (b >= b0 && b < b1) (i < cf ? res_orig : res_rev_comp)[b].emplace_back(d.win_read[w], d.win_pos[w]);
+                        }
+                        next += cf + cr;
+                    }
+                }
+            };
+            if (T <= 1) {
+                scatter(0);
+            } else {
+                std::vector<std::thread> pool;
+                for (unsigned t = 1; t < T; t++) pool.emplace_back(scatter, t);
+                scatter(0);
+                for (auto &th : pool) th.join();
+            }
         }
 
-        const float time = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count() / 1000.0f;
+        if (log_batches_)
+            std::cerr << "[bm] all batches done " << std::chrono::duration<float, std::milli>(t_batches - t0).count()
+                      << " ms after map() began; per-bucket lists built in "
+                      << std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_batches).count() << " ms\n";
+        const float time = std::chrono::duration<float>(std::chrono::steady_clock::now() - t0).count();
         // q_gram_mapper.h:548-555 (the reference divides by the running num_records)
         std::cerr << "[BENCHMARK]\tElapsed time for bucket mapping: " << time << " s (" << time * 1000 * 1000 / num_records
                   << " μs/seq).\n";
@@ -224,16 +299,21 @@ public:
         query_result_t res;
         auto t0 = std::chrono::steady_clock::now();
         std::vector<uint8_t> bases, quals;
-        std::vector<uint64_t> win_start;
+        std::vector<uint64_t> win_start, qual_start;
         std::vector<uint32_t> win_len, counts, ids;
         auto flush = [&]() {
             const uint32_t n = static_cast<uint32_t>(win_start.size());
             if (n == 0) return;
             counts.assign(2 * static_cast<size_t>(n), 0);
             ids.clear();
+            // one text: the batch's sequences, then its qualities
+            const uint64_t n_bases = bases.size();
+            bases.insert(bases.end(), quals.begin(), quals.end());
+            qual_start.resize(n);
+            for (uint32_t w = 0; w < n; w++) qual_start[w] = n_bases + win_start[w];
             if (!index_loaded()) {
                 std::cerr << "[ERROR]\t\tThe q-gram index is empty. Cannot accept query.\n";
-            } else if (!query_windows(bases.data(), quals.data(), bases.size(), win_start.data(), win_len.data(), n, counts.data(), ids)) {
+            } else if (!query_windows(bases.data(), bases.size(), win_start.data(), qual_start.data(), win_len.data(), n, counts.data(), ids)) {
                 throw std::runtime_error("the candidate-bucket filter failed (see the [ERROR] line above)");
             }
             const uint32_t *next = ids.data();
@@ -300,29 +380,14 @@ class gpu_q_gram_mapper : public batched_mapper {
 
 protected:
     bool index_loaded() const override { return loaded_; }
-    // Staging: ordinary memory.  bmf_map_windows_compact moves the reads in pieces through page-locked buffers of its own,
-    // at the same speed from either kind of source (bench.py, pcie_inclusive: 58.0 ms page-locked, 58.1 ms pageable),
-    // and page-locking four batch-sized buffers cost the tool more than it could ever return.  BM_PINNED_STAGING=1: the
-    // round-1 behaviour.
-    bool pinned_staging_ = std::getenv("BM_PINNED_STAGING") != nullptr;
-    uint8_t *host_alloc(size_t bytes) override {
-        if (!pinned_staging_) return batched_mapper::host_alloc(bytes);
-        void *p = nullptr;
-        return bmf_pinned_alloc(bytes, &p) == BMF_OK ? static_cast<uint8_t *>(p) : nullptr;
-    }
-    void host_free(uint8_t *p) override {
-        if (!pinned_staging_) return batched_mapper::host_free(p);
-        bmf_pinned_free(p);
-    }
-
-    bool query_windows(const uint8_t *bases, const uint8_t *quals, uint64_t n_bytes, const uint64_t *win_start,
+    bool query_windows(const uint8_t *text, uint64_t n_bytes, const uint64_t *seq_start, const uint64_t *qual_start,
                        const uint32_t *win_len, uint32_t n, uint32_t *counts, std::vector<uint32_t> &ids) override {
         const size_t D = ctx_.size();
         std::vector<int> rc(D, BMF_OK);
         std::vector<std::string> msg(D);
         std::vector<uint64_t> used(D, 0);
-        // every context is handed the shared buffers and ITS window range: bmf_map_windows_compact uploads only the
-        // byte span those windows cover, and packs the range's candidate lists into the device's own buffer
+        // every context is handed the shared text and ITS window range: bmf_map_text_windows_compact gathers and uploads only
+        // those windows, and packs the range's candidate lists into the device's own buffer
         auto work = [&](size_t d) {
             const uint32_t w0 = static_cast<uint32_t>(static_cast<uint64_t>(n) * d / D);
             const uint32_t w1 = static_cast<uint32_t>(static_cast<uint64_t>(n) * (d + 1) / D);
@@ -331,8 +396,8 @@ protected:
                 ids_buf_[d].reset(new uint32_t[cap]);
                 ids_cap_[d] = cap;
             }
-            rc[d] = bmf_map_windows_compact(ctx_[d], bases, quals, n_bytes, win_start + w0, win_len + w0, w1 - w0,
-                                            counts + 2 * static_cast<size_t>(w0), ids_buf_[d].get(), cap, &used[d]);
+            rc[d] = bmf_map_text_windows_compact(ctx_[d], text, n_bytes, seq_start + w0, qual_start + w0, win_len + w0, w1 - w0,
+                                                 counts + 2 * static_cast<size_t>(w0), ids_buf_[d].get(), cap, &used[d]);
             if (rc[d] != BMF_OK) msg[d] = bmf_last_error();
         };
         if (D == 1) {
@@ -412,6 +477,12 @@ public:
             if (rc != BMF_OK) throw std::runtime_error(std::string("loading the index failed: ") + bmf_last_error());
         }
         loaded_ = true;
+        // the staging buffers of map()'s calls, now: its first batch then pays for neither page-locking nor device allocations
+        for (bmf_ctx *c : ctx_) {
+            const size_t per_call = std::min<size_t>(batch_reads_, batch_bytes_ / std::max(1u, read_length_)) / ctx_.size() + 1;
+            if (bmf_map_reserve(c, static_cast<uint32_t>(std::min<size_t>(per_call, 1u << 24)), 1) != BMF_OK)
+                std::cerr << "[WARNING]\t" << bmf_last_error() << "\n";
+        }
         {   // distinguishability_filter::read's log line (q_gram_mapper.h:171-186): rows with MORE zeros than the threshold
             uint64_t n_rows = 0;
             if (bmf_index_download(ctx_[0], nullptr, &n_rows) == BMF_OK && n_rows) {

@@ -60,6 +60,9 @@ SYMBOLS = {
     "bmf_map_windows": (C.c_int, [C.c_void_p, _u8p, _u8p, C.c_uint64, _u64p, _u32p, C.c_uint32, _u32p, _u32p]),
     "bmf_map_windows_compact": (C.c_int, [C.c_void_p, _u8p, _u8p, C.c_uint64, _u64p, _u32p, C.c_uint32, _u32p, _u32p,
                                           C.c_uint64, _u64p]),
+    "bmf_map_reserve": (C.c_int, [C.c_void_p, C.c_uint32, C.c_int]),
+    "bmf_map_text_windows_compact": (C.c_int, [C.c_void_p, _u8p, C.c_uint64, _u64p, _u64p, _u32p, C.c_uint32, _u32p, _u32p,
+                                               C.c_uint64, _u64p]),
     "bmf_batch_create": (C.c_int, [C.c_void_p, _u8p, _u8p, C.c_uint64, _u64p, _u32p, C.c_uint32,
                                    C.POINTER(C.c_void_p)]),
     "bmf_batch_run": (C.c_int, [C.c_void_p, C.c_void_p]),
@@ -355,6 +358,23 @@ class Filter:
         _check(lib().bmf_map_windows_compact(self._h, _ptr(bases, _u8p), _ptr(quals, _u8p), len(bases), _ptr(win_start, _u64p),
                                              _ptr(win_len, _u32p), n, _ptr(counts, _u32p), _ptr(ids, _u32p), ids.size,
                                              C.byref(used)))
+        return counts, ids[: used.value]
+
+    def map_text_windows_compact(self, text, seq_start, qual_start, win_len, out=None):
+        """bmf_map_text_windows_compact: windows whose bases and qualities lie apart in one buffer (a FASTQ text); the
+        library gathers them.  Returns (counts[n,2], ids) as map_windows_compact."""
+        text = np.ascontiguousarray(text, dtype=np.uint8)
+        seq_start = np.ascontiguousarray(seq_start, dtype=np.uint64)
+        qual_start = np.ascontiguousarray(qual_start, dtype=np.uint64)
+        win_len = np.ascontiguousarray(win_len, dtype=np.uint32)
+        n = len(seq_start)
+        if out is None:
+            out = (np.zeros((n, 2), dtype=np.uint32), np.empty(2 * n * self.params.max_candidates, dtype=np.uint32))
+        counts, ids = out
+        used = C.c_uint64()
+        _check(lib().bmf_map_text_windows_compact(self._h, _ptr(text, _u8p), len(text), _ptr(seq_start, _u64p), _ptr(qual_start, _u64p),
+                                                  _ptr(win_len, _u32p), n, _ptr(counts, _u32p), _ptr(ids, _u32p), ids.size,
+                                                  C.byref(used)))
         return counts, ids[: used.value]
 
     def batch(self, bases, quals, win_start, win_len) -> Batch:

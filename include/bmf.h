@@ -139,6 +139,21 @@ int  bmf_map_windows_compact(bmf_ctx *ctx, const uint8_t *bases, const uint8_t *
                              const uint64_t *win_start, const uint32_t *win_len, uint32_t n_windows,
                              uint32_t *out_counts, uint32_t *out_ids, uint64_t ids_capacity, uint64_t *n_ids);
 
+/* The same call for reads that do NOT lie as bmf_map_windows wants them: a FASTQ text, where a read's bases and its
+ * qualities are apart.  Window w = text[seq_start[w] .. +win_len[w]) with qualities text[qual_start[w] .. +win_len[w]).
+ * The library gathers the windows of a piece back to back into page-locked buffers of its own (a few host threads,
+ * BMF_GATHER_THREADS) while the piece before is on the device, so the caller copies nothing: what `bucketmap` calls with
+ * the memory-mapped FASTQ file.  Outputs as bmf_map_windows_compact. */
+int  bmf_map_text_windows_compact(bmf_ctx *ctx, const uint8_t *text, uint64_t n_bytes, const uint64_t *seq_start,
+                                  const uint64_t *qual_start, const uint32_t *win_len, uint32_t n_windows,
+                                  uint32_t *out_counts, uint32_t *out_ids, uint64_t ids_capacity, uint64_t *n_ids);
+
+/* Optional: sizes the staging buffers of bmf_map_windows[_compact] (text_windows = 0) or bmf_map_text_windows_compact
+ * (text_windows = 1) for calls of up to max_windows_per_call windows of read_len bases NOW -- a mapper calls it when it
+ * loads its index, so that its first batch does not pay for page-locking and device allocations.  Buffers still grow on
+ * demand. */
+int  bmf_map_reserve(bmf_ctx *ctx, uint32_t max_windows_per_call, int text_windows);
+
 /* Device-resident form (benchmarks, pipelines): upload once, run many times, download when needed. */
 int  bmf_batch_create(bmf_ctx *ctx, const uint8_t *bases, const uint8_t *quals, uint64_t n_bytes,
                       const uint64_t *win_start, const uint32_t *win_len, uint32_t n_windows, bmf_batch **out);

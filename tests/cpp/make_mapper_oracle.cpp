@@ -23,10 +23,13 @@ class oracle_mapper : public bm::batched_mapper {
 
 protected:
     bool index_loaded() const override { return ix_ != nullptr; }
-    bool query_windows(const uint8_t *bases, const uint8_t *quals, uint64_t, const uint64_t *win_start,
+    bool query_windows(const uint8_t *text, uint64_t, const uint64_t *seq_start, const uint64_t *qual_start,
                        const uint32_t *win_len, uint32_t n, uint32_t *counts, std::vector<uint32_t> &ids) override {
         std::vector<uint32_t> dense(2 * static_cast<size_t>(n) * p_.max_candidates);
-        bmo_map_windows(ix_, bases, quals, win_start, win_len, n, counts, dense.data());
+        std::vector<uint8_t> bases, quals;
+        std::vector<uint64_t> win_start;
+        gather_windows(text, seq_start, qual_start, win_len, n, bases, quals, win_start);
+        bmo_map_windows(ix_, bases.data(), quals.data(), win_start.data(), win_len, n, counts, dense.data());
         for (size_t i = 0; i < 2 * static_cast<size_t>(n); i++)
             ids.insert(ids.end(), dense.begin() + i * p_.max_candidates, dense.begin() + i * p_.max_candidates + counts[i]);
         return true;

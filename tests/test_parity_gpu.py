@@ -326,6 +326,55 @@ def test_ragged_and_degenerate_windows(ecoli_like):
     flt.close()
 
 
+@pytest.mark.parametrize("flags", [0, 1])
+def test_windows_gathered_from_a_fastq_text(ecoli_like, flags, monkeypatch):
+    """bmf_map_text_windows_compact (what `bucketmap` calls with the memory-mapped FASTQ file): bases and qualities of a
+    window lie apart in one buffer and the library gathers them piece by piece, by several threads -- same counts and ids
+    as bmf_map_windows_compact on the same windows laid out back to back; windows out of order, overlapping, empty,
+    and pieces smaller than the thread count's share included."""
+    case = ecoli_like
+    rd = case.reads
+    rng = np.random.default_rng(77)
+    text, seq_at, qual_at, lens = [], [], [], []
+    at = 0
+    for r in range(rd.n):
+        o0, o1 = int(rd.offsets[r]), int(rd.offsets[r + 1])
+        b, q = rd.bases[o0:o1], rd.quals[o0:o1]
+        head = np.frombuffer(f"@read{r} some description\n".encode(), np.uint8)
+        text += [head, b, np.frombuffer(b"\n+\n", np.uint8), q, np.frombuffer(b"\n", np.uint8)]
+        seq_at.append(at + len(head))
+        qual_at.append(at + len(head) + len(b) + 3)
+        lens.append(min(len(b), case.read_len))
+        at += len(head) + 2 * len(b) + 4
+    text = np.concatenate(text)
+    seq_at, qual_at, lens = np.array(seq_at, np.uint64), np.array(qual_at, np.uint64), np.array(lens, np.uint32)
+    # a few windows again, shifted and shortened (overlapping views), an empty one, and everything shuffled
+    extra = rng.integers(0, rd.n, 40)
+    seq_at = np.concatenate([seq_at, seq_at[extra] + 7, seq_at[:1]])
+    qual_at = np.concatenate([qual_at, qual_at[extra] + 7, qual_at[:1]])
+    lens = np.concatenate([lens, lens[extra] - 7, np.zeros(1, np.uint32)]).astype(np.uint32)
+    perm = rng.permutation(len(lens))
+    seq_at, qual_at, lens = seq_at[perm], qual_at[perm], lens[perm]
+    # reference layout: the same windows back to back
+    ws = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.uint64)
+    bases = np.concatenate([text[int(a): int(a) + int(n)] for a, n in zip(seq_at, lens)] + [np.zeros(1, np.uint8)])
+    quals = np.concatenate([text[int(a): int(a) + int(n)] for a, n in zip(qual_at, lens)] + [np.zeros(1, np.uint8)])
+    f = case.gpu_filter(flags=flags)
+    want_c, want_ids = f.map_windows_compact(bases, quals, ws, lens)
+    want_ids = want_ids.copy()
+    for threads, piece in (("1", "100000"), ("5", "64"), ("3", "97")):
+        monkeypatch.setenv("BMF_PIECE_WINDOWS", piece)
+        monkeypatch.setenv("BMF_GATHER_THREADS", threads)
+        got_c, got_ids = f.map_text_windows_compact(text, seq_at, qual_at, lens)
+        assert np.array_equal(got_c, want_c) and np.array_equal(got_ids, want_ids), (threads, piece)
+    assert want_c.sum() > 0.9 * rd.n
+    # a window past the end of the text is an error, not a read
+    import bucket_map_amd as bma
+    with pytest.raises(bma.BmfError):
+        f.map_text_windows_compact(text, seq_at, np.full_like(qual_at, len(text)), lens)
+    f.close()
+
+
 def test_golden_reads_on_gpu():
     import bucket_map_amd as bma
     with open(os.path.join(GOLDEN, "reads_small.json")) as f:
