@@ -3,7 +3,10 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <cstring>
 #include <mutex>
+#include <thread>
 #include <tuple>
 #include <vector>
 
@@ -29,6 +32,59 @@ inline hipError_t raise_dynamic_lds(const void *fn, size_t bytes) {
     r = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
     if (r == hipSuccess) seen.emplace_back(fn, dev, bytes);
     return r;
+}
+
+// memcpy by a few threads (a page-cache or heap source into a page-locked buffer runs at 5-8 GB/s per thread)
+inline void parallel_memcpy(void *dst, const void *src, size_t bytes, unsigned threads) {
+    if (threads <= 1 || bytes < (4u << 20)) {
+        std::memcpy(dst, src, bytes);
+        return;
+    }
+    std::vector<std::thread> pool;
+    auto part = [&](unsigned t) {
+        const size_t lo = bytes * t / threads, hi = bytes * (t + 1) / threads;
+        std::memcpy(static_cast<char *>(dst) + lo, static_cast<const char *>(src) + lo, hi - lo);
+    };
+    for (unsigned t = 1; t < threads; t++) pool.emplace_back(part, t);
+    part(0);
+    for (auto &t : pool) t.join();
+}
+
+// A large upload from ORDINARY host memory: hipMemcpy from pageable memory stages through the runtime's own small
+// buffers on one thread (4-6 GB/s: 0.3 s for a 1.7 Gbp genome); here the source goes through two page-locked 32 MiB
+// buffers, filled by a few threads while the buffer before is on the link.  Synchronous: returns when the data is there.
+inline hipError_t upload_pageable(void *dst, const void *src, size_t bytes) {
+    constexpr size_t kPiece = 32u << 20;
+    if (bytes < 2 * kPiece) return bytes ? hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice) : hipSuccess;
+    void *stage[2] = {nullptr, nullptr};
+    hipEvent_t done[2] = {nullptr, nullptr};
+    hipStream_t stream = nullptr;
+    hipError_t e = hipStreamCreateWithFlags(&stream, hipStreamNonBlocking);
+    for (int i = 0; i < 2 && e == hipSuccess; i++) {
+        e = hipHostMalloc(&stage[i], kPiece, hipHostMallocDefault);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&done[i], hipEventDisableTiming);
+    }
+    const unsigned threads = std::max(1u, std::min(6u, std::thread::hardware_concurrency() / 2u));
+    size_t piece = 0;
+    for (size_t at = 0; e == hipSuccess && at < bytes; at += kPiece, piece++) {
+        const int slot = (int)(piece & 1);
+        const size_t n = std::min(kPiece, bytes - at);
+        if (piece >= 2) e = hipEventSynchronize(done[slot]);           // the buffer's previous copy has left it
+        if (e != hipSuccess) break;
+        parallel_memcpy(stage[slot], static_cast<const char *>(src) + at, n, threads);
+        e = hipMemcpyAsync(static_cast<char *>(dst) + at, stage[slot], n, hipMemcpyHostToDevice, stream);
+        if (e == hipSuccess) e = hipEventRecord(done[slot], stream);
+    }
+    if (stream) {
+        const hipError_t s = hipStreamSynchronize(stream);
+        if (e == hipSuccess) e = s;
+    }
+    for (int i = 0; i < 2; i++) {
+        if (done[i]) (void)hipEventDestroy(done[i]);
+        if (stage[i]) (void)hipHostFree(stage[i]);
+    }
+    if (stream) (void)hipStreamDestroy(stream);
+    return e;
 }
 
 }  // namespace bmhip

@@ -15,6 +15,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <thread>
 #include <vector>
 
 namespace {
@@ -93,11 +94,36 @@ struct bml_ctx {
     DevBuf<uint32_t> s_win_len, s_hash;
     DevBuf<uint16_t> s_pos, s_table;
     uint32_t s_table_len = 0;        // windows up to this length are tabulated
+    // bml_sample_text_windows: two page-locked slots for the gathered windows, two for the results
+    uint8_t *t_bases[2] = {nullptr, nullptr}, *t_quals[2] = {nullptr, nullptr}, *t_out[2] = {nullptr, nullptr};
+    size_t t_cap[2] = {0, 0}, t_out_cap[2] = {0, 0};
+    hipEvent_t t_done[2] = {nullptr, nullptr};
     DevBuf<unsigned long long> occ_count;
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // scan | (gap) | light replay | heavy replay
     float ms[3] = {0, 0, 0};         // scan kernels | host time between and around the kernels | replay kernels
     uint64_t last_occ = 0;
 };
+
+// Sampler(p).sample_deterministically(n - 1) for every possible selection size n (utils.h:160-178), in
+// fp64 on the host so that device rounding can never differ; tabulated for windows of up to max_len bases
+static int sampler_table(bml_ctx *c, uint32_t max_len) {
+    if (max_len <= c->s_table_len) return BML_OK;
+    const uint32_t k = c->p.k, p = c->p.num_samples;
+    HIP_TRY(hipStreamSynchronize(c->stream));                    // (a kernel in flight may still read the old table)
+    const uint32_t max_nk = max_len >= k ? max_len - k + 1 : 0;
+    std::vector<uint16_t> tab((size_t)(max_nk + 1) * p, 0);
+    for (uint32_t n = 1; n <= max_nk; n++) {
+        const uint32_t ub = n - 1;
+        double delta = 0.0;
+        if (p != 1) delta = (double)(ub + 1u) / (double)(p - 1u);
+        for (uint32_t s = 0; s + 1 < p; s++) tab[(size_t)n * p + s] = (uint16_t)floor((double)s * delta);
+        tab[(size_t)n * p + p - 1] = (uint16_t)ub;
+    }
+    HIP_TRY(c->s_table.need(tab.size()));
+    HIP_TRY(hipMemcpy(c->s_table.p, tab.data(), tab.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    c->s_table_len = max_len;
+    return BML_OK;
+}
 
 extern "C" {
 
@@ -162,6 +188,12 @@ void bml_destroy(bml_ctx *c) {
     c->out_offset.release(); c->chunks.release(); c->occ_count.release();
     c->s_bases.release(); c->s_quals.release(); c->s_has.release(); c->s_win_start.release(); c->s_win_len.release();
     c->s_hash.release(); c->s_pos.release(); c->s_table.release();
+    for (int i = 0; i < 2; i++) {
+        if (c->t_bases[i]) (void)hipHostFree(c->t_bases[i]);
+        if (c->t_quals[i]) (void)hipHostFree(c->t_quals[i]);
+        if (c->t_out[i]) (void)hipHostFree(c->t_out[i]);
+        if (c->t_done[i]) (void)hipEventDestroy(c->t_done[i]);
+    }
     for (auto &e : c->ev)
         if (e) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -189,22 +221,7 @@ int bml_sample_windows(bml_ctx *c, const uint8_t *bases, const uint8_t *quals, u
     HIP_TRY(hipSetDevice(c->p.device));
     if (lds > 48 * 1024)
         HIP_TRY(bmhip::raise_dynamic_lds(reinterpret_cast<const void *>(bml::bml_sample_kernel), lds));
-    // Sampler(p).sample_deterministically(n - 1) for every possible selection size n (utils.h:160-178), in
-    // fp64 on the host so that device rounding can never differ
-    if (max_len > c->s_table_len) {
-        const uint32_t max_nk = max_len >= k ? max_len - k + 1 : 0;
-        std::vector<uint16_t> tab((size_t)(max_nk + 1) * p, 0);
-        for (uint32_t n = 1; n <= max_nk; n++) {
-            const uint32_t ub = n - 1;
-            double delta = 0.0;
-            if (p != 1) delta = (double)(ub + 1u) / (double)(p - 1u);
-            for (uint32_t s = 0; s + 1 < p; s++) tab[(size_t)n * p + s] = (uint16_t)floor((double)s * delta);
-            tab[(size_t)n * p + p - 1] = (uint16_t)ub;
-        }
-        HIP_TRY(c->s_table.need(tab.size()));
-        HIP_TRY(hipMemcpy(c->s_table.p, tab.data(), tab.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
-        c->s_table_len = max_len;
-    }
+    if (int rc = sampler_table(c, max_len)) return rc;
     HIP_TRY(c->s_bases.need((size_t)n_bytes));
     HIP_TRY(c->s_quals.need((size_t)n_bytes));
     HIP_TRY(c->s_win_start.need(n_windows));
@@ -230,6 +247,123 @@ int bml_sample_windows(bml_ctx *c, const uint8_t *bases, const uint8_t *quals, u
     return BML_OK;
 }
 
+// The same sampling for windows whose bases and qualities lie apart in one buffer (a FASTQ text): the library gathers a
+// piece's windows back to back into page-locked buffers (a few threads) while the piece before is on the device.
+int bml_sample_text_windows(bml_ctx *c, const uint8_t *text, uint64_t n_bytes, const uint64_t *seq_start, const uint64_t *qual_start,
+                            const uint32_t *win_len, uint32_t n_windows, uint32_t min_base_quality, uint32_t *out_hash,
+                            uint16_t *out_pos, uint8_t *out_has) {
+    if (!c) return fail(BML_ERR_ARG, "bml_sample_text_windows: null context");
+    if (n_windows == 0) return BML_OK;
+    if (!seq_start || !qual_start || !win_len || !out_hash || !out_pos || !out_has || (n_bytes && !text))
+        return fail(BML_ERR_ARG, "bml_sample_text_windows: null argument");
+    uint32_t max_len = 1;
+    for (uint32_t w = 0; w < n_windows; w++) {
+        if (seq_start[w] > n_bytes || win_len[w] > n_bytes - seq_start[w] || qual_start[w] > n_bytes || win_len[w] > n_bytes - qual_start[w])
+            return fail(BML_ERR_ARG, "window %u lies outside the text", w);
+        if (win_len[w] > 0xFFFFu) return fail(BML_ERR_UNSUPPORTED, "window %u is %u bases long (positions are 16-bit)", w, win_len[w]);
+        max_len = std::max(max_len, win_len[w]);
+    }
+    HIP_TRY(hipSetDevice(c->p.device));
+    // pieces of about 32 MiB of bases; two page-locked slots in, two out
+    const uint32_t piece = std::max<uint32_t>(1024u, (uint32_t)std::min<uint64_t>(1u << 20, ((uint64_t)32 << 20) / max_len));
+    const uint32_t p = c->p.num_samples;
+    const size_t res_bytes = ((size_t)piece * (p * 6u + 1u) + 7u) & ~(size_t)7;      // hash | pos | has, then the piece's window views:
+    const size_t out_bytes = res_bytes + (size_t)piece * 12;                         // start u64[piece] | len u32[piece]
+    for (int i = 0; i < 2; i++) {
+        if (!c->t_done[i]) HIP_TRY(hipEventCreateWithFlags(&c->t_done[i], hipEventDisableTiming));
+        if (c->t_cap[i] < (size_t)piece * max_len + 64 || c->t_out_cap[i] < out_bytes) {
+            if (c->t_bases[i]) (void)hipHostFree(c->t_bases[i]);
+            if (c->t_quals[i]) (void)hipHostFree(c->t_quals[i]);
+            if (c->t_out[i]) (void)hipHostFree(c->t_out[i]);
+            c->t_bases[i] = c->t_quals[i] = c->t_out[i] = nullptr;
+            c->t_cap[i] = c->t_out_cap[i] = 0;
+            HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&c->t_bases[i]), (size_t)piece * max_len + 64, hipHostMallocDefault));
+            HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&c->t_quals[i]), (size_t)piece * max_len + 64, hipHostMallocDefault));
+            HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&c->t_out[i]), out_bytes, hipHostMallocDefault));
+            c->t_cap[i] = (size_t)piece * max_len + 64;
+            c->t_out_cap[i] = out_bytes;
+        }
+    }
+    // the device buffers at a piece's largest, once: the pieces follow each other on the stream, none may be re-allocated
+    // under the one before
+    if (int rc = sampler_table(c, max_len)) return rc;
+    HIP_TRY(c->s_bases.need((size_t)piece * max_len + 64));
+    HIP_TRY(c->s_quals.need((size_t)piece * max_len + 64));
+    HIP_TRY(c->s_win_start.need(piece));
+    HIP_TRY(c->s_win_len.need(piece));
+    HIP_TRY(c->s_hash.need((size_t)piece * p));
+    HIP_TRY(c->s_pos.need((size_t)piece * p));
+    HIP_TRY(c->s_has.need(piece));
+    const unsigned hw = std::max(1u, std::min(6u, std::thread::hardware_concurrency() / 2u));
+    struct InFlight { uint32_t first = 0, n = 0; bool busy = false; } fl[2];
+    auto finish = [&](int slot) -> int {                         // the piece's results, from the page-locked slot to the caller
+        if (!fl[slot].busy) return BML_OK;
+        HIP_TRY(hipEventSynchronize(c->t_done[slot]));
+        const uint32_t first = fl[slot].first, n = fl[slot].n;
+        const uint8_t *o = c->t_out[slot];
+        memcpy(out_hash + (size_t)first * p, o, (size_t)n * p * 4);
+        memcpy(out_pos + (size_t)first * p, o + (size_t)piece * p * 4, (size_t)n * p * 2);
+        memcpy(out_has + first, o + (size_t)piece * p * 6, n);
+        fl[slot].busy = false;
+        return BML_OK;
+    };
+    uint32_t n_piece = 0;
+    for (uint32_t first = 0; first < n_windows; first += piece, n_piece++) {
+        const int slot = (int)(n_piece & 1);
+        if (int rc = finish(slot)) return rc;                    // (also: the slot's upload has left its buffers)
+        const uint32_t n = std::min(piece, n_windows - first);
+        uint64_t *start = reinterpret_cast<uint64_t *>(c->t_out[slot] + res_bytes);
+        uint32_t *lens = reinterpret_cast<uint32_t *>(c->t_out[slot] + res_bytes + (size_t)piece * 8);
+        uint64_t at = 0;
+        for (uint32_t w = 0; w < n; w++) {
+            start[w] = at;
+            lens[w] = win_len[first + w];
+            at += lens[w];
+        }
+        auto gather = [&](uint32_t w0, uint32_t w1) {
+            for (uint32_t w = w0; w < w1; w++) {
+                memcpy(c->t_bases[slot] + start[w], text + seq_start[first + w], win_len[first + w]);
+                memcpy(c->t_quals[slot] + start[w], text + qual_start[first + w], win_len[first + w]);
+            }
+        };
+        const unsigned T = std::min(hw, std::max(1u, n / 2048u));
+        if (T <= 1) {
+            gather(0, n);
+        } else {
+            std::vector<std::thread> pool;
+            for (unsigned t = 1; t < T; t++) pool.emplace_back(gather, (uint32_t)((uint64_t)n * t / T), (uint32_t)((uint64_t)n * (t + 1) / T));
+            gather(0, (uint32_t)((uint64_t)n / T));
+            for (auto &t : pool) t.join();
+        }
+        // the rest is bml_sample_windows on the gathered piece, without a synchronisation
+        const uint32_t k = c->p.k;
+        const size_t lds = bml::sample_lds_bytes(max_len, k);
+        if (lds > 160 * 1024) return fail(BML_ERR_UNSUPPORTED, "windows of %u bases need %zu B of LDS", max_len, lds);
+        if (lds > 48 * 1024)
+            HIP_TRY(bmhip::raise_dynamic_lds(reinterpret_cast<const void *>(bml::bml_sample_kernel), lds));
+        if (at) {
+            HIP_TRY(hipMemcpyAsync(c->s_bases.p, c->t_bases[slot], (size_t)at, hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(hipMemcpyAsync(c->s_quals.p, c->t_quals[slot], (size_t)at, hipMemcpyHostToDevice, c->stream));
+        }
+        HIP_TRY(hipMemcpyAsync(c->s_win_start.p, start, (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(c->s_win_len.p, lens, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+        hipLaunchKernelGGL(bml::bml_sample_kernel, dim3(n), dim3(64), lds, c->stream, k, p, min_base_quality, max_len, c->s_bases.p,
+                           c->s_quals.p, c->s_win_start.p, c->s_win_len.p, c->lut.p, c->s_table.p, c->s_hash.p, c->s_pos.p, c->s_has.p);
+        HIP_TRY(hipGetLastError());
+        uint8_t *o = c->t_out[slot];
+        HIP_TRY(hipMemcpyAsync(o, c->s_hash.p, (size_t)n * p * 4, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemcpyAsync(o + (size_t)piece * p * 4, c->s_pos.p, (size_t)n * p * 2, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemcpyAsync(o + (size_t)piece * p * 6, c->s_has.p, n, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipEventRecord(c->t_done[slot], c->stream));
+        fl[slot].first = first;
+        fl[slot].n = n;
+        fl[slot].busy = true;
+    }
+    if (int rc = finish(0)) return rc;
+    if (int rc = finish(1)) return rc;
+    return BML_OK;
+}
+
 int bml_load_genome(bml_ctx *c, const uint8_t *bases, uint64_t n_bases, const uint64_t *bucket_start,
                     const uint32_t *bucket_len, uint32_t n_buckets) {
     if (!c || (n_bases && !bases) || (n_buckets && (!bucket_start || !bucket_len)))
@@ -246,7 +380,7 @@ int bml_load_genome(bml_ctx *c, const uint8_t *bases, uint64_t n_bases, const ui
     HIP_TRY(hipMemset(c->genome.p + n_bases, 'A', 64));
     HIP_TRY(c->bucket_start.need(n_buckets));
     HIP_TRY(c->bucket_len.need(n_buckets));
-    if (n_bases) HIP_TRY(hipMemcpy(c->genome.p, bases, (size_t)n_bases, hipMemcpyHostToDevice));
+    if (n_bases) HIP_TRY(bmhip::upload_pageable(c->genome.p, bases, (size_t)n_bases));
     if (n_buckets) {
         HIP_TRY(hipMemcpy(c->bucket_start.p, bucket_start, (size_t)n_buckets * sizeof(uint64_t), hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(c->bucket_len.p, bucket_len, (size_t)n_buckets * sizeof(uint32_t), hipMemcpyHostToDevice));

@@ -279,7 +279,7 @@ int bmv_load_genome(bmv_ctx *c, const uint8_t *bases, uint64_t n_bases) {
     if (!c || (n_bases && !bases)) return fail(BMV_ERR_ARG, "bmv_load_genome: null argument");
     HIP_TRY(hipSetDevice(c->p.device));
     HIP_TRY(c->genome.need((size_t)n_bases + 64u));             // (slack: an empty text window at the very end is still fetched from)
-    if (n_bases) HIP_TRY(hipMemcpy(c->genome.p, bases, (size_t)n_bases, hipMemcpyHostToDevice));
+    if (n_bases) HIP_TRY(bmhip::upload_pageable(c->genome.p, bases, (size_t)n_bases));
     c->n_genome = n_bases;
     c->loaded = true;
     return BMV_OK;

@@ -39,6 +39,25 @@ public:
     virtual void sample_windows(const uint8_t *bases, const uint8_t *quals, uint64_t n_bytes, const uint64_t *win_start,
                                 const uint32_t *win_len, uint32_t n_windows, uint32_t min_base_quality,
                                 uint32_t *out_hash, uint16_t *out_pos, uint8_t *out_has) = 0;
+    // the same for windows whose bases and qualities lie apart in one buffer (the mapped FASTQ file): window w =
+    // text[seq_start[w], +win_len[w]) with qualities text[qual_start[w], +win_len[w]).  Default: gather, then sample_windows.
+    virtual void sample_text_windows(const uint8_t *text, uint64_t n_bytes, const uint64_t *seq_start, const uint64_t *qual_start,
+                                     const uint32_t *win_len, uint32_t n_windows, uint32_t min_base_quality, uint32_t *out_hash,
+                                     uint16_t *out_pos, uint8_t *out_has) {
+        (void)n_bytes;
+        std::vector<uint64_t> start(n_windows);
+        uint64_t at = 0;
+        for (uint32_t w = 0; w < n_windows; w++) {
+            start[w] = at;
+            at += win_len[w];
+        }
+        std::vector<uint8_t> bases(at + 1), quals(at + 1);
+        for (uint32_t w = 0; w < n_windows; w++) {
+            std::memcpy(bases.data() + start[w], text + seq_start[w], win_len[w]);
+            std::memcpy(quals.data() + start[w], text + qual_start[w], win_len[w]);
+        }
+        sample_windows(bases.data(), quals.data(), at, start.data(), win_len, n_windows, min_base_quality, out_hash, out_pos, out_has);
+    }
     // genome as one byte string; bucket b = [bucket_start[b], +bucket_len[b])
     virtual void load_genome(const uint8_t *bases, uint64_t n_bases, const uint64_t *bucket_start,
                              const uint32_t *bucket_len, uint32_t n_buckets) = 0;
@@ -162,9 +181,54 @@ private:
         first_window.clear(); window_start.clear(); sample_hash.clear(); sample_pos.clear();
         segment_length.clear(); window_has_samples.clear(); read_lengths.clear();
         std::vector<uint8_t> bases, quals;
-        std::vector<uint64_t> win_start;
+        std::vector<uint64_t> win_start, qual_start;
         std::vector<uint32_t> win_len;
         const size_t block_bases = 256u << 20;
+        // A regular file: nothing is copied here -- the windows are views into the mapped file (the index the mapper's pass
+        // built, or is building), and the scanner gathers them where it needs them.
+        if (std::shared_ptr<FastqFile> fq = FastqFile::open(fastq)) {
+            const uint8_t *text = reinterpret_cast<const uint8_t *>(fq->data());
+            size_t block = 0;
+            auto flush_views = [&]() {
+                const size_t n = win_start.size(), at = sample_hash.size();
+                if (n == 0) return;
+                sample_hash.resize(at + n * num_samples);
+                sample_pos.resize(at + n * num_samples);
+                const size_t has_at = window_has_samples.size();
+                window_has_samples.resize(has_at + n);
+                _s->sample_text_windows(text, fq->size(), win_start.data(), qual_start.data(), win_len.data(), static_cast<uint32_t>(n),
+                                        min_base_quality, sample_hash.data() + at, sample_pos.data() + at, window_has_samples.data() + has_at);
+                win_start.clear(); qual_start.clear(); win_len.clear();
+                block = 0;
+            };
+            for (size_t i = 0;;) {
+                const size_t n = fq->wait(i + 1);
+                if (n <= i) break;
+                for (; i < n; i++) {
+                    const FastqFile::Rec &r = fq->rec(i);
+                    const uint32_t len = r.len;
+                    first_window.push_back(static_cast<uint32_t>(window_start.size()));
+                    auto add = [&](uint32_t st) {
+                        const uint32_t end = std::min(st + read_length, len);
+                        window_start.push_back(static_cast<int>(st));
+                        segment_length.push_back(end - st);
+                        win_start.push_back(r.seq + st);
+                        qual_start.push_back(r.qual + st);
+                        win_len.push_back(end - st);
+                    };
+                    if (len > 2 * read_length)
+                        for (uint32_t st : sample_deterministically(num_segment_samples, len - read_length - 1)) add(st);
+                    else
+                        add(0);
+                    read_lengths.push_back(len);
+                    block += len;
+                    if (block >= block_bases) flush_views();
+                }
+            }
+            flush_views();
+            first_window.push_back(static_cast<uint32_t>(window_start.size()));
+            return;
+        }
         auto flush = [&]() {
             const size_t n = win_start.size(), at = sample_hash.size();
             if (n == 0) return;
@@ -177,7 +241,7 @@ private:
                                window_has_samples.data() + has_at);
             bases.clear(); quals.clear(); win_start.clear(); win_len.clear();
         };
-        for_each_fastq(fastq, [&](const FastqRecord &rec) {
+        for_each_fastq_stream(fastq, [&](const FastqRecord &rec) {
             const uint32_t len = static_cast<uint32_t>(rec.seq.size());
             first_window.push_back(static_cast<uint32_t>(window_start.size()));
             std::vector<uint32_t> starting_positions{0};
@@ -315,14 +379,25 @@ public:
             _s->load_genome(flat.get(), total, bstart_.data(), blen_.data(), static_cast<uint32_t>(buckets_.size()));
             if (_v) _v->load_genome(flat.get(), total);
         };
-        std::exception_ptr upload_error;
+        // (two threads: the upload touches the scanner's genome buffers, the sampling its window buffers and its stream)
+        std::exception_ptr upload_error, sampling_error;
+        const auto t_side = std::chrono::steady_clock::now();
+        float upload_ms = 0.f, sampling_ms = 0.f;
         std::thread uploader([&]() {
             try {
                 upload_genome();
-                prepare_read_query(sequence_file);
             } catch (...) {
                 upload_error = std::current_exception();
             }
+            upload_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_side).count();
+        });
+        std::thread sampler([&]() {
+            try {
+                prepare_read_query(sequence_file);
+            } catch (...) {
+                sampling_error = std::current_exception();
+            }
+            sampling_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_side).count();
         });
         segments_t sequence_ids_orig, sequence_ids_rev_comp;
         try {
@@ -330,11 +405,17 @@ public:
             _m->reset();
         } catch (...) {
             uploader.join();
+            sampler.join();
             throw;
         }
         auto t0 = std::chrono::steady_clock::now();
         uploader.join();
+        sampler.join();
         if (upload_error) std::rethrow_exception(upload_error);
+        if (sampling_error) std::rethrow_exception(sampling_error);
+        if (std::getenv("BM_LOG_BATCHES"))
+            std::cerr << "[bm] beside map(): genome upload done after " << upload_ms << " ms, k-mer sampling pass after " << sampling_ms
+                      << " ms; map() returned after " << std::chrono::duration<float, std::milli>(t0 - t_side).count() << " ms\n";
 
         // Candidates in the order of the reference's bucket loop (:651-693): buckets ascending; inside a
         // bucket the reads as-is in list order, then the reverse complements in REVERSE list order.

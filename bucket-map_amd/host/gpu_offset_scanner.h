@@ -80,6 +80,21 @@ public:
         });
     }
 
+    void sample_text_windows(const uint8_t *text, uint64_t n_bytes, const uint64_t *seq_start, const uint64_t *qual_start,
+                             const uint32_t *win_len, uint32_t n_windows, uint32_t min_base_quality, uint32_t *out_hash,
+                             uint16_t *out_pos, uint8_t *out_has) override {
+        // every device is handed the shared text and ITS window range: it gathers and uploads those windows only
+        const size_t D = ctx_.size(), p = num_samples_;
+        const std::vector<uint32_t> cut = cut_evenly(n_windows, D);
+        for_each_device(D, [&](size_t d) {
+            const uint32_t w0 = cut[d], n = cut[d + 1] - cut[d];
+            if (n == 0) return;
+            check(bml_sample_text_windows(ctx_[d], text, n_bytes, seq_start + w0, qual_start + w0, win_len + w0, n, min_base_quality,
+                                          out_hash + w0 * p, out_pos + w0 * p, out_has + w0),
+                  "the GPU k-mer sampling failed: ");
+        });
+    }
+
     void scan(const uint32_t *sample_hash, const uint16_t *sample_pos, const uint32_t *seg_len, uint32_t n_windows,
               const uint32_t *pair_bucket, const uint32_t *pair_window, const uint8_t *pair_rc, uint32_t n_pairs,
               int32_t *out_offset, uint32_t *out_votes) override {

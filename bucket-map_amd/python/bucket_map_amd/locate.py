@@ -29,6 +29,7 @@ SYMBOLS = {
     "bml_destroy": (None, [C.c_void_p]),
     "bml_load_genome": (C.c_int, [C.c_void_p, _u8p, C.c_uint64, _u64p, _u32p, C.c_uint32]),
     "bml_sample_windows": (C.c_int, [C.c_void_p, _u8p, _u8p, C.c_uint64, _u64p, _u32p, C.c_uint32, C.c_uint32, _u32p, _u16p, _u8p]),
+    "bml_sample_text_windows": (C.c_int, [C.c_void_p, _u8p, C.c_uint64, _u64p, _u64p, _u32p, C.c_uint32, C.c_uint32, _u32p, _u16p, _u8p]),
     "bml_locate": (C.c_int, [C.c_void_p, _u32p, _u16p, _u32p, C.c_uint32, _u32p, _u32p, _u8p, C.c_uint32, _i32p, _u32p]),
     "bml_last_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float), _u64p]),
     "bml_last_heavy_candidates": (C.c_int, [C.c_void_p, _u32p]),
@@ -83,6 +84,19 @@ class LocatorScan:
         has = np.zeros(n, np.uint8)
         _check(lib().bml_sample_windows(self._h, _p(b, _u8p), _p(q, _u8p), len(b), _p(ws, _u64p), _p(wl, _u32p), n,
                                         min_base_quality, _p(h, _u32p), _p(pos, _u16p), _p(has, _u8p)))
+        return h, pos, has
+
+    def sample_text_windows(self, text, seq_start, qual_start, win_len, min_base_quality: int):
+        """bml_sample_text_windows: the same sampling for windows whose bases and qualities lie apart in one buffer."""
+        t = np.ascontiguousarray(text, np.uint8)
+        ss, qs = np.ascontiguousarray(seq_start, np.uint64), np.ascontiguousarray(qual_start, np.uint64)
+        wl = np.ascontiguousarray(win_len, np.uint32)
+        n = len(ss)
+        h = np.zeros((n, self.p), np.uint32)
+        pos = np.zeros((n, self.p), np.uint16)
+        has = np.zeros(n, np.uint8)
+        _check(lib().bml_sample_text_windows(self._h, _p(t, _u8p), len(t), _p(ss, _u64p), _p(qs, _u64p), _p(wl, _u32p), n,
+                                             min_base_quality, _p(h, _u32p), _p(pos, _u16p), _p(has, _u8p)))
         return h, pos, has
 
     def locate(self, sample_hash, sample_pos, seg_len, pair_bucket, pair_window, pair_rc):

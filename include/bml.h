@@ -68,6 +68,13 @@ int  bml_sample_windows(bml_ctx *ctx, const uint8_t *bases, const uint8_t *quals
                         const uint64_t *win_start, const uint32_t *win_len, uint32_t n_windows,
                         uint32_t min_base_quality, uint32_t *out_hash, uint16_t *out_pos, uint8_t *out_has);
 
+/* The same for windows whose bases and qualities lie apart in one buffer (a FASTQ text, as bmf_map_text_windows_compact
+ * takes them): window w = text[seq_start[w] .. +win_len[w]) with qualities text[qual_start[w] .. +win_len[w]).  The
+ * library gathers the windows into page-locked buffers piece by piece (a few host threads), so the caller copies nothing. */
+int  bml_sample_text_windows(bml_ctx *ctx, const uint8_t *text, uint64_t n_bytes, const uint64_t *seq_start,
+                             const uint64_t *qual_start, const uint32_t *win_len, uint32_t n_windows,
+                             uint32_t min_base_quality, uint32_t *out_hash, uint16_t *out_pos, uint8_t *out_has);
+
 /* One batch of candidates.
  *   windows : sample_hash[w*p + s], sample_pos[w*p + s] (start of the k-mer in the window, u16 as
  *             query_sequences_storage keeps it), seg_len[w] = length of the window

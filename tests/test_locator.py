@@ -361,6 +361,34 @@ def test_gpu_sampling_with_exactly_one_good_kmer(p):
     assert [got[1][w].tolist() for w in range(len(ws))] == [[j] * p for j in at]
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("k,p,max_len", [(12, 10, 300), (12, 20, 300), (16, 10, 2500)])
+def test_gpu_sampling_from_a_fastq_text_equals_oracle(k, p, max_len):
+    """bml_sample_text_windows (what `bucketmap` calls with the memory-mapped FASTQ file): bases and qualities of a window
+    lie apart in one buffer and the library gathers them piece by piece -- same samples as the oracle on the windows."""
+    from bucket_map_amd import locate
+    rng = np.random.default_rng(k * 100 + p)
+    bases, quals, ws, wl = _sample_case(rng, 5000 if max_len <= 300 else 300, max_len, k)
+    want = oc.sample_windows(k, p, 25 * k, bases, quals, ws, wl)
+    # a FASTQ-like text: header, bases, "+", qualities per window
+    parts, seq_at, qual_at, at = [], [], [], 0
+    for w in range(len(ws)):
+        b, q = bases[int(ws[w]): int(ws[w]) + int(wl[w])], quals[int(ws[w]): int(ws[w]) + int(wl[w])]
+        head = np.frombuffer(f"@w{w}\n".encode(), np.uint8)
+        parts += [head, b, np.frombuffer(b"\n+\n", np.uint8), q, np.frombuffer(b"\n", np.uint8)]
+        seq_at.append(at + len(head))
+        qual_at.append(at + len(head) + len(b) + 3)
+        at += len(head) + 2 * len(b) + 4
+    text = np.concatenate(parts)
+    scan = locate.LocatorScan(k, p, 4, 6, 70000)
+    got = scan.sample_text_windows(text, seq_at, qual_at, wl, 25 * k)
+    for a, b, what in zip(want, got, ("hash", "position", "has-samples")):
+        assert np.array_equal(a, b), what
+    with pytest.raises(locate.BmlError):                       # a window past the end of the text
+        scan.sample_text_windows(text, seq_at, np.full(len(ws), len(text), np.uint64), wl, 0)
+    scan.close()
+
+
 def _golden_sampling():
     import json
     here = os.path.dirname(os.path.abspath(__file__))
