@@ -236,7 +236,7 @@ def locator_leg(inp, cli, device, counts, buckets, steps, cpu_seconds, log):
     bml_locate (include/bml.h).  Kernel times are HIP events inside the library (scan = bml_scan_kernel, replay = the light
     and heavy vote kernels); `ms_call` is the wall time of the C-ABI call with host buffers in and out.  Algorithmic bytes:
     every (bucket, chunk of candidates) reads its bucket once (bucket bases) and every k-mer occurrence is written once by
-    the scan and read once by the replay (8 B each way).  cpu_baseline: oracle/bm_locator_oracle.c::bmlo_locate, 1 thread,
+    the scan and read once by the replay (4 B each way: an occurrence is its offset in the bucket).  cpu_baseline: oracle/bm_locator_oracle.c::bmlo_locate, 1 thread,
     on the candidates of the first buckets (the analogue of the reference's per-bucket multimap build + vote)."""
     import numpy as np
     import bucket_map_amd as bma
@@ -279,7 +279,7 @@ def locator_leg(inp, cli, device, counts, buckets, steps, cpu_seconds, log):
     n_chunks = int(np.sum((run_len + chunk_max - 1) // chunk_max))
     bucket_bytes = int(np.sum(((run_len + chunk_max - 1) // chunk_max) * blen[pb[np.concatenate(([0], np.cumsum(run_len)[:-1]))]].astype(np.int64)))
     occ = int(st["occurrences"])
-    algo = bucket_bytes + 16 * occ + int(pb.size) * (p * 6 + 9 + 8)   # + samples (hash u32, pos u16) and the pair record in, (offset, votes) out
+    algo = bucket_bytes + 8 * occ + int(pb.size) * (p * 10 + 9 + 8)   # + samples (hash u32, pos u16), group ends (u32) and the pair record in, (offset, votes) out
     kern_ms = ms_scan + ms_replay
     # the read's own position: a candidate on the true (bucket, strand) must be located at the simulated offset
     true_pair = (pb == rd.truth_bucket[pw]) & (pr == rd.truth_rc[pw])
@@ -295,9 +295,9 @@ def locator_leg(inp, cli, device, counts, buckets, steps, cpu_seconds, log):
            "roofline": {"bound": "hbm", "achieved": algo / (kern_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                         "frac": algo / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "kernel": "bml_scan_kernel + bml_replay_*",
                         "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": int(algo),
-                        "bytes": {"bucket_bases": bucket_bytes, "occurrences_written_and_read": 16 * occ},
-                        "scan_only": {"achieved": (bucket_bytes + 8 * occ) / (ms_scan * 1e-3) / 1e9,
-                                      "frac": (bucket_bytes + 8 * occ) / (ms_scan * 1e-3) / 1e9 / HBM_PEAK_GBPS},
+                        "bytes": {"bucket_bases": bucket_bytes, "occurrences_written_and_read": 8 * occ},
+                        "scan_only": {"achieved": (bucket_bytes + 4 * occ) / (ms_scan * 1e-3) / 1e9,
+                                      "frac": (bucket_bytes + 4 * occ) / (ms_scan * 1e-3) / 1e9 / HBM_PEAK_GBPS},
                         "note": "the scan is a chain of dependent LDS reads per bucket k-mer (filter, table) and the vote an "
                                 "order-dependent replay: the HBM fraction says how far the path is from moving its bytes at "
                                 "stream speed, not that HBM is what it waits for (profiles/r04/locate_sq_counters_*.txt)"},

@@ -79,7 +79,8 @@ struct bml_ctx {
     uint32_t n_buckets = 0;
     std::vector<uint32_t> h_bucket_len;
     DevBuf<uint8_t> genome, lut, pair_rc;
-    DevBuf<uint64_t> bucket_start, occ_a, cand_start;
+    DevBuf<uint64_t> bucket_start, cand_start;
+    DevBuf<uint32_t> occ_a, samp_end;            // an occurrence is its offset in the bucket (4 bytes); per (candidate, sample): where its group ends
     DevBuf<uint32_t> bucket_len, sample_hash, seg_len, pair_window, out_votes;
     DevBuf<uint32_t> cand_count, heavy, n_heavy, heavy_votes, heavy_bitmaps;
     double occ_per_pair = 0;                     // k-mer occurrences per candidate the batches so far needed (sizes the next buffer)
@@ -180,7 +181,7 @@ void bml_destroy(bml_ctx *c) {
     (void)hipSetDevice(c->p.device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     c->genome.release(); c->lut.release(); c->pair_rc.release();
-    c->bucket_start.release(); c->occ_a.release(); c->cand_start.release();
+    c->bucket_start.release(); c->occ_a.release(); c->samp_end.release(); c->cand_start.release();
     c->cand_count.release(); c->heavy.release(); c->n_heavy.release(); c->heavy_votes.release();
     c->heavy_bitmaps.release();
     c->bucket_len.release(); c->sample_hash.release(); c->seg_len.release(); c->pair_window.release();
@@ -437,10 +438,11 @@ int bml_locate(bml_ctx *c, const uint32_t *sample_hash, const uint16_t *sample_p
 
     // Occurrence buffer.  A true match per sample is the common case, so the first scan runs with room for two per sample;
     // it counts every candidate's occurrences whether they fit or not.  If they did not fit, the candidates are cut into
-    // GROUPS of whole chunks whose occurrences fit a budget (BML_MAX_OCC occurrences, default 2^31 = 16 GiB of keys: reads
+    // GROUPS of whole chunks whose occurrences fit a budget (BML_MAX_OCC occurrences, default 2^31 = 8 GiB of offsets: reads
     // in repeats bring 1 000+ occurrences per candidate, 11 G for 10 M reads on the genome-like genome), and every group is
     // scanned again and replayed on its own.
     HIP_TRY(c->cand_count.need(n_pairs));
+    HIP_TRY(c->samp_end.need((size_t)n_pairs * p));
     HIP_TRY(c->cand_start.need(n_pairs));
     HIP_TRY(c->heavy.need(n_pairs));
     unsigned long long budget = 1ull << 31;
@@ -462,7 +464,8 @@ int bml_locate(bml_ctx *c, const uint32_t *sample_hash, const uint16_t *sample_p
         HIP_TRY(hipEventRecord(c->ev[0], c->stream));
         hipLaunchKernelGGL(bml::bml_scan_kernel, dim3((unsigned)(chunk_hi - chunk_lo)), dim3(bml::kScanThreads), c->scan_lds, c->stream,
                            c->lp, c->genome.p, c->bucket_start.p, c->bucket_len.p, c->chunks.p + chunk_lo, c->sample_hash.p,
-                           c->pair_window.p, c->pair_rc.p, c->occ_a.p, c->occ_count.p, cap, c->cand_start.p, c->cand_count.p, placed ? 1u : 0u);
+                           c->pair_window.p, c->pair_rc.p, c->occ_a.p, c->occ_count.p, cap, c->cand_start.p, c->cand_count.p, c->samp_end.p,
+                           placed ? 1u : 0u);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(c->ev[1], c->stream));
         unsigned long long state[2] = {0, 0};
@@ -482,7 +485,7 @@ int bml_locate(bml_ctx *c, const uint32_t *sample_hash, const uint16_t *sample_p
         const uint32_t count = pair_hi - pair_lo;
         auto light = [&](auto kernel, unsigned threads) {
             hipLaunchKernelGGL(kernel, dim3((count + threads - 1) / threads), dim3(threads), 0, c->stream, c->lp, c->occ_a.p,
-                               c->cand_start.p, c->cand_count.p, c->sample_pos.p, c->seg_len.p, c->pair_window.p, c->pair_rc.p,
+                               c->cand_start.p, c->cand_count.p, c->samp_end.p, c->sample_pos.p, c->seg_len.p, c->pair_window.p, c->pair_rc.p,
                                pair_lo, pair_hi, c->out_offset.p, c->out_votes.p, c->heavy.p, c->n_heavy.p);
         };
         if (p <= 10) light(bml::bml_replay_light_kernel<16, 256>, 256);
@@ -521,7 +524,7 @@ int bml_locate(bml_ctx *c, const uint32_t *sample_hash, const uint16_t *sample_p
             const bml::HeavyScratch hs{c->heavy_votes.p, c->heavy_bitmaps.p, vote_stride};
             HIP_TRY(hipEventRecord(c->ev[5], c->stream));        // (the allocations above are not replay time)
             hipLaunchKernelGGL(bml::bml_replay_heavy_kernel, dim3(grid), dim3(bml::kThreads), lds, c->stream, c->lp, c->occ_a.p,
-                               c->cand_start.p, c->cand_count.p, c->sample_pos.p, c->seg_len.p, c->pair_window.p, c->pair_rc.p, c->heavy.p,
+                               c->cand_start.p, c->cand_count.p, c->samp_end.p, c->sample_pos.p, c->seg_len.p, c->pair_window.p, c->pair_rc.p, c->heavy.p,
                                c->n_heavy.p, range, max_seg, in_lds ? 1u : 0u, hs, c->out_offset.p, c->out_votes.p);
             HIP_TRY(hipGetLastError());
         }

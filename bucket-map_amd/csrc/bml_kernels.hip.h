@@ -101,8 +101,9 @@ __global__ __launch_bounds__(kScanThreads) void bml_scan_kernel(
     LocParams P, const uint8_t *__restrict__ genome, const uint64_t *__restrict__ bucket_start,
     const uint32_t *__restrict__ bucket_len, const Chunk *__restrict__ chunks,
     const uint32_t *__restrict__ sample_hash, const uint32_t *__restrict__ pair_window,
-    const uint8_t *__restrict__ pair_rc, uint64_t *__restrict__ occ_keys, unsigned long long *__restrict__ occ_count,
-    unsigned long long occ_cap, uint64_t *__restrict__ cand_start, uint32_t *__restrict__ cand_count, uint32_t placed) {
+    const uint8_t *__restrict__ pair_rc, uint32_t *__restrict__ occ, unsigned long long *__restrict__ occ_count,
+    unsigned long long occ_cap, uint64_t *__restrict__ cand_start, uint32_t *__restrict__ cand_count,
+    uint32_t *__restrict__ samp_end, uint32_t placed) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     unsigned long long &gbase = *reinterpret_cast<unsigned long long *>(smem);
     uint32_t &total = *reinterpret_cast<uint32_t *>(smem + 8);
@@ -254,14 +255,14 @@ __global__ __launch_bounds__(kScanThreads) void bml_scan_kernel(
             cand_start[ch.pair_begin + c] = base + first;
         }
     }
+    // where every sample's occurrences end inside its candidate's segment (the replay kernels' group boundaries)
+    for (uint32_t t = tid; t < n_t; t += kScanThreads) samp_end[(size_t)ch.pair_begin * P.p + t] = tstart[t + 1u] - tstart[(t / P.p) * P.p];
     if (total == 0u || base + total > occ_cap) return;                     // (too small: the host grows the buffer and scans again)
 
     // sweep 2: the rank of every asked-for k-mer among its equals, and one store into its owner's list
-    const uint64_t gid0 = (uint64_t)ch.pair_begin * P.p;                   // target t's id in the keys: gid0 + t
     auto place = [&](uint32_t slot, uint32_t j) {
         const uint32_t rank = atomicSub(&tcnt[slot], 1u) - 1u;
-        const uint32_t owner = thead[slot];
-        occ_keys[base + tstart[owner] + rank] = ((gid0 + owner) << 32) | (uint32_t)(0x7FFFFFFFu - j);   // (target, offset descending)
+        occ[base + tstart[thead[slot]] + rank] = j;                         // an occurrence is its offset in the bucket: 4 bytes
     };
     const uint32_t staged = n_stage;
     if (staged <= kStage) {                                                // (never when the special slot was met)
@@ -292,12 +293,9 @@ __global__ __launch_bounds__(kScanThreads) void bml_scan_kernel(
     __syncthreads();
     auto copy_list = [&](uint32_t t, uint32_t first, uint32_t step) {
         const uint32_t owner = thead[tslot[t]], len = tstart[t + 1u] - tstart[t];
-        const uint64_t *src = occ_keys + base + tstart[owner];
-        uint64_t *dst = occ_keys + base + tstart[t];
-        const uint64_t hi = (gid0 + t) << 32;
-        for (uint32_t e = first; e < len; e += step) {
-            dst[e] = hi | (uint32_t)src[e];
-        }
+        const uint32_t *src = occ + base + tstart[owner];
+        uint32_t *dst = occ + base + tstart[t];
+        for (uint32_t e = first; e < len; e += step) dst[e] = src[e];
     };
     const uint32_t ns = n_short, nl = n_long;
     for (uint32_t i = 0; i < nl; i++) copy_list(long_list[i], tid, kScanThreads);
@@ -315,10 +313,10 @@ __global__ __launch_bounds__(kScanThreads) void bml_scan_kernel(
 // at the same entry hit 64 different banks.  9 bytes x 16 entries x 256 threads = 36 KB per workgroup.
 template <int kLightMax, int kLightThreads>
 __global__ __launch_bounds__(kLightThreads) void bml_replay_light_kernel(
-    LocParams P, const uint64_t *__restrict__ keys, const uint64_t *__restrict__ cand_start, const uint32_t *__restrict__ cand_count,
-    const uint16_t *__restrict__ sample_pos, const uint32_t *__restrict__ seg_len, const uint32_t *__restrict__ pair_window,
-    const uint8_t *__restrict__ pair_rc, uint32_t pair_lo, uint32_t pair_hi, int32_t *__restrict__ out_offset,
-    uint32_t *__restrict__ out_votes, uint32_t *__restrict__ heavy, uint32_t *__restrict__ n_heavy) {
+    LocParams P, const uint32_t *__restrict__ occ, const uint64_t *__restrict__ cand_start, const uint32_t *__restrict__ cand_count,
+    const uint32_t *__restrict__ samp_end, const uint16_t *__restrict__ sample_pos, const uint32_t *__restrict__ seg_len,
+    const uint32_t *__restrict__ pair_window, const uint8_t *__restrict__ pair_rc, uint32_t pair_lo, uint32_t pair_hi,
+    int32_t *__restrict__ out_offset, uint32_t *__restrict__ out_votes, uint32_t *__restrict__ heavy, uint32_t *__restrict__ n_heavy) {
     __shared__ uint32_t s_key[kLightMax][kLightThreads];
     __shared__ int32_t s_pk[kLightMax][kLightThreads];
     __shared__ uint8_t s_pv[kLightMax][kLightThreads];
@@ -330,11 +328,13 @@ __global__ __launch_bounds__(kLightThreads) void bml_replay_light_kernel(
         atomicMax(n_heavy + 1, n);
         return;
     }
-    // (sample in processing order) ascending, offset descending: insertion sort while loading
-    const uint64_t *mine = keys + cand_start[pair];
+    // (sample in processing order) ascending, offset descending: the segment arrives grouped by sample; insertion sort while loading
+    const uint32_t *mine = occ + cand_start[pair];
+    const uint32_t *ends = samp_end + (size_t)pair * P.p;
+    uint32_t sample = 0, sample_stop = ends[0];
     for (uint32_t a = 0; a < n; a++) {
-        const uint64_t key = mine[a];
-        const uint32_t v = (((uint32_t)(key >> 32) - pair * P.p) << 20) | (0xFFFFFu - (0x7FFFFFFFu - (uint32_t)key));
+        while (a >= sample_stop) sample_stop = ends[++sample];      // (a < n = ends[p - 1]: stays in range)
+        const uint32_t v = (sample << 20) | (0xFFFFFu - mine[a]);
         uint32_t b = a;
         while (b > 0 && s_key[b - 1][tid] > v) {
             s_key[b][tid] = s_key[b - 1][tid];
@@ -429,8 +429,9 @@ struct HeavyScratch {
 };
 
 __global__ __launch_bounds__(kThreads) void bml_replay_heavy_kernel(
-    LocParams P, const uint64_t *__restrict__ keys, const uint64_t *__restrict__ cand_start,
-    const uint32_t *__restrict__ cand_count, const uint16_t *__restrict__ sample_pos, const uint32_t *__restrict__ seg_len,
+    LocParams P, const uint32_t *__restrict__ occ, const uint64_t *__restrict__ cand_start,
+    const uint32_t *__restrict__ cand_count, const uint32_t *__restrict__ samp_end, const uint16_t *__restrict__ sample_pos,
+    const uint32_t *__restrict__ seg_len,
     const uint32_t *__restrict__ pair_window,
     const uint8_t *__restrict__ pair_rc, const uint32_t *__restrict__ heavy, const uint32_t *__restrict__ n_heavy,
     uint32_t range, uint32_t bias, uint32_t lds_bitmaps, HeavyScratch S, int32_t *__restrict__ out_offset,
@@ -485,24 +486,17 @@ __global__ __launch_bounds__(kThreads) void bml_replay_heavy_kernel(
         const uint32_t h = s_next;
         if (h >= total) break;
         const uint32_t pair = heavy[h];
-        const uint64_t first = cand_start[pair], n = cand_count[pair];
+        const uint64_t first = cand_start[pair];
         const uint32_t w = pair_window[pair];
         const bool rc = pair_rc[pair] != 0;
         const uint32_t length = seg_len[w];
-        // 0. the scan wrote the candidate's occurrences grouped by sample, in processing order: s_hist[i] = the first of
-        //    sample i, found by a binary search on the keys' target id (p + 1 threads, ~log2(n) loads each)
-        const uint64_t *mine = keys + first;
-        if (tid == 0) s_np = 0;
-        if (tid <= P.p) {
-            const uint64_t want = ((uint64_t)pair * P.p + tid) << 32;     // first key of sample `tid` or later
-            uint64_t lo = 0, hi = n;
-            while (lo < hi) {
-                const uint64_t mid = (lo + hi) >> 1;
-                if (mine[mid] < want) lo = mid + 1;
-                else hi = mid;
-            }
-            s_hist[tid] = (uint32_t)lo;
+        // 0. the scan wrote the candidate's occurrences grouped by sample, in processing order, and where every group ends
+        const uint32_t *mine = occ + first;
+        if (tid == 0) {
+            s_np = 0;
+            s_hist[0] = 0;
         }
+        if (tid < P.p) s_hist[tid + 1] = samp_end[(size_t)pair * P.p + tid];
         __syncthreads();
         for (uint32_t i = 0; i < P.p; i++) {
             uint32_t idx = sample_pos[(size_t)w * P.p + (rc ? P.p - 1u - i : i)];
@@ -514,12 +508,12 @@ __global__ __launch_bounds__(kThreads) void bml_replay_heavy_kernel(
             // every step below walks the sample's occurrences again (global memory: four loads in flight, one latency)
             auto for_each_pos = [&](auto fn) {
                 for (uint32_t o = o0 + tid; o < o1; o += 4u * kThreads) {
-                    uint64_t key[4];
+                    uint32_t at[4];
 #pragma unroll
-                    for (int u = 0; u < 4; u++) key[u] = o + u * kThreads < o1 ? mine[o + u * kThreads] : 0ull;
+                    for (int u = 0; u < 4; u++) at[u] = o + u * kThreads < o1 ? mine[o + u * kThreads] : 0u;
 #pragma unroll
                     for (int u = 0; u < 4; u++)
-                        if (o + u * kThreads < o1) fn(start_of(0x7FFFFFFFu - (uint32_t)key[u]), o + u * kThreads - o0);
+                        if (o + u * kThreads < o1) fn(start_of(at[u]), o + u * kThreads - o0);
                 }
             };
             const uint32_t np = s_np;                                // proposals before this sample (uniform)
