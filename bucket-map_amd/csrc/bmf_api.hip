@@ -1326,20 +1326,38 @@ static int tune_pruned(bmf_ctx *c, bmf_batch *b) {
         return fail(BMF_ERR_HIP, "tune_pruned: cannot create timing events");
     }
     const auto wall0 = std::chrono::steady_clock::now();
-    // the queue buffers at their largest, so that no timed run reallocates
+    // EVERY queue buffer at its largest, so that no timed run allocates inside its window ...
     int rc = BMF_OK;
-    if (b->q_live_mask.need(2 * (size_t)b->n_windows * bmf::kMaxLive) != hipSuccess) rc = fail(BMF_ERR_HIP, "tune_pruned: out of device memory");
+    const size_t n_it = 2 * (size_t)b->n_windows;
+    if (b->q_counters.need(4) != hipSuccess || b->q_slow.need(n_it) != hipSuccess || b->q_left.need(n_it) != hipSuccess ||
+        b->q_live_n.need(n_it) != hipSuccess || b->q_live_chunks.need(n_it * bmf::kMaxLive) != hipSuccess ||
+        b->q_live_mask.need(n_it * bmf::kMaxLive) != hipSuccess)
+        rc = fail(BMF_ERR_HIP, "tune_pruned: out of device memory");
+    // ... and every form timed on the lists it will meet in production: the order kernel re-orders the row-id lists IN
+    // PLACE, so a form that runs without it must not be timed on lists an earlier candidate left sorted.  A copy of the
+    // prefix's lists (as the sample kernel wrote them) is put back before such a run.
+    const size_t list_bytes = 2 * (size_t)n_win * c->dp.list_len * sizeof(uint32_t);
+    uint32_t *saved = nullptr;
+    if (rc == BMF_OK && (hipMalloc(reinterpret_cast<void **>(&saved), list_bytes) != hipSuccess ||
+                         hipMemcpyAsync(saved, b->lists.p, list_bytes, hipMemcpyDeviceToDevice, c->stream) != hipSuccess))
+        rc = fail(BMF_ERR_HIP, "tune_pruned: out of device memory");
+    bool lists_sorted = false;
     std::vector<float> ms(cands.size(), 1e30f);
     auto time_one = [&](size_t i) {
         rc = apply_choice(c, cands[i]);
         if (rc != BMF_OK) return;
         if (cands[i].kind == 2 && (!c->dp.pass1_rows || (cands[i].fold > 1 && !c->pass1_fold))) return;   // no such kernel
+        if (lists_sorted && !(c->sort_rows && c->dp.pass1_rows)) {
+            (void)hipMemcpyAsync(b->lists.p, saved, list_bytes, hipMemcpyDeviceToDevice, c->stream);
+            lists_sorted = false;
+        }
         c->guard_pending = true;                                   // (no guard samples from the tuning runs)
         (void)hipEventRecord(e0, c->stream);
         rc = launch_vote_stage(c, b, n_win);
         (void)hipEventRecord(e1, c->stream);
         if (hipEventSynchronize(e1) != hipSuccess || hipGetLastError() != hipSuccess) rc = fail(BMF_ERR_HIP, "tuning run failed");
         c->guard_pending = false;
+        if (c->sort_rows && c->dp.pass1_rows) lists_sorted = true;
         float t = 0.f;
         (void)hipEventElapsedTime(&t, e0, e1);
         ms[i] = std::min(ms[i], t);
@@ -1352,6 +1370,11 @@ static int tune_pruned(bmf_ctx *c, bmf_batch *b) {
         for (int rep = 0; rep < 2 && rc == BMF_OK; rep++) time_one(order[k]);
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
+    if (saved) {
+        if (lists_sorted) (void)hipMemcpyAsync(b->lists.p, saved, list_bytes, hipMemcpyDeviceToDevice, c->stream);   // as the sample kernel left them
+        (void)hipStreamSynchronize(c->stream);
+        (void)hipFree(saved);
+    }
     if (rc != BMF_OK) return rc;
     size_t best = 0;
     for (size_t i = 1; i < cands.size(); i++)
