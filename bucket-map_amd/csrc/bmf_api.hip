@@ -1894,6 +1894,34 @@ int bmf_batch_pass2_counts(bmf_ctx *c, bmf_batch *b, uint32_t *recounted, uint32
     return BMF_OK;
 }
 
+int bmf_batch_live_histogram(bmf_ctx *c, bmf_batch *b, uint64_t *stored, uint64_t *lowest) {
+    if (!c || !b || !stored || !lowest) return fail(BMF_ERR_ARG, "bmf_batch_live_histogram: null argument");
+    for (int i = 0; i < 34; i++) stored[i] = lowest[i] = 0;
+    HIP_TRY(hipSetDevice(c->p.device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (!c->dp.pass1_rows || !b->q_live_n.p) return BMF_OK;
+    const size_t n_items = 2 * (size_t)b->n_windows, ml = bmf::kMaxLive;
+    std::vector<uint32_t> live_n(n_items);
+    std::vector<uint16_t> chunks(n_items * ml);
+    HIP_TRY(hipMemcpy(live_n.data(), b->q_live_n.p, n_items * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(chunks.data(), b->q_live_chunks.p, n_items * ml * sizeof(uint16_t), hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < n_items; i++) {
+        const uint32_t t = live_n[i];
+        if (t >= bmf::kSlowBound) {                                // went to the slow kernel (from pass 1 or from the recount)
+            stored[33]++;
+            lowest[33]++;
+            continue;
+        }
+        // (the finish kernel marks the single-chunk items it finished with 0: they count as "0 stored" here)
+        const uint32_t n = t & 0xFFu, L = (t >> 8) & 0xFFu;
+        stored[std::min<uint32_t>(n, 32)]++;
+        uint32_t at_l = 0;
+        for (uint32_t k = 0; k < n && k < c->dp.max_live; k++) at_l += (uint32_t)(chunks[i * c->dp.max_live + k] >> bmf::kChunkIdBits) == L;
+        lowest[std::min<uint32_t>(at_l, 32)]++;
+    }
+    return BMF_OK;
+}
+
 int bmf_batch_recount_loads(bmf_ctx *c, bmf_batch *b, uint64_t *loads) {
     if (!c || !b || !loads) return fail(BMF_ERR_ARG, "bmf_batch_recount_loads: null argument");
     uint32_t v[4] = {0, 0, 0, 0};

@@ -80,6 +80,7 @@ SYMBOLS = {
     "bmf_pass1_fold": (C.c_int, [C.c_void_p, _u32p, _u32p]),
     "bmf_batch_pass2_counts": (C.c_int, [C.c_void_p, C.c_void_p, _u32p, _u32p]),
     "bmf_batch_recount_loads": (C.c_int, [C.c_void_p, C.c_void_p, _u64p]),
+    "bmf_batch_live_histogram": (C.c_int, [C.c_void_p, C.c_void_p, _u64p, _u64p]),
 }
 
 _lib = None
@@ -239,6 +240,12 @@ class Batch:
         a, b = C.c_uint32(), C.c_uint32()
         _check(lib().bmf_batch_pass2_counts(self._flt._h, self._h, C.byref(a), C.byref(b)))
         return int(a.value), int(b.value)
+
+    def live_histogram(self):
+        """(stored, lowest): items by stored chunks after pass 1 / by chunks at their lowest level; [33] = slow items."""
+        a, b = np.zeros(34, np.uint64), np.zeros(34, np.uint64)
+        _check(lib().bmf_batch_live_histogram(self._flt._h, self._h, _ptr(a, _u64p), _ptr(b, _u64p)))
+        return a, b
 
     def recount_loads(self) -> int:
         """16-byte column loads (one 64-byte sector each) of the recount kernel in the last run; two-pass pruning only."""

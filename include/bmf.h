@@ -197,6 +197,9 @@ int  bmf_batch_pass2_counts(bmf_ctx *ctx, bmf_batch *batch, uint32_t *recounted,
 /* Same run: 16-byte column loads the recount kernel issued (each one its own 64-byte sector of a random row) --
  * the unit its HBM traffic is priced in.  Synchronises. */
 int  bmf_batch_recount_loads(bmf_ctx *ctx, bmf_batch *batch, uint64_t *loads);
+/* Same flag, statistics of the last two-pass run: stored[n] = items that left pass 1 with n stored chunks (n = 0..32;
+ * [33] = items that went to the slow kernel), lowest[n] = items with n chunks at their lowest level.  34 entries each. */
+int  bmf_batch_live_histogram(bmf_ctx *ctx, bmf_batch *batch, uint64_t *stored, uint64_t *lowest);
 
 #ifdef __cplusplus
 }
