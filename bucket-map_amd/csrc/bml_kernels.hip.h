@@ -181,29 +181,39 @@ __global__ __launch_bounds__(kScanThreads) void bml_scan_kernel(
     // that somebody asked for
     const uint32_t nk = nb >= P.k ? nb - P.k + 1u : 0u;
     const uint32_t kmask = P.k >= 16 ? 0xFFFFFFFFu : ((1u << (2u * P.k)) - 1u);
+    // A thread takes the 16 k-mers that START in one word of the 2-bit stream: two LDS reads (its word and the next -- the
+    // lanes of a wave read consecutive words) and one 64-bit shift per k-mer, instead of two reads and the address arithmetic
+    // per k-mer (the scan on bases without repeats is bound by its VALU instruction count: profiles/r04/locate_sq_counters_*).
+    const uint32_t top = 64u - 2u * P.k;                          // a k-mer that starts at the word's first base: shift by `top`
+    const uint32_t n_groups = (shift + nk + 15u) >> 4;
     auto sweep = [&](auto hit) {
-        for (uint32_t j = tid; j < nk; j += kScanThreads) {
-            const uint32_t at = shift + j;
-            const uint64_t two = ((uint64_t)packed[at >> 4] << 32) | packed[(at >> 4) + 1];
-            const uint32_t h = (uint32_t)(two >> (64u - 2u * (at & 15u) - 2u * P.k)) & kmask;
-            const uint32_t fb = filter_bit(h);
-            if (!((filter[fb >> 5] >> (fb & 31u)) & 1u)) continue;          // nobody asked for this k-mer
-            uint32_t slot;
-            if (h == kEmpty) {
-                slot = tkey[kSpecialSlot] != kEmpty ? kSpecialSlot : kNone;
-            } else {
-                slot = slot_of(h);
-                for (;;) {
-                    const uint32_t key = tkey[slot];
-                    if (key == h) break;
-                    if (key == kEmpty) {
-                        slot = kNone;
-                        break;
+        for (uint32_t g = tid; g < n_groups; g += kScanThreads) {
+            const uint64_t two = ((uint64_t)packed[g] << 32) | packed[g + 1u];
+            const uint32_t j0 = 16u * g - shift;                  // bucket offset of the word's first base (wraps below 0: caught by j < nk)
+#pragma unroll
+            for (uint32_t o = 0; o < 16u; o++) {
+                const uint32_t j = j0 + o;
+                if (j >= nk) continue;                            // before the bucket's first base, or no whole k-mer left
+                const uint32_t h = (uint32_t)(two >> (top - 2u * o)) & kmask;
+                const uint32_t fb = filter_bit(h);
+                if (!((filter[fb >> 5] >> (fb & 31u)) & 1u)) continue;      // nobody asked for this k-mer
+                uint32_t slot;
+                if (h == kEmpty) {
+                    slot = tkey[kSpecialSlot] != kEmpty ? kSpecialSlot : kNone;
+                } else {
+                    slot = slot_of(h);
+                    for (;;) {
+                        const uint32_t key = tkey[slot];
+                        if (key == h) break;
+                        if (key == kEmpty) {
+                            slot = kNone;
+                            break;
+                        }
+                        slot = (slot + 1u) & (kTableSlots - 1u);
                     }
-                    slot = (slot + 1u) & (kTableSlots - 1u);
                 }
+                if (slot != kNone) hit(slot, j);
             }
-            if (slot != kNone) hit(slot, j);
         }
     };
     sweep([&](uint32_t slot, uint32_t j) {
