@@ -19,14 +19,22 @@ reference ANDs, both orientations) x ceil(NB/8)   / mean kernel ti
 the kernel's own stream.  `cpu_baseline` = the CPU oracle (a port: the reference cannot be built
 here) timed on one host core over a bounded sample of the same reads.
 
-Beside the headline, the default N = 1 run reports two more legs on the same card (never as `value`):
+Beside the headline, the default N = 1 run reports more legs on the same card (never as `value`; each is guarded: a leg that
+fails is recorded under its key and costs nothing else):
+  `locator`               north_star's second replaced subsystem, `bucket_map/locator`'s candidate scan: bml_locate over EVERY
+                          candidate the filter produced for the batch -- scan and vote-replay kernel times (HIP events inside the
+                          library), occurrences, algorithmic bytes and the fraction of the HBM peak they amount to, the scan's VALU
+                          wave-instructions against the issue peak (live rocprofv3 child), the CPU oracle on the candidates of the
+                          first buckets beside it (1 thread) and GPU == oracle on that sample.  The `skewed` leg carries its own;
   `skewed`                the same geometry on bm_synth.h's genome-LIKE genome (skewed q-gram spectrum, repeat families,
                           satellites, segmental duplications): what the data-dependent parts of the path do on real data --
                           rows that fail the distinguishability threshold, reads without a candidate, and the
                           exact-pruning kernels, whose form the library measures on the first batch;
   `roofline_large_index`  the vote kernel on a 4.6 GB index (2.29 Gbp at bucket_len 16 384, NB = 140 471), of which the
                           256 MiB Infinity Cache can hold 6 %: the un-flattered HBM fraction (the 872 MB headline index
-                          is 31 % cache-resident).
+                          is 31 % cache-resident);
+  `verifier`              the alignment verifier (include/bmv.h) on two short-read shapes and the long-read shape, each with a
+                          live SQ_INSTS_VALU roofline against the VALU issue peak.
 """
 import argparse
 import json
@@ -230,7 +238,7 @@ def candidate_pairs(counts, buckets):
 LOCATOR_SAMPLES, LOCATOR_MISMATCH_RATE, LOCATOR_INDEL_RATE = 10, 0.4, 0.02      # -p, -e, -n defaults (main.cpp:30-37)
 
 
-def locator_leg(inp, cli, device, counts, buckets, steps, cpu_seconds, log):
+def locator_leg(inp, cli, device, counts, buckets, steps, cpu_seconds, log, pmc=False):
     """north_star's second replaced subsystem, `bucket_map/locator`'s candidate scan: `_create_kmer_index` +
     `_find_offset` (bucket_locator.h:162-177,209-290) for EVERY candidate the filter produced for this batch, through
     bml_locate (include/bml.h).  Kernel times are HIP events inside the library (scan = bml_scan_kernel, replay = the light
@@ -324,6 +332,21 @@ def locator_leg(inp, cli, device, counts, buckets, steps, cpu_seconds, log):
         leg["checks"]["gpu_equals_oracle_on_sample"] = bool(np.array_equal(o_ref, off[:n1]) and np.array_equal(v_ref, votes[:n1]))
         leg["checks"]["parity_sample_candidates"] = n1
     scan.close()
+    # The scan's own bound on bases without repeats is its instruction count: a child under `rocprofv3 --pmc SQ_INSTS_VALU`
+    # (uniform headline leg only; tools/bench_locate.py repeats this leg on its own) counts the scan kernel's VALU
+    # wave-instructions, priced against the issue peak like the verifier's.
+    if pmc and inp.profile == "uniform" and inp.workload == "egu":
+        valu = live_pmc_counter([sys.executable, os.path.join(ROOT, "tools", "bench_locate.py"), "--genome-profile", "uniform", "--calls", "2",
+                                 "--reads", str(rd.n)], "SQ_INSTS_VALU", "bml_scan_kernel", log)
+        if valu:
+            per = sorted(valu["values"])[len(valu["values"]) // 2]           # (the first call's scan may run twice: the median dispatch)
+            ach = per / (ms_scan * 1e-3) / 1e9
+            leg["roofline"]["scan_valu_issue"] = {
+                "bound": "valu_issue", "achieved": ach, "peak": VALU_ISSUE_PEAK_GINST, "unit": "G wave-instructions/s",
+                "frac": ach / VALU_ISSUE_PEAK_GINST, "valu_wave_instructions_per_launch": per,
+                "valu_wave_instructions_per_bucket_base": per / max(1, bucket_bytes),
+                "source": f"live: rocprofv3 --pmc SQ_INSTS_VALU child of tools/bench_locate.py (bml_scan_kernel, median of "
+                          f"{valu['dispatches']} dispatches); kernel time from the un-profiled run"}
     leg["seconds"] = time.perf_counter() - t_leg
     log(f"locator leg ({inp.profile}): {pb.size} candidates, {occ} occurrences, scan {ms_scan:.2f} ms + replay {ms_replay:.2f} ms "
         f"(call {leg['ms_call']:.1f} ms), {leg['roofline']['frac']:.3f} of the HBM peak, {leg['seconds']:.0f} s")
@@ -475,8 +498,8 @@ def verifier_leg(log, pmc=True):
 
 
 def live_pmc_counter(cmd, counter, kernel_substr, log):
-    """Runs `cmd` under `rocprofv3 --pmc <counter>` (a pass of its own: no tracing) and returns {"sum", "dispatches"} of the
-    counter over the kernels whose name contains `kernel_substr`; None when the profiler is not usable here."""
+    """Runs `cmd` under `rocprofv3 --pmc <counter>` (a pass of its own: no tracing) and returns {"sum", "dispatches", "values"}
+    of the counter over the kernels whose name contains `kernel_substr`; None when the profiler is not usable here."""
     import csv
     import glob
     import shutil
@@ -497,7 +520,7 @@ def live_pmc_counter(cmd, counter, kernel_substr, log):
             return None
         vals = [float(row["Counter_Value"]) for row in csv.DictReader(open(max(files, key=os.path.getmtime)))
                 if row["Counter_Name"] == counter and kernel_substr in row["Kernel_Name"]]
-        return {"sum": sum(vals), "dispatches": len(vals)} if vals else None
+        return {"sum": sum(vals), "dispatches": len(vals), "values": vals} if vals else None
     except (OSError, ValueError, KeyError, subprocess.SubprocessError) as e:
         log(f"pmc child ({counter}) failed: {e}")
         return None
@@ -864,7 +887,8 @@ def main():
     flt.close()
     if rank == 0 and world == 1 and not args.no_locator_leg and not args.no_extra_legs:
         try:
-            result["locator"] = locator_leg(inp, cli, device, counts, buckets, min(args.steps, 3), args.locator_cpu_seconds, log)
+            result["locator"] = locator_leg(inp, cli, device, counts, buckets, min(args.steps, 3), args.locator_cpu_seconds, log,
+                                            pmc=not args.no_pmc and not args.reads and not args.total_bp and not args.bucket_len)
         except Exception as e:                                 # an optional leg must not cost the headline record
             result["locator"] = {"error": f"{type(e).__name__}: {e}"[:400]}
     del inp, reads, genome, index
