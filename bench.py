@@ -331,6 +331,9 @@ def locator_leg(inp, cli, device, counts, buckets, steps, cpu_seconds, log, pmc=
                                          f"{cpu_s:.1f} s, {cpu_s / nb_want * 1e3:.2f} ms per bucket"}
         leg["checks"]["gpu_equals_oracle_on_sample"] = bool(np.array_equal(o_ref, off[:n1]) and np.array_equal(v_ref, votes[:n1]))
         leg["checks"]["parity_sample_candidates"] = n1
+    hc, ho = scan.count_histogram(int(pb.size))
+    leg["occurrences_per_candidate"] = {"bins": "[2^(b-1), 2^b), bin 0 = none", "candidates": [int(x) for x in hc[:24]],
+                                        "occurrences": [int(x) for x in ho[:24]]}
     scan.close()
     # The scan's own bound on bases without repeats is its instruction count: a child under `rocprofv3 --pmc SQ_INSTS_VALU`
     # (uniform headline leg only; tools/bench_locate.py repeats this leg on its own) counts the scan kernel's VALU

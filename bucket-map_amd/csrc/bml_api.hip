@@ -609,6 +609,21 @@ int bml_last_stats(bml_ctx *c, float *ms_scan, float *ms_host, float *ms_replay,
     return BML_OK;
 }
 
+int bml_last_count_histogram(bml_ctx *c, uint32_t n_pairs, uint64_t *candidates, uint64_t *occurrences) {
+    if (!c || !candidates || !occurrences) return fail(BML_ERR_ARG, "bml_last_count_histogram: null argument");
+    for (int i = 0; i < 33; i++) candidates[i] = occurrences[i] = 0;
+    if (n_pairs == 0 || n_pairs > c->cand_count.cap) return BML_OK;
+    HIP_TRY(hipSetDevice(c->p.device));
+    std::vector<uint32_t> counts(n_pairs);
+    HIP_TRY(hipMemcpy(counts.data(), c->cand_count.p, (size_t)n_pairs * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    for (uint32_t v : counts) {
+        const int b = v ? 32 - __builtin_clz(v) : 0;              // 0, then [2^(b-1), 2^b)
+        candidates[b]++;
+        occurrences[b] += v;
+    }
+    return BML_OK;
+}
+
 int bml_last_heavy_candidates(bml_ctx *c, uint32_t *n_heavy) {
     if (!c || !n_heavy) return fail(BML_ERR_ARG, "bml_last_heavy_candidates: null argument");
     *n_heavy = c->last_heavy;

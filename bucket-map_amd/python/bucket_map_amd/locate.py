@@ -33,6 +33,7 @@ SYMBOLS = {
     "bml_locate": (C.c_int, [C.c_void_p, _u32p, _u16p, _u32p, C.c_uint32, _u32p, _u32p, _u8p, C.c_uint32, _i32p, _u32p]),
     "bml_last_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float), _u64p]),
     "bml_last_heavy_candidates": (C.c_int, [C.c_void_p, _u32p]),
+    "bml_last_count_histogram": (C.c_int, [C.c_void_p, C.c_uint32, _u64p, _u64p]),
 }
 _ready = False
 
@@ -119,6 +120,12 @@ class LocatorScan:
         h = C.c_uint32()
         _check(lib().bml_last_heavy_candidates(self._h, C.byref(h)))
         return {"ms_scan": a.value, "ms_host": b.value, "ms_replay": c.value, "occurrences": n.value, "heavy_candidates": h.value}
+
+    def count_histogram(self, n_pairs: int):
+        """(candidates, occurrences) of the last locate by occurrence count: bin b = [2^(b-1), 2^b), bin 0 = none."""
+        a, b = np.zeros(33, np.uint64), np.zeros(33, np.uint64)
+        _check(lib().bml_last_count_histogram(self._h, n_pairs, _p(a, _u64p), _p(b, _u64p)))
+        return a, b
 
     def close(self) -> None:
         if self._h:

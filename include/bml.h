@@ -95,6 +95,10 @@ int  bml_last_stats(bml_ctx *ctx, float *ms_scan, float *ms_host, float *ms_repl
  * the workgroup-per-candidate kernel. */
 int  bml_last_heavy_candidates(bml_ctx *ctx, uint32_t *n_heavy);
 
+/* Statistics of the last bml_locate (n_pairs = its candidate count): candidates[b] = candidates whose occurrence count lies in
+ * [2^(b-1), 2^b) (b = 0: none), occurrences[b] = the occurrences they hold.  33 entries each. */
+int  bml_last_count_histogram(bml_ctx *ctx, uint32_t n_pairs, uint64_t *candidates, uint64_t *occurrences);
+
 #ifdef __cplusplus
 }
 #endif
