@@ -34,9 +34,15 @@
 
 #include "bm_dna4.hip.h"
 
+// threads of a heavy-replay workgroup (one candidate each).  Measured on the genome-like 1 M-read batch (builds with
+// -DBML_HEAVY_THREADS=n): 64: 25.4 ms, 128: 18.8, 256: 15.0, 512: 21.1, 1024: 48.1 -- LDS holds six candidates a CU whatever
+// the size, fewer threads leave the CU short of waves, more make every barrier dearer.
+#ifndef BML_HEAVY_THREADS
+#define BML_HEAVY_THREADS 256
+#endif
 namespace bml {
 
-constexpr int kThreads = 256;        // replay kernel
+constexpr int kThreads = BML_HEAVY_THREADS;        // replay kernel
 constexpr int kScanThreads = 1024;   // scan kernel: its loops are chains of dependent LDS reads, and the 66 KB of
                                      // LDS per workgroup allow two workgroups per CU -- 16 waves each hide the latency
                                      // that 4 waves each did not (6.96 -> 2.70 ms per 1 M candidates)
