@@ -396,6 +396,38 @@ def test_fasta_reader_edge_cases(tmp_path):
 
 
 @pytest.mark.timeout(180)
+def test_fastq_index_is_shared_between_passes_and_follows_the_file(tmp_path, monkeypatch):
+    """FastqFile (host/bm_genome.h): ONE mapped, progressively built index per file, shared by the tool's passes.  Several
+    consumers walk it at once while it is still being built (tiny chunks: dozens of publications) and see the same records;
+    a file rewritten under the same name is indexed afresh (size / mtime / inode are part of the key)."""
+    from concurrent.futures import ThreadPoolExecutor
+    g = host.Genome.synth(77, [90_000])
+    host.Reads(g, 4096, 150, 150, 6000, seed=5, noisy_quals=True).write_fastq(str(tmp_path / "a"))
+    host.Reads(g, 4096, 150, 150, 2500, seed=6).write_fastq(str(tmp_path / "b"))
+    want_a, want_b = host.fastq_stats(str(tmp_path / "a.fastq")), host.fastq_stats(str(tmp_path / "b.fastq"))
+    assert want_a[0] == 6000 and want_b[0] == 2500 and want_a != want_b
+    monkeypatch.setenv("BM_IO_BLOCK", "4096")
+    path = tmp_path / "shared.fastq"
+    for src, want in (("a.fastq", want_a), ("b.fastq", want_b), ("a.fastq", want_a)):
+        path.write_bytes((tmp_path / src).read_bytes())               # same name, new content
+        with ThreadPoolExecutor(6) as pool:
+            got = list(pool.map(lambda _: host.fastq_stats(str(path)), range(6)))
+        assert got == [want] * 6
+    # an error in the middle of the file: every consumer gets the records before it, then the error
+    text = path.read_text().split("\n")
+    text[4 * 3000 + 2] = "-"                                             # record 3000 loses its '+' line
+    path.write_text("\n".join(text))
+    with ThreadPoolExecutor(4) as pool:
+        def attempt(_):
+            try:
+                host.fastq_stats(str(path))
+                return "no error"
+            except RuntimeError as e:
+                return str(e)
+        errs = list(pool.map(attempt, range(4)))
+    assert all("FASTQ" in e and "shared.fastq" in e for e in errs), errs
+
+
 def test_fastq_reader_finds_record_starts_anywhere(tmp_path, monkeypatch):
     """The mapped FASTQ reader resynchronises at every chunk boundary on "a line that begins with '@' whose line after
     next begins with '+'".  Qualities that begin with '@' or '+', headers that look like anything, reads of every
