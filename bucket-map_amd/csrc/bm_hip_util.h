@@ -64,7 +64,7 @@ inline hipError_t upload_pageable(void *dst, const void *src, size_t bytes) {
         e = hipHostMalloc(&stage[i], kPiece, hipHostMallocDefault);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&done[i], hipEventDisableTiming);
     }
-    const unsigned threads = std::max(1u, std::min(6u, std::thread::hardware_concurrency() / 2u));
+    const unsigned threads = std::max(1u, std::min(3u, std::thread::hardware_concurrency() / 2u));
     size_t piece = 0;
     for (size_t at = 0; e == hipSuccess && at < bytes; at += kPiece, piece++) {
         const int slot = (int)(piece & 1);

@@ -295,7 +295,7 @@ int bml_sample_text_windows(bml_ctx *c, const uint8_t *text, uint64_t n_bytes, c
     HIP_TRY(c->s_hash.need((size_t)piece * p));
     HIP_TRY(c->s_pos.need((size_t)piece * p));
     HIP_TRY(c->s_has.need(piece));
-    const unsigned hw = std::max(1u, std::min(6u, std::thread::hardware_concurrency() / 2u));
+    const unsigned hw = std::max(1u, std::min(3u, std::thread::hardware_concurrency() / 2u));
     struct InFlight { uint32_t first = 0, n = 0; bool busy = false; } fl[2];
     auto finish = [&](int slot) -> int {                         // the piece's results, from the page-locked slot to the caller
         if (!fl[slot].busy) return BML_OK;

@@ -339,58 +339,85 @@ public:
     int get_allowed_mismatch() const { return allowed_mismatch; }
     int get_allowed_indel() const { return allowed_indel; }
 
-    // initialize (:440-453): remember the genome, load the q-gram index into the mapper
+    // initialize (:440-453): remember the genome, load the q-gram index into the mapper -- and send the bucket sequences to the
+    // scanner's (and the verifier's) devices on a thread of its own, NOW: the upload (_initialize_kmer_index, :151-160) needs
+    // nothing but the genome, so it runs under the index load and under map() instead of after them.
     void initialize(const Genome &genome, std::filesystem::path const &index_directory, std::string const &indicator) {
         genome_ = &genome;
+        if (!serial_passes_) start_genome_upload();
         _m->load(index_directory, indicator);
     }
 
+    ~bucket_locator() {
+        if (uploader_.joinable()) uploader_.join();
+    }
+
+private:
+    // BM_SERIAL_PASSES=1 (measurement): the upload and the sampling pass start when map() has returned, so that map()'s own
+    // time can be read without two other passes sharing the PCIe link and the cores with it
+    bool serial_passes_ = std::getenv("BM_SERIAL_PASSES") != nullptr;
+    std::thread uploader_;
+    std::exception_ptr upload_error_;
+    float upload_ms_ = 0.f;
+    bool upload_started_ = false;
+
+    // the bucket sequences as views into one byte string that goes to the devices (_initialize_kmer_index, :151-160)
+    void start_genome_upload() {
+        if (upload_started_) return;
+        upload_started_ = true;
+        buckets_ = cut_buckets(*genome_, static_cast<int>(bucket_length), static_cast<int>(read_length));
+        const auto t_begin = std::chrono::steady_clock::now();
+        uploader_ = std::thread([this, t_begin]() {
+            try {
+                std::vector<uint64_t> rec_off(genome_->seqs.size() + 1, 0);
+                for (size_t r = 0; r < genome_->seqs.size(); r++) rec_off[r + 1] = rec_off[r] + genome_->seqs[r].size();
+                // the records back to back, for the uploads only: uninitialised storage, copied by a few threads
+                const uint64_t total = rec_off.back();
+                std::unique_ptr<uint8_t[]> flat(new uint8_t[total ? total : 1]);
+                {
+                    const unsigned n_thr = std::min<unsigned>(8, std::max(1u, std::thread::hardware_concurrency()));
+                    std::atomic<size_t> next{0};
+                    auto copy_records = [&]() {
+                        for (size_t r = next.fetch_add(1); r < genome_->seqs.size(); r = next.fetch_add(1))
+                            std::memcpy(flat.get() + rec_off[r], genome_->seqs[r].data(), genome_->seqs[r].size());
+                    };
+                    std::vector<std::thread> pool;
+                    for (unsigned t = 1; t < n_thr; t++) pool.emplace_back(copy_records);
+                    copy_records();
+                    for (auto &t : pool) t.join();
+                }
+                bstart_.assign(buckets_.size(), 0);
+                blen_.assign(buckets_.size(), 0);
+                for (size_t b = 0; b < buckets_.size(); b++) {
+                    bstart_[b] = rec_off[buckets_[b].record] + buckets_[b].start;
+                    blen_[b] = buckets_[b].end - buckets_[b].start;
+                }
+                _s->load_genome(flat.get(), total, bstart_.data(), blen_.data(), static_cast<uint32_t>(buckets_.size()));
+                if (_v) _v->load_genome(flat.get(), total);
+            } catch (...) {
+                upload_error_ = std::current_exception();
+            }
+            upload_ms_ = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+        });
+    }
+
+public:
     // _locate (:613-705)
     std::vector<std::vector<locate_t>> locate_reads(const std::string &sequence_file) {
-        // _initialize_kmer_index (:151-160): the bucket sequences, here as views into one byte string that goes to
-        // the scanner's (and the verifier's) devices, and then _prepare_read_query (:292-347), the locator's own pass
-        // over the FASTQ file.  Neither depends on the mapper's results, so both run on their own thread while
-        // _m->map() parses the reads and drives the filter.
-        buckets_ = cut_buckets(*genome_, static_cast<int>(bucket_length), static_cast<int>(read_length));
-        auto upload_genome = [&]() {
-            std::vector<uint64_t> rec_off(genome_->seqs.size() + 1, 0);
-            for (size_t r = 0; r < genome_->seqs.size(); r++) rec_off[r + 1] = rec_off[r] + genome_->seqs[r].size();
-            // the records back to back, for the uploads only: uninitialised storage, copied by a few threads
-            const uint64_t total = rec_off.back();
-            std::unique_ptr<uint8_t[]> flat(new uint8_t[total ? total : 1]);
-            {
-                const unsigned n_thr = std::min<unsigned>(8, std::max(1u, std::thread::hardware_concurrency()));
-                std::atomic<size_t> next{0};
-                auto copy_records = [&]() {
-                    for (size_t r = next.fetch_add(1); r < genome_->seqs.size(); r = next.fetch_add(1))
-                        std::memcpy(flat.get() + rec_off[r], genome_->seqs[r].data(), genome_->seqs[r].size());
-                };
-                std::vector<std::thread> pool;
-                for (unsigned t = 1; t < n_thr; t++) pool.emplace_back(copy_records);
-                copy_records();
-                for (auto &t : pool) t.join();
-            }
-            bstart_.assign(buckets_.size(), 0);
-            blen_.assign(buckets_.size(), 0);
-            for (size_t b = 0; b < buckets_.size(); b++) {
-                bstart_[b] = rec_off[buckets_[b].record] + buckets_[b].start;
-                blen_[b] = buckets_[b].end - buckets_[b].start;
-            }
-            _s->load_genome(flat.get(), total, bstart_.data(), blen_.data(), static_cast<uint32_t>(buckets_.size()));
-            if (_v) _v->load_genome(flat.get(), total);
-        };
+        // The bucket sequences are on their way to the devices since initialize(); _prepare_read_query (:292-347), the
+        // locator's own pass over the FASTQ file, does not depend on the mapper's results either, so it runs on a thread
+        // of its own while _m->map() lays out the reads' windows and drives the filter.
+        if (!serial_passes_) start_genome_upload();
         // (two threads: the upload touches the scanner's genome buffers, the sampling its window buffers and its stream)
-        std::exception_ptr upload_error, sampling_error;
+        std::exception_ptr sampling_error;
         const auto t_side = std::chrono::steady_clock::now();
-        float upload_ms = 0.f, sampling_ms = 0.f;
-        std::thread uploader([&]() {
-            try {
-                upload_genome();
-            } catch (...) {
-                upload_error = std::current_exception();
-            }
-            upload_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_side).count();
-        });
+        float sampling_ms = 0.f;
+        segments_t sequence_ids_orig, sequence_ids_rev_comp;
+        if (serial_passes_) {
+            std::tie(sequence_ids_orig, sequence_ids_rev_comp) = _m->map(sequence_file);
+            _m->reset();
+            start_genome_upload();
+        }
         std::thread sampler([&]() {
             try {
                 prepare_read_query(sequence_file);
@@ -399,23 +426,31 @@ public:
             }
             sampling_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_side).count();
         });
-        segments_t sequence_ids_orig, sequence_ids_rev_comp;
         try {
-            std::tie(sequence_ids_orig, sequence_ids_rev_comp) = _m->map(sequence_file);
-            _m->reset();
+            if (!serial_passes_) {
+                std::tie(sequence_ids_orig, sequence_ids_rev_comp) = _m->map(sequence_file);
+                _m->reset();
+            }
         } catch (...) {
-            uploader.join();
+            if (uploader_.joinable()) uploader_.join();
             sampler.join();
             throw;
         }
         auto t0 = std::chrono::steady_clock::now();
-        uploader.join();
+        if (uploader_.joinable()) uploader_.join();
         sampler.join();
-        if (upload_error) std::rethrow_exception(upload_error);
+        upload_started_ = false;                                 // (a second locate() on this object uploads again)
+        if (upload_error_) {
+            std::exception_ptr e = upload_error_;
+            upload_error_ = nullptr;
+            std::rethrow_exception(e);
+        }
         if (sampling_error) std::rethrow_exception(sampling_error);
         if (std::getenv("BM_LOG_BATCHES"))
-            std::cerr << "[bm] beside map(): genome upload done after " << upload_ms << " ms, k-mer sampling pass after " << sampling_ms
-                      << " ms; map() returned after " << std::chrono::duration<float, std::milli>(t0 - t_side).count() << " ms\n";
+            std::cerr << "[bm] genome upload (begun at initialize()) took " << upload_ms_ << " ms; beside map(): k-mer sampling pass done after "
+                      << sampling_ms << " ms, map() returned after " << std::chrono::duration<float, std::milli>(t0 - t_side).count()
+                      << " ms, both passes and the upload done after "
+                      << std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_side).count() << " ms\n";
 
         // Candidates in the order of the reference's bucket loop (:651-693): buckets ascending; inside a
         // bucket the reads as-is in list order, then the reverse complements in REVERSE list order.
