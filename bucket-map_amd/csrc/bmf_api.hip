@@ -244,6 +244,7 @@ struct bmf_ctx {
     TwoPass two_pass;                // used instead of `vote` when dp.pass1_rows > 0
     // folded first pass (bmf_fold4_kernel): one bit per group of 4 buckets, a quarter of the row bytes
     uint8_t *d_fold = nullptr;       // (n_rows + 1) x dpf.pitch
+    DevBuf<uint32_t> tune_lists;     // tune_pruned: the measured prefix's row-id lists as the sample kernel wrote them
     bmf::DevParams dpf{};            // the folded geometry + rows per sample the folded pass reads
     uint32_t fold = 1;               // 2 or 4 when pass1_fold is set
     // The folded pass is chosen by a model of how many chunks survive it by chance.  Guard: every run's slow-path
@@ -748,6 +749,7 @@ void bmf_destroy(bmf_ctx *c) {
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
     free_map_slots(c);
     free_index(c);
+    c->tune_lists.release();
     (void)hipFree(c->d_lut);
     (void)hipFree(c->d_pos_table);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -1101,12 +1103,16 @@ static hipError_t batch_reserve(bmf_ctx *c, bmf_batch *b, size_t n, size_t n_byt
         ok(b->slice_cnt.need(2 * n * c->n_slices));
         ok(b->slice_ids.need(2 * n * c->n_slices * c->p.max_candidates));
     }
-    if (c->dp.pass1_rows) {
+    if (c->dp.pass1_rows || c->tunable) {
+        // at their largest whatever form serves the context now: the measured forms (tune_pruned) and a later change of form
+        // must never re-allocate -- DevBuf frees before it grows, and hipFree waits for every stream of the device (in the
+        // tools: for the genome upload that runs beside map(), 150 ms)
         ok(b->q_counters.need(4));
         ok(b->q_slow.need(2 * n));
+        ok(b->q_left.need(2 * n));
         ok(b->q_live_n.need(2 * n));
         ok(b->q_live_chunks.need(2 * n * bmf::kMaxLive));
-        ok(b->q_live_mask.need(2 * n * c->dp.max_live));
+        ok(b->q_live_mask.need(2 * n * bmf::kMaxLive));
     }
     return e;
 }
@@ -1337,10 +1343,13 @@ static int tune_pruned(bmf_ctx *c, bmf_batch *b) {
     // PLACE, so a form that runs without it must not be timed on lists an earlier candidate left sorted.  A copy of the
     // prefix's lists (as the sample kernel wrote them) is put back before such a run.
     const size_t list_bytes = 2 * (size_t)n_win * c->dp.list_len * sizeof(uint32_t);
+    // (a buffer of the context's, kept: hipFree waits for the whole device -- in the tools for the genome upload that runs
+    // beside map() -- and one such wait cost the measured batch 160 ms)
     uint32_t *saved = nullptr;
-    if (rc == BMF_OK && (hipMalloc(reinterpret_cast<void **>(&saved), list_bytes) != hipSuccess ||
-                         hipMemcpyAsync(saved, b->lists.p, list_bytes, hipMemcpyDeviceToDevice, c->stream) != hipSuccess))
+    if (rc == BMF_OK && (c->tune_lists.need(list_bytes / sizeof(uint32_t)) != hipSuccess ||
+                         hipMemcpyAsync(c->tune_lists.p, b->lists.p, list_bytes, hipMemcpyDeviceToDevice, c->stream) != hipSuccess))
         rc = fail(BMF_ERR_HIP, "tune_pruned: out of device memory");
+    saved = c->tune_lists.p;
     bool lists_sorted = false;
     std::vector<float> ms(cands.size(), 1e30f);
     auto time_one = [&](size_t i) {
@@ -1373,7 +1382,6 @@ static int tune_pruned(bmf_ctx *c, bmf_batch *b) {
     if (saved) {
         if (lists_sorted) (void)hipMemcpyAsync(b->lists.p, saved, list_bytes, hipMemcpyDeviceToDevice, c->stream);   // as the sample kernel left them
         (void)hipStreamSynchronize(c->stream);
-        (void)hipFree(saved);
     }
     if (rc != BMF_OK) return rc;
     size_t best = 0;
@@ -1388,10 +1396,8 @@ static int tune_pruned(bmf_ctx *c, bmf_batch *b) {
                 std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count());
     }
     rc = apply_choice(c, cands[best]);
-    if (rc == BMF_OK && !c->pass1_fold && c->d_fold) {             // no folded pass in the end: its copy of the index goes
-        (void)hipFree(c->d_fold);
-        c->d_fold = nullptr;
-    }
+    // (no folded pass in the end: its copy of the index stays until bmf_reset / bmf_destroy -- freeing it here would wait for
+    // every stream of the device)
     return rc;
 }
 
@@ -1751,6 +1757,7 @@ int bmf_map_reserve(bmf_ctx *c, uint32_t max_windows_per_call, int text_windows)
     if (rc != BMF_OK) return rc;
     const size_t n = std::min(piece_windows_of(max_windows_per_call), max_windows_per_call), span = n * (size_t)c->p.read_len;
     const size_t n_items = 2 * n, mc = c->p.max_candidates;
+    if (c->tunable) HIP_TRY(c->tune_lists.need(2 * (size_t)std::min<size_t>(n, c->tune_windows) * c->dp.list_len));
     for (auto *sl : c->slot) {
         bmf_batch *b = &sl->dev;
         HIP_TRY(batch_reserve(c, b, n, span));

@@ -339,12 +339,12 @@ public:
     int get_allowed_mismatch() const { return allowed_mismatch; }
     int get_allowed_indel() const { return allowed_indel; }
 
-    // initialize (:440-453): remember the genome, load the q-gram index into the mapper -- and send the bucket sequences to the
-    // scanner's (and the verifier's) devices on a thread of its own, NOW: the upload (_initialize_kmer_index, :151-160) needs
-    // nothing but the genome, so it runs under the index load and under map() instead of after them.
+    // initialize (:440-453): remember the genome, load the q-gram index into the mapper.
+    // (Tried: the genome upload begun HERE, under the index load -- everything the locator needs was there no sooner, the
+    // upload being the longest of the three passes either way, and map() took twice as long for sharing the link with it
+    // from its first batch on: 0.09 -> 0.22 s per 1 M reads.  It starts with map(), in locate_reads.)
     void initialize(const Genome &genome, std::filesystem::path const &index_directory, std::string const &indicator) {
         genome_ = &genome;
-        if (!serial_passes_) start_genome_upload();
         _m->load(index_directory, indicator);
     }
 
@@ -404,9 +404,9 @@ private:
 public:
     // _locate (:613-705)
     std::vector<std::vector<locate_t>> locate_reads(const std::string &sequence_file) {
-        // The bucket sequences are on their way to the devices since initialize(); _prepare_read_query (:292-347), the
-        // locator's own pass over the FASTQ file, does not depend on the mapper's results either, so it runs on a thread
-        // of its own while _m->map() lays out the reads' windows and drives the filter.
+        // _initialize_kmer_index (:151-160: the bucket sequences to the devices) and _prepare_read_query (:292-347: the
+        // locator's own pass over the FASTQ file) do not depend on the mapper's results, so each runs on a thread of its own
+        // while _m->map() lays out the reads' windows and drives the filter.
         if (!serial_passes_) start_genome_upload();
         // (two threads: the upload touches the scanner's genome buffers, the sampling its window buffers and its stream)
         std::exception_ptr sampling_error;
@@ -447,7 +447,7 @@ public:
         }
         if (sampling_error) std::rethrow_exception(sampling_error);
         if (std::getenv("BM_LOG_BATCHES"))
-            std::cerr << "[bm] genome upload (begun at initialize()) took " << upload_ms_ << " ms; beside map(): k-mer sampling pass done after "
+            std::cerr << "[bm] beside map(): genome upload done after " << upload_ms_ << " ms, k-mer sampling pass after "
                       << sampling_ms << " ms, map() returned after " << std::chrono::duration<float, std::milli>(t0 - t_side).count()
                       << " ms, both passes and the upload done after "
                       << std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_side).count() << " ms\n";
