@@ -87,4 +87,72 @@ inline hipError_t upload_pageable(void *dst, const void *src, size_t bytes) {
     return e;
 }
 
+// The same for a source that lies in PIECES on the host (the records of a genome, each a buffer of its own): the pieces go
+// to dst back to back, in order, through the same two page-locked buffers -- no flattened copy on the host.
+inline hipError_t upload_pageable_records(void *dst, const uint8_t *const *rec, const uint64_t *rec_len, uint32_t n_records) {
+    constexpr size_t kPiece = 32u << 20;
+    uint64_t total = 0;
+    for (uint32_t r = 0; r < n_records; r++) total += rec_len[r];
+    if (total == 0) return hipSuccess;
+    void *stage[2] = {nullptr, nullptr};
+    hipEvent_t done[2] = {nullptr, nullptr};
+    hipStream_t stream = nullptr;
+    hipError_t e = hipStreamCreateWithFlags(&stream, hipStreamNonBlocking);
+    for (int i = 0; i < 2 && e == hipSuccess; i++) {
+        e = hipHostMalloc(&stage[i], kPiece, hipHostMallocDefault);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&done[i], hipEventDisableTiming);
+    }
+    const unsigned threads = std::max(1u, std::min(3u, std::thread::hardware_concurrency() / 2u));
+    uint32_t r = 0;                 // the record and the offset in it where the next piece begins
+    uint64_t in_r = 0;
+    size_t piece = 0;
+    for (uint64_t at = 0; e == hipSuccess && at < total; at += kPiece, piece++) {
+        const int slot = (int)(piece & 1);
+        const size_t n = (size_t)std::min<uint64_t>(kPiece, total - at);
+        if (piece >= 2) e = hipEventSynchronize(done[slot]);           // the buffer's previous copy has left it
+        if (e != hipSuccess) break;
+        // the stretches of records that make up this piece
+        struct Part { const uint8_t *src; size_t to, len; };
+        std::vector<Part> parts;
+        for (size_t filled = 0; filled < n;) {
+            while (in_r == rec_len[r]) {
+                r++;
+                in_r = 0;
+            }
+            const size_t take = (size_t)std::min<uint64_t>(rec_len[r] - in_r, n - filled);
+            parts.push_back(Part{rec[r] + in_r, filled, take});
+            filled += take;
+            in_r += take;
+        }
+        // ... copied by a few threads, each a contiguous share of the piece's bytes
+        auto share = [&](unsigned t) {
+            const size_t lo = n * t / threads, hi = n * (t + 1) / threads;
+            for (const Part &p : parts) {
+                const size_t a = std::max(lo, p.to), b = std::min(hi, p.to + p.len);
+                if (a < b) std::memcpy(static_cast<char *>(stage[slot]) + a, p.src + (a - p.to), b - a);
+            }
+        };
+        if (threads <= 1 || n < (4u << 20)) {
+            for (unsigned t = 0; t < threads; t++) share(t);
+        } else {
+            std::vector<std::thread> pool;
+            for (unsigned t = 1; t < threads; t++) pool.emplace_back(share, t);
+            share(0);
+            for (auto &t : pool) t.join();
+        }
+        e = hipMemcpyAsync(static_cast<char *>(dst) + at, stage[slot], n, hipMemcpyHostToDevice, stream);
+        if (e == hipSuccess) e = hipEventRecord(done[slot], stream);
+    }
+    if (stream) {
+        const hipError_t s = hipStreamSynchronize(stream);
+        if (e == hipSuccess) e = s;
+    }
+    for (int i = 0; i < 2; i++) {
+        if (done[i]) (void)hipEventDestroy(done[i]);
+        if (stage[i]) (void)hipHostFree(stage[i]);
+    }
+    if (stream) (void)hipStreamDestroy(stream);
+    return e;
+}
+
 }  // namespace bmhip

@@ -392,6 +392,39 @@ int bml_load_genome(bml_ctx *c, const uint8_t *bases, uint64_t n_bases, const ui
     return BML_OK;
 }
 
+// The same for a genome whose records are buffers of their own on the host (no flattened copy needed): the records go
+// to the device back to back, in order; bucket_start counts in that concatenation.
+int bml_load_genome_records(bml_ctx *c, const uint8_t *const *rec, const uint64_t *rec_len, uint32_t n_records,
+                            const uint64_t *bucket_start, const uint32_t *bucket_len, uint32_t n_buckets) {
+    if (!c || (n_records && (!rec || !rec_len)) || (n_buckets && (!bucket_start || !bucket_len)))
+        return fail(BML_ERR_ARG, "bml_load_genome_records: null argument");
+    uint64_t n_bases = 0;
+    for (uint32_t r = 0; r < n_records; r++) {
+        if (rec_len[r] && !rec[r]) return fail(BML_ERR_ARG, "bml_load_genome_records: record %u is null", r);
+        n_bases += rec_len[r];
+    }
+    for (uint32_t b = 0; b < n_buckets; b++) {
+        if (bucket_len[b] > c->p.max_bucket_bases)
+            return fail(BML_ERR_ARG, "bucket %u has %u bases, more than max_bucket_bases = %u", b, bucket_len[b], c->p.max_bucket_bases);
+        if (bucket_start[b] > n_bases || bucket_len[b] > n_bases - bucket_start[b])
+            return fail(BML_ERR_ARG, "bucket %u lies outside the genome buffer", b);
+    }
+    HIP_TRY(hipSetDevice(c->p.device));
+    HIP_TRY(c->genome.need((size_t)n_bases + 64));
+    HIP_TRY(hipMemset(c->genome.p + n_bases, 'A', 64));
+    HIP_TRY(c->bucket_start.need(n_buckets));
+    HIP_TRY(c->bucket_len.need(n_buckets));
+    HIP_TRY(bmhip::upload_pageable_records(c->genome.p, rec, rec_len, n_records));
+    if (n_buckets) {
+        HIP_TRY(hipMemcpy(c->bucket_start.p, bucket_start, (size_t)n_buckets * sizeof(uint64_t), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(c->bucket_len.p, bucket_len, (size_t)n_buckets * sizeof(uint32_t), hipMemcpyHostToDevice));
+    }
+    c->n_buckets = n_buckets;
+    c->h_bucket_len.assign(bucket_len, bucket_len + n_buckets);
+    c->loaded = true;
+    return BML_OK;
+}
+
 int bml_locate(bml_ctx *c, const uint32_t *sample_hash, const uint16_t *sample_pos, const uint32_t *seg_len,
                uint32_t n_windows, const uint32_t *pair_bucket, const uint32_t *pair_window, const uint8_t *pair_rc,
                uint32_t n_pairs, int32_t *out_offset, uint32_t *out_votes) {

@@ -285,6 +285,21 @@ int bmv_load_genome(bmv_ctx *c, const uint8_t *bases, uint64_t n_bases) {
     return BMV_OK;
 }
 
+int bmv_load_genome_records(bmv_ctx *c, const uint8_t *const *rec, const uint64_t *rec_len, uint32_t n_records) {
+    if (!c || (n_records && (!rec || !rec_len))) return fail(BMV_ERR_ARG, "bmv_load_genome_records: null argument");
+    uint64_t n_bases = 0;
+    for (uint32_t r = 0; r < n_records; r++) {
+        if (rec_len[r] && !rec[r]) return fail(BMV_ERR_ARG, "bmv_load_genome_records: record %u is null", r);
+        n_bases += rec_len[r];
+    }
+    HIP_TRY(hipSetDevice(c->p.device));
+    HIP_TRY(c->genome.need((size_t)n_bases + 64u));
+    HIP_TRY(bmhip::upload_pageable_records(c->genome.p, rec, rec_len, n_records));
+    c->n_genome = n_bases;
+    c->loaded = true;
+    return BMV_OK;
+}
+
 int bmv_align(bmv_ctx *c, const uint8_t *reads, uint64_t n_read_bytes, const uint64_t *text_start,
               const uint32_t *text_len, const uint8_t *text_rc, const uint64_t *query_start, const uint32_t *query_len,
               uint32_t n, uint64_t *total_cigar) {

@@ -61,6 +61,20 @@ public:
     // genome as one byte string; bucket b = [bucket_start[b], +bucket_len[b])
     virtual void load_genome(const uint8_t *bases, uint64_t n_bases, const uint64_t *bucket_start,
                              const uint32_t *bucket_len, uint32_t n_buckets) = 0;
+    // ... or from records that are buffers of their own (concatenated in order; bucket_start counts in that concatenation).
+    // Default: flatten, then load_genome.
+    virtual void load_genome_records(const uint8_t *const *rec, const uint64_t *rec_len, uint32_t n_records,
+                                     const uint64_t *bucket_start, const uint32_t *bucket_len, uint32_t n_buckets) {
+        uint64_t total = 0;
+        for (uint32_t r = 0; r < n_records; r++) total += rec_len[r];
+        std::unique_ptr<uint8_t[]> flat(new uint8_t[total ? total : 1]);
+        uint64_t at = 0;
+        for (uint32_t r = 0; r < n_records; r++) {
+            std::memcpy(flat.get() + at, rec[r], rec_len[r]);
+            at += rec_len[r];
+        }
+        load_genome(flat.get(), total, bucket_start, bucket_len, n_buckets);
+    }
     // windows: sample_hash/sample_pos [n_windows x p], seg_len[n_windows]; candidates grouped by bucket.
     // out_offset = what _find_offset returns (first of the pair, or -1), out_votes = second.
     virtual void scan(const uint32_t *sample_hash, const uint16_t *sample_pos, const uint32_t *seg_len,
@@ -75,6 +89,17 @@ class alignment_verifier {
 public:
     virtual ~alignment_verifier() = default;
     virtual void load_genome(const uint8_t *bases, uint64_t n_bases) = 0;
+    virtual void load_genome_records(const uint8_t *const *rec, const uint64_t *rec_len, uint32_t n_records) {
+        uint64_t total = 0;
+        for (uint32_t r = 0; r < n_records; r++) total += rec_len[r];
+        std::unique_ptr<uint8_t[]> flat(new uint8_t[total ? total : 1]);
+        uint64_t at = 0;
+        for (uint32_t r = 0; r < n_records; r++) {
+            std::memcpy(flat.get() + at, rec[r], rec_len[r]);
+            at += rec_len[r];
+        }
+        load_genome(flat.get(), total);
+    }
     // score = alignment.score(), begin = sequence1_begin_position(), CIGAR entries packed len << 4 | op
     // (0 M, 1 I, 2 D); alignment a owns cigar[cigar_offset[a] .. cigar_offset[a + 1])
     virtual void align(const uint8_t *reads, uint64_t n_read_bytes, const uint64_t *text_start, const uint32_t *text_len,
@@ -369,22 +394,14 @@ private:
         const auto t_begin = std::chrono::steady_clock::now();
         uploader_ = std::thread([this, t_begin]() {
             try {
-                std::vector<uint64_t> rec_off(genome_->seqs.size() + 1, 0);
-                for (size_t r = 0; r < genome_->seqs.size(); r++) rec_off[r + 1] = rec_off[r] + genome_->seqs[r].size();
-                // the records back to back, for the uploads only: uninitialised storage, copied by a few threads
-                const uint64_t total = rec_off.back();
-                std::unique_ptr<uint8_t[]> flat(new uint8_t[total ? total : 1]);
-                {
-                    const unsigned n_thr = std::min<unsigned>(8, std::max(1u, std::thread::hardware_concurrency()));
-                    std::atomic<size_t> next{0};
-                    auto copy_records = [&]() {
-                        for (size_t r = next.fetch_add(1); r < genome_->seqs.size(); r = next.fetch_add(1))
-                            std::memcpy(flat.get() + rec_off[r], genome_->seqs[r].data(), genome_->seqs[r].size());
-                    };
-                    std::vector<std::thread> pool;
-                    for (unsigned t = 1; t < n_thr; t++) pool.emplace_back(copy_records);
-                    copy_records();
-                    for (auto &t : pool) t.join();
+                // the records go to the devices back to back, each from where it lies (no flattened copy on the host)
+                const size_t n_rec = genome_->seqs.size();
+                std::vector<uint64_t> rec_off(n_rec + 1, 0), rec_len(n_rec);
+                std::vector<const uint8_t *> rec(n_rec);
+                for (size_t r = 0; r < n_rec; r++) {
+                    rec[r] = reinterpret_cast<const uint8_t *>(genome_->seqs[r].data());
+                    rec_len[r] = genome_->seqs[r].size();
+                    rec_off[r + 1] = rec_off[r] + rec_len[r];
                 }
                 bstart_.assign(buckets_.size(), 0);
                 blen_.assign(buckets_.size(), 0);
@@ -392,8 +409,9 @@ private:
                     bstart_[b] = rec_off[buckets_[b].record] + buckets_[b].start;
                     blen_[b] = buckets_[b].end - buckets_[b].start;
                 }
-                _s->load_genome(flat.get(), total, bstart_.data(), blen_.data(), static_cast<uint32_t>(buckets_.size()));
-                if (_v) _v->load_genome(flat.get(), total);
+                _s->load_genome_records(rec.data(), rec_len.data(), static_cast<uint32_t>(n_rec), bstart_.data(), blen_.data(),
+                                        static_cast<uint32_t>(buckets_.size()));
+                if (_v) _v->load_genome_records(rec.data(), rec_len.data(), static_cast<uint32_t>(n_rec));
             } catch (...) {
                 upload_error_ = std::current_exception();
             }

@@ -40,6 +40,9 @@ public:
         for (bmv_ctx *c : ctx_) bmv_destroy(c);
     }
 
+    void load_genome_records(const uint8_t *const *rec, const uint64_t *rec_len, uint32_t n_records) override {
+        for_each_device(ctx_.size(), [&](size_t d) { check(bmv_load_genome_records(ctx_[d], rec, rec_len, n_records), "uploading the genome failed: "); });
+    }
     void load_genome(const uint8_t *bases, uint64_t n_bases) override {
         for_each_device(ctx_.size(), [&](size_t d) { check(bmv_load_genome(ctx_[d], bases, n_bases), "uploading the genome failed: "); });
     }

@@ -52,6 +52,13 @@ public:
         });
     }
 
+    void load_genome_records(const uint8_t *const *rec, const uint64_t *rec_len, uint32_t n_records, const uint64_t *bucket_start,
+                             const uint32_t *bucket_len, uint32_t n_buckets) override {
+        for_each_device(ctx_.size(), [&](size_t d) {
+            check(bml_load_genome_records(ctx_[d], rec, rec_len, n_records, bucket_start, bucket_len, n_buckets), "uploading the genome failed: ");
+        });
+    }
+
     void sample_windows(const uint8_t *bases, const uint8_t *quals, uint64_t n_bytes, const uint64_t *win_start,
                         const uint32_t *win_len, uint32_t n_windows, uint32_t min_base_quality, uint32_t *out_hash,
                         uint16_t *out_pos, uint8_t *out_has) override {

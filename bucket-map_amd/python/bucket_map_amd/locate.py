@@ -28,6 +28,7 @@ SYMBOLS = {
     "bml_create": (C.c_int, [C.POINTER(_Params), C.POINTER(C.c_void_p)]),
     "bml_destroy": (None, [C.c_void_p]),
     "bml_load_genome": (C.c_int, [C.c_void_p, _u8p, C.c_uint64, _u64p, _u32p, C.c_uint32]),
+    "bml_load_genome_records": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), _u64p, C.c_uint32, _u64p, _u32p, C.c_uint32]),
     "bml_sample_windows": (C.c_int, [C.c_void_p, _u8p, _u8p, C.c_uint64, _u64p, _u32p, C.c_uint32, C.c_uint32, _u32p, _u16p, _u8p]),
     "bml_sample_text_windows": (C.c_int, [C.c_void_p, _u8p, C.c_uint64, _u64p, _u64p, _u32p, C.c_uint32, C.c_uint32, _u32p, _u16p, _u8p]),
     "bml_locate": (C.c_int, [C.c_void_p, _u32p, _u16p, _u32p, C.c_uint32, _u32p, _u32p, _u8p, C.c_uint32, _i32p, _u32p]),
@@ -74,6 +75,15 @@ class LocatorScan:
         bs = np.ascontiguousarray(bucket_start, np.uint64)
         bl = np.ascontiguousarray(bucket_len, np.uint32)
         _check(lib().bml_load_genome(self._h, _p(bases, _u8p), len(bases), _p(bs, _u64p), _p(bl, _u32p), len(bs)))
+
+    def load_genome_records(self, records, bucket_start, bucket_len) -> None:
+        """bml_load_genome_records: the genome as a list of uint8 arrays (records), uploaded back to back."""
+        recs = [np.ascontiguousarray(r, np.uint8) for r in records]
+        ptrs = (C.c_void_p * len(recs))(*[r.ctypes.data for r in recs])
+        lens = np.array([len(r) for r in recs], np.uint64)
+        bs = np.ascontiguousarray(bucket_start, np.uint64)
+        bl = np.ascontiguousarray(bucket_len, np.uint32)
+        _check(lib().bml_load_genome_records(self._h, ptrs, _p(lens, _u64p), len(recs), _p(bs, _u64p), _p(bl, _u32p), len(bs)))
 
     def sample_windows(self, bases, quals, win_start, win_len, min_base_quality: int):
         """_prepare_read_query's sampling: (hash u32[n, p], pos u16[n, p], has u8[n])."""

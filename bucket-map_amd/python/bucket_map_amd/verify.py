@@ -27,6 +27,7 @@ SYMBOLS = {
     "bmv_create": (C.c_int, [C.POINTER(_Params), C.POINTER(C.c_void_p)]),
     "bmv_destroy": (None, [C.c_void_p]),
     "bmv_load_genome": (C.c_int, [C.c_void_p, _u8p, C.c_uint64]),
+    "bmv_load_genome_records": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.c_uint32]),
     "bmv_align": (C.c_int, [C.c_void_p, _u8p, C.c_uint64, _u64p, _u32p, _u8p, _u64p, _u32p, C.c_uint32, _u64p]),
     "bmv_results": (C.c_int, [C.c_void_p, _i32p, _u32p, _u64p, _u32p]),
     "bmv_last_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), _u64p]),

@@ -57,6 +57,11 @@ void bml_destroy(bml_ctx *ctx);
 int  bml_load_genome(bml_ctx *ctx, const uint8_t *bases, uint64_t n_bases, const uint64_t *bucket_start,
                      const uint32_t *bucket_len, uint32_t n_buckets);
 
+/* The same for a genome whose records are buffers of their own on the host: they go to the device back to back, in
+ * order, through page-locked pieces -- the caller needs no flattened copy; bucket_start counts in that concatenation. */
+int  bml_load_genome_records(bml_ctx *ctx, const uint8_t *const *rec, const uint64_t *rec_len, uint32_t n_records,
+                             const uint64_t *bucket_start, const uint32_t *bucket_len, uint32_t n_buckets);
+
 /* _prepare_read_query (:292-347) for a batch of windows: window w is the view [win_start[w], +win_len[w]) of
  * `bases` (ASCII, dna4 folding) and `quals` (phred+33), as in bmf_map_windows.  Per window: the k-mers whose
  * quality sum over their k bases is >= min_base_quality (:325-327; all k-mers if none is, :330-332),

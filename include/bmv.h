@@ -59,6 +59,8 @@ void bmv_destroy(bmv_ctx *ctx);
 /* The reference genome as one byte string (ASCII; the same string bml_load_genome takes).  Uploaded once;
  * text windows are views into it. */
 int  bmv_load_genome(bmv_ctx *ctx, const uint8_t *bases, uint64_t n_bases);
+/* ... or from records that are buffers of their own on the host (concatenated on the device, in order; bml_load_genome_records). */
+int  bmv_load_genome_records(bmv_ctx *ctx, const uint8_t *const *rec, const uint64_t *rec_len, uint32_t n_records);
 
 /* One batch of alignments: alignment a aligns the query reads[query_start[a], +query_len[a]) against the
  * text genome[text_start[a], +text_len[a]), reverse-complemented first when text_rc[a] != 0.  `reads` is

@@ -389,6 +389,43 @@ def test_gpu_sampling_from_a_fastq_text_equals_oracle(k, p, max_len):
     scan.close()
 
 
+@pytest.mark.gpu
+def test_gpu_genome_loaded_from_records_equals_the_flat_genome():
+    """bml_load_genome_records (what the tool calls: no flattened copy of the genome on the host): records of very different
+    sizes -- empty ones, one larger than two 32 MiB staging pieces -- concatenated on the device; the scan must find what it
+    finds in the same genome uploaded as one string."""
+    from bucket_map_amd import locate
+    rng = np.random.default_rng(99)
+    lens = [5, 0, 70_000, 1, (72 << 20) + 12_345, 0, 33_333, 900_000]
+    records = [LETTERS[rng.integers(0, 4, n)] for n in lens]
+    flat = np.concatenate(records)
+    k, p, read_len, bucket_len = 12, 10, 150, 65536
+    n_b = len(flat) // bucket_len
+    bstart = (np.arange(n_b) * bucket_len).astype(np.uint64)
+    blen = np.minimum(bucket_len + read_len, len(flat) - bstart.astype(np.int64)).astype(np.uint32)
+    # reads cut from the genome, a few per region incl. the staging-piece boundaries at 32 and 64 MiB
+    sh, sp, sl, pb, pw, pr = [], [], [], [], [], []
+    for at in [100, 70_100, (32 << 20) - 70, (64 << 20) - 10, n_b * bucket_len - 400, (40 << 20) + 7]:
+        seq = flat[at: at + read_len]
+        hs = onp.kmer_hashes(seq, k)
+        pos = [int(i) for i in onp.sample_positions(p, len(hs) - 1)]
+        sh.append([int(hs[j]) for j in pos]); sp.append(pos); sl.append(read_len)
+        pb.append(at // bucket_len); pw.append(len(sl) - 1); pr.append(0)
+    order = np.argsort(pb, kind="stable")
+    args = (np.array(sh, np.uint32), np.array(sp, np.uint16), np.array(sl, np.uint32), np.array(pb, np.uint32)[order],
+            np.array(pw, np.uint32)[order], np.array(pr, np.uint8)[order])
+    a = locate.LocatorScan(k, p, 4, 6, bucket_len + read_len)
+    a.load_genome(flat, bstart, blen)
+    want = a.locate(*args)
+    a.close()
+    b = locate.LocatorScan(k, p, 4, 6, bucket_len + read_len)
+    b.load_genome_records(records, bstart, blen)
+    got = b.locate(*args)
+    b.close()
+    assert np.array_equal(want[0], got[0]) and np.array_equal(want[1], got[1])
+    assert (want[0] > 0).all() and (want[1] == p).all()        # every read found where it was cut, with all its samples
+
+
 def _golden_sampling():
     import json
     here = os.path.dirname(os.path.abspath(__file__))
