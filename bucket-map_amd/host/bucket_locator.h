@@ -113,7 +113,14 @@ public:
 // of the tool after the device work had shrunk to milliseconds).
 class sam_text {
     std::ofstream out_;
-    std::string buf_;
+    std::string buf_, writing_;     // the buffer being filled / the one a writer thread is putting into the file
+    std::thread writer_;
+    bool write_failed_ = false;
+
+    void join_writer() {
+        if (writer_.joinable()) writer_.join();
+        if (write_failed_) throw std::runtime_error("writing the SAM file failed");
+    }
 
     void number(uint64_t v) {
         char tmp[24];
@@ -125,11 +132,32 @@ public:
     explicit sam_text(std::filesystem::path const &file) : out_(file, std::ios::binary) {
         if (!out_) throw std::runtime_error("cannot write " + file.string());
         buf_.reserve(5u << 20);
+        writing_.reserve(5u << 20);
     }
-    ~sam_text() { flush(); }
+    ~sam_text() {
+        try {
+            flush();
+            join_writer();
+        } catch (...) {
+        }
+    }
+    // the filled buffer goes to the file on a thread of its own while the next one is filled (records are formatted at
+    // about the speed the file system takes them: one after the other they cost twice)
     void flush() {
-        out_.write(buf_.data(), static_cast<std::streamsize>(buf_.size()));
+        join_writer();
+        writing_.swap(buf_);
         buf_.clear();
+        writer_ = std::thread([this]() {
+            out_.write(writing_.data(), static_cast<std::streamsize>(writing_.size()));
+            if (!out_) write_failed_ = true;
+        });
+    }
+    // everything written (call before reading the file back or reporting success)
+    void close() {
+        flush();
+        join_writer();
+        out_.flush();
+        if (!out_) throw std::runtime_error("writing the SAM file failed");
     }
     void header(const std::vector<std::string> &ref_ids, const std::vector<size_t> &ref_lengths) {
         buf_ += "@HD\tVN:1.6\n";
@@ -584,6 +612,7 @@ public:
                 read_id++;
             });
         }
+        sam.close();                                             // (every record is in the file before the time is taken)
         const float s = std::chrono::duration<float>(std::chrono::steady_clock::now() - t0).count();
         std::cerr << "[BENCHMARK]\tTotal mapped locations: " << mapped_locations << " ("
                   << static_cast<float>(mapped_locations) / read_id << " per sequence).\n";
