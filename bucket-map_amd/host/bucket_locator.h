@@ -122,11 +122,12 @@ class sam_text {
         if (write_failed_) throw std::runtime_error("writing the SAM file failed");
     }
 
-    void number(uint64_t v) {
+    static void number(std::string &buf, uint64_t v) {
         char tmp[24];
         const auto r = std::to_chars(tmp, tmp + sizeof tmp, v);
-        buf_.append(tmp, static_cast<size_t>(r.ptr - tmp));
+        buf.append(tmp, static_cast<size_t>(r.ptr - tmp));
     }
+    void number(uint64_t v) { number(buf_, v); }
 
 public:
     explicit sam_text(std::filesystem::path const &file) : out_(file, std::ios::binary) {
@@ -170,17 +171,26 @@ public:
         }
     }
     // QNAME FLAG RNAME POS MAPQ CIGAR * 0 0 SEQ QUAL
+    static void format(std::string &buf, std::string_view qname, unsigned flag, std::string_view rname, uint64_t pos, unsigned mapq,
+                       std::string_view cigar, std::string_view seq, std::string_view qual) {
+        buf.append(qname); buf += '\t';
+        number(buf, flag); buf += '\t';
+        buf.append(rname); buf += '\t';
+        number(buf, pos); buf += '\t';
+        number(buf, mapq); buf += '\t';
+        buf.append(cigar);
+        buf += "\t*\t0\t0\t";
+        buf.append(seq); buf += '\t';
+        buf.append(qual); buf += '\n';
+    }
     void record(std::string_view qname, unsigned flag, std::string_view rname, uint64_t pos, unsigned mapq, std::string_view cigar,
                 std::string_view seq, std::string_view qual) {
-        buf_.append(qname); buf_ += '\t';
-        number(flag); buf_ += '\t';
-        buf_.append(rname); buf_ += '\t';
-        number(pos); buf_ += '\t';
-        number(mapq); buf_ += '\t';
-        buf_.append(cigar);
-        buf_ += "\t*\t0\t0\t";
-        buf_.append(seq); buf_ += '\t';
-        buf_.append(qual); buf_ += '\n';
+        format(buf_, qname, flag, rname, pos, mapq, cigar, seq, qual);
+        if (buf_.size() > (4u << 20)) flush();
+    }
+    // records formatted elsewhere (format(): a few threads, each a block of reads), appended in order
+    void append(std::string_view records) {
+        buf_.append(records);
         if (buf_.size() > (4u << 20)) flush();
     }
 };
@@ -594,9 +604,48 @@ public:
         auto t0 = std::chrono::steady_clock::now();
         if (_v) {
             mapped_locations = write_verified(sequence_file, locate_res, h, sam, quality_threshold, read_id);
+        } else if (std::shared_ptr<FastqFile> fq = FastqFile::open(sequence_file)) {
+            // the records of a block of reads are formatted by a thread of their own (blocks of 16 384 reads, rounds of up to
+            // eight) and appended in read order: formatting 640 MB of SAM text on one thread was the tool's longest stage
+            const size_t n = fq->count(), block = 16384;
+            const unsigned T = std::min(8u, std::max(1u, std::thread::hardware_concurrency()));
+            std::vector<std::string> text(T);
+            std::vector<unsigned int> made(T);
+            auto format_block = [&](unsigned t, size_t r0, size_t r1) {
+                std::string &out = text[t], seq;
+                out.clear();
+                made[t] = 0;
+                for (size_t r = r0; r < r1; r++) {
+                    const FastqRecord rec = fq->view(r);
+                    auto best = filter_best_locations(locate_res[r], static_cast<unsigned int>(rec.seq.size()));   // :540
+                    if (best.empty()) continue;
+                    seq.clear();
+                    append_dna4(seq, rec.seq);
+                    for (auto &[bucket_id, offset, segment_offset, votes, is_original] : best) {
+                        (void)segment_offset;
+                        const unsigned int map_qual = std::min(60u, 6 * votes);                      // :591
+                        const size_t ref_offset = static_cast<size_t>(h.bucket_offsets[bucket_id]) + offset;  // :592, 0-based
+                        sam_text::format(out, rec.id, is_original ? 0 : 16, h.bucket_name[bucket_id], ref_offset + 1, map_qual, "*", seq, rec.qual);
+                        made[t]++;
+                    }
+                }
+            };
+            for (size_t r0 = 0; r0 < n; r0 += T * block) {
+                std::vector<std::thread> pool;
+                unsigned used = 0;
+                for (unsigned t = 0; t < T && r0 + t * block < n; t++, used++)
+                    if (t) pool.emplace_back(format_block, t, r0 + t * block, std::min(n, r0 + (t + 1) * block));
+                format_block(0, r0, std::min(n, r0 + block));
+                for (auto &th : pool) th.join();
+                for (unsigned t = 0; t < used; t++) {
+                    sam.append(text[t]);
+                    mapped_locations += made[t];
+                }
+            }
+            read_id = static_cast<unsigned int>(n);
         } else {
             std::string seq;
-            for_each_fastq(sequence_file, [&](const FastqRecord &rec) {
+            for_each_fastq_stream(sequence_file, [&](const FastqRecord &rec) {
                 auto best = filter_best_locations(locate_res[read_id], static_cast<unsigned int>(rec.seq.size()));   // :540
                 if (!best.empty()) {
                     seq.clear();
