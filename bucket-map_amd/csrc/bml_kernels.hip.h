@@ -609,10 +609,16 @@ __global__ __launch_bounds__(kThreads) void bml_replay_heavy_kernel(
                 atomicOr(&exists[at >> 5], 1u << (at & 31u));
             }
             __syncthreads();
-            for_each_pos([&](uint32_t pos, uint32_t) {               // (this sample's words only)
-                starts[pos >> 5] = 0;
-                fresh[pos >> 5] = 0;
-            });
+            if (o1 - o0 >= words / 16u) {
+                // a sample with more than a sixteenth as many occurrences as the bitmaps have words: sweeping both bitmaps is cheaper than
+                // another pass over its occurrences in global memory (fresh follows starts in memory)
+                for (uint32_t i = tid; i < 2u * words; i += kThreads) fresh[i] = 0;
+            } else {
+                for_each_pos([&](uint32_t pos, uint32_t) {           // (this sample's words only)
+                    starts[pos >> 5] = 0;
+                    fresh[pos >> 5] = 0;
+                });
+            }
             if (tid == 0) s_np = np + s_new;
             __syncthreads();
         }
