@@ -57,6 +57,23 @@ def test_many_small_batches_keep_the_order(tmp_path):
     assert (tmp_path / "small.sam").read_bytes() == ref and (tmp_path / "one.sam").read_bytes() == ref
 
 
+def test_pass_order_and_batching_do_not_change_the_sam_file(tmp_path):
+    # the locator's passes beside map() (default) or after it (BM_SERIAL_PASSES=1, the measurement knob), the ramped batches or
+    # fixed ones, one gather thread or many, tiny index chunks: byte-identical SAM
+    from bucket_map_amd import host
+    g = host.Genome.synth(29, [500_000, 40_000])
+    g.write_fasta(str(tmp_path / "g.fa"))
+    host.Reads(g, 8192, 150, 150, 40_000, sub=0.01, seed=13).write_fastq(str(tmp_path / "reads"))
+    common = ["-i", "idx", "--genome", "g.fa", "--bucket-len", "8192", "-r", "150", "-f", "1", "-q", "reads.fastq"]
+    _run(GPU_CLI, [*common, "-o", "default.sam"], tmp_path)
+    _run(GPU_CLI, [*common, "-o", "serial.sam"], tmp_path, env={"BM_SERIAL_PASSES": "1"})
+    _run(GPU_CLI, [*common, "-o", "odd.sam", "--gpus", "0,0"], tmp_path,
+         env={"BM_BATCH_READS": "7001", "BMF_GATHER_THREADS": "5", "BMF_PIECE_WINDOWS": "1111", "BM_IO_BLOCK": "65536"})
+    ref = (tmp_path / "default.sam").read_bytes()
+    assert ref.count(b"\n") > 0.9 * 40_000
+    assert (tmp_path / "serial.sam").read_bytes() == ref and (tmp_path / "odd.sam").read_bytes() == ref
+
+
 def test_long_read_profile_sam_identical(tmp_path):
     # the reference's long-read command line (benchmark/long_read/benchmark_map.sh:25):
     # -s 30 -e 0.9 -n 0.1 -l 12 -p 20 -u 5 on ONT-like reads (sub 0.03, ins = del 0.025), bucket_len 262144
