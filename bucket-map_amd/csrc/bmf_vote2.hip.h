@@ -773,11 +773,19 @@ template <int CPL, int PLANES, int DEPTH>
 __device__ __forceinline__ void vote2_item(const DevParams &P, const uint8_t *__restrict__ rows,
                                            const uint32_t *__restrict__ list, uint32_t item, uint32_t lane, uint32_t bound,
                                            uint32_t *live_chunk, uint32_t *__restrict__ out_counts,
-                                           uint32_t *__restrict__ out_buckets) {
+                                           uint32_t *__restrict__ out_buckets, bool skip_pass1 = false) {
     uint32_t cidx[CPL], coff[CPL];
     bool act[CPL];
     u128 cnt[PLANES][CPL];
     full_width_slots<CPL, PLANES>(P, lane, cidx, coff, act, cnt);
+    if (skip_pass1) {
+        // pass 1 itself sent the item here: more chunks at its lowest level than the recount kernel has lanes (a read in a
+        // satellite or a young repeat).  Its lower bounds would say the same again -- nearly every chunk alive -- so the exact
+        // count at full width comes first and only: S*G rows instead of S*r + S*G.
+        stream_rows<CPL, PLANES, DEPTH, false>(P, rows, list, P.G, coff, act, cnt);
+        emit_best<CPL, PLANES, false>(for_emit<PLANES>(P), cnt, item, lane, cidx, out_counts, out_buckets, nullptr);
+        return;
+    }
     if (!stream_rows<CPL, PLANES, DEPTH, true>(P, rows, list, P.pass1_rows, coff, act, cnt)) {
         if (lane == 0) out_counts[item] = 0;
         return;
@@ -850,7 +858,7 @@ __global__ __launch_bounds__(kWave) void bmf_vote2_slow_kernel(DevParams P, cons
         const uint32_t tag = Q.live_n[item];
         const uint32_t bound = tag != kSlowItem && tag >= kSlowBound ? (tag & 0xFFu) : (1u << PLANES) - 2u;
         vote2_item<CPL, PLANES, DEPTH>(P, rows, row_lists + (size_t)item * P.list_len, item, threadIdx.x, bound, live_chunk,
-                                       out_counts, out_buckets);
+                                       out_counts, out_buckets, tag == kSlowItem);
     }
 }
 
